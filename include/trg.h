@@ -1,0 +1,147 @@
+/*
+ * trg.h -- C ABI of the MI355X (gfx950) path-tracing layer: libtoyraygun_hip.so.
+ *
+ * This is the drop-in boundary of SURVEY.md section 8(b).  The reference (andr3wmac/ToyRaygun)
+ * has no C ABI of its own: its backends are C++ subclasses of toyraygun::Renderer that call a
+ * closed vendor intersector (MPS / DXR).  Each entry point below names the reference interface
+ * it replaces (file:line under the reference tree).  Only plain pointers and sizes cross the
+ * ABI; no exception does; every function returns TRG_OK (0) or a negative error code and
+ * trg_last_error() gives the message.  One context per device, one host thread per context,
+ * all kernels of a context on one HIP stream.
+ */
+#ifndef TRG_H
+#define TRG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRG_OK 0
+#define TRG_ERR_INVALID (-22)  /* bad argument / call order        */
+#define TRG_ERR_NOMEM (-12)    /* device or host allocation failed */
+#define TRG_ERR_DEVICE (-5)    /* HIP runtime error                */
+#define TRG_ERR_NODEV (-19)    /* no usable gfx950 device          */
+#define TRG_ERR_RANGE (-34)    /* scene exceeds a kernel limit (BVH depth, bounce count) */
+
+#define TRG_MATERIAL_DEFAULT 1u  /* src/engine/Renderer.h:16 */
+#define TRG_MATERIAL_EMISSIVE 2u /* src/engine/Renderer.h:17 */
+#define TRG_MAX_BOUNCES 15u      /* Halton dimension 2 + 4*bounce + 3 must stay < 64 */
+
+typedef struct trg_ctx trg_ctx;
+
+/* The 176-byte shader `Uniforms` block: runtime/shaders/common.h:14-34 as laid out by
+ * src/engine/Uniforms.h:19-41 + src/engine/Metal/MetalUniforms.h:16-60.  inv_view_proj is the memory
+ * image of the simd float4x4, i.e. element [col*4+row] = bx row-major invViewProj[row*4+col]. */
+typedef struct trg_uniforms {
+    uint32_t width, height, frameIndex, _pad;
+    float cam_pos[4];
+    float inv_view_proj[16];
+    float light_pos[4], light_forward[4], light_right[4], light_up[4], light_color[4];
+} trg_uniforms;
+
+/* runtime/shaders/metal/Raytracing.metal:21-28 (48 B) and :31-38 (16 B) */
+typedef struct trg_ray {
+    float origin[3];
+    uint32_t mask;
+    float direction[3];
+    float maxDistance;
+    float color[4];
+} trg_ray;
+typedef struct trg_isect {
+    float distance;          /* < 0: miss or inactive ray */
+    int32_t primitiveIndex;  /* index into the ORIGINAL triangle order; -1 on miss */
+    float coordinates[2];    /* barycentric weights of vertex 0 and vertex 1 */
+} trg_isect;
+
+typedef struct trg_stats {
+    /* ray counts accumulated over every trg_render since create / trg_reset_stats.  A ray is
+     * counted iff it is actually traversed: primary rays, bounce rays (nearest-hit, bounce >= 1)
+     * and shadow rays (any-hit) submitted with maxDistance >= 0. */
+    uint64_t primary_rays, bounce_rays, shadow_rays, shaded_hits;
+    /* filled only while TRG_OPT_COUNTERS is on: 64-byte node fetches (= 2 BVH2-equivalent boxes
+     * each) and ray/triangle tests */
+    uint64_t node_fetches, tri_tests;
+    double last_render_ms;  /* HIP-event time of the kernels of the last trg_render, on its stream */
+    double total_render_ms; /* sum over renders since reset */
+    uint32_t renders;       /* trg_render calls since reset */
+    uint32_t bvh_nodes, bvh_depth, bvh_leaves, scene_in_lds, lds_bytes;
+    uint64_t scene_bytes;   /* bytes of nodes + triangle records + attributes on the device */
+} trg_stats;
+
+enum trg_option {
+    TRG_OPT_STRICT = 1,       /* 1: run the -ffp-contract=off kernels that match the oracle bit for bit (debug/parity); 0 (default): fast kernels */
+    TRG_OPT_COUNTERS = 2,     /* 1: count node fetches / triangle tests (slower) */
+    TRG_OPT_FORCE_GLOBAL = 3, /* 1: keep the scene in HBM even if it would fit in LDS */
+    TRG_OPT_TIMING = 4        /* 1 (default): bracket trg_render with HIP events (forces a stream sync) */
+};
+
+/* --- lifetime: replaces MetalRenderer::init / resize (src/engine/Metal/MetalRenderer.mm:282-338,557-574):
+ *     allocates the float4 accumulation target and the per-pixel Halton-offset texture. */
+int trg_create(trg_ctx **out, int device, uint32_t width, uint32_t height);
+void trg_destroy(trg_ctx *ctx);
+const char *trg_last_error(trg_ctx *ctx); /* ctx may be NULL: error of the last failed trg_create */
+
+/* --- scene upload + acceleration-structure build: replaces MetalRenderer::loadScene
+ *     (MetalRenderer.mm:204-280), i.e. the five memcpy at :245-249 and the MPS
+ *     MPSTriangleAccelerationStructure rebuild at :272-279.  Buffers are the five public vectors of
+ *     toyraygun::Scene (src/engine/Scene.h:25-29) with bx::Vec3 = 3 packed floats: positions3 has
+ *     n_verts entries and is addressed through indices (3*n_tris entries); normals3 / colors3 have
+ *     3*n_tris entries addressed as [triangle*3 + corner] (Raytracing.metal:104-108); material_ids has
+ *     n_tris entries and doubles as the per-primitive ray mask (MetalRenderer.mm:276).  In the
+ *     reference n_verts == 3*n_tris and indices is the identity.  All inputs are copied; nothing is
+ *     retained. */
+int trg_load_scene(trg_ctx *ctx, const float *positions3, const float *normals3, const float *colors3,
+                   const uint32_t *indices, const uint32_t *material_ids, uint32_t n_verts, uint32_t n_tris);
+
+/* --- per-frame uniforms: replaces MetalRenderer updateUniforms (MetalRenderer.mm:340-371).
+ *     frameIndex in the struct is ignored by trg_render (it iterates its own range). */
+int trg_set_uniforms(trg_ctx *ctx, const trg_uniforms *u);
+
+/* --- per-pixel Halton index offsets: replaces the R32Uint random texture filled by
+ *     Texture::generateRandomTexture (src/engine/Texture.cpp:16-29; MetalRenderer.mm:315-335). */
+int trg_set_pixel_offsets(trg_ctx *ctx, const uint32_t *offsets /* width*height, host */);
+int trg_set_pixel_offsets_seed(trg_ctx *ctx, uint32_t seed); /* offset(x,y) = pcg_hash32(seed ^ (y*w+x)) on the device */
+
+/* --- the hot path: replaces the body of MetalRenderer render: (MetalRenderer.mm:400-515): raygen, then
+ *     `bounces` x [nearest-hit, primaryHit, any-hit, shadowHit], then accumulate, for frames
+ *     frameIndexBegin .. frameIndexBegin+spp-1 over image rows [row0, row0+rows), in ONE launch.
+ *     Result: running average in the float4 accumulation buffer (row 0 = scene bottom).  If
+ *     frameIndexBegin > 0 the buffer must hold the average of frames [0, frameIndexBegin). */
+int trg_render(trg_ctx *ctx, uint32_t frameIndexBegin, uint32_t spp, uint32_t bounces, uint32_t row0, uint32_t rows);
+
+/* --- read back the accumulation target (what the reference hands to its blit pass,
+ *     MetalRenderer.mm:538): width*height*4 floats, host memory. */
+int trg_read_accum(trg_ctx *ctx, float *rgba);
+
+int trg_get_stats(trg_ctx *ctx, trg_stats *out);
+int trg_reset_stats(trg_ctx *ctx);
+int trg_set_option(trg_ctx *ctx, int option, int64_t value);
+
+/* --- plumbing for multi-GPU / framework interop (no reference equivalent) */
+int trg_bind_accum(trg_ctx *ctx, void *device_ptr); /* use caller-owned device memory (width*height*16 B) as the accumulation buffer; NULL restores the internal one */
+int trg_accum_device_ptr(trg_ctx *ctx, void **out);
+int trg_set_stream(trg_ctx *ctx, void *hip_stream); /* NULL = the context's own stream */
+int trg_sync(trg_ctx *ctx);
+
+/* --- stage-level entry points used by the parity tests (each isolates one SURVEY 8a row) */
+/* a7 / a12: the intersector alone.  any_hit=0: out = trg_isect[n]; any_hit=1: out = float[n] distance (<0: unoccluded). */
+int trg_trace(trg_ctx *ctx, const trg_ray *rays, size_t n, int any_hit, void *out);
+/* a5: halton(i[k], d[k]) */
+int trg_halton(trg_ctx *ctx, const uint32_t *i, const uint32_t *d, size_t n, float *out);
+/* a6: primary rays of one frame for the whole image (width*height trg_ray) */
+int trg_raygen(trg_ctx *ctx, uint32_t frameIndex, trg_ray *out);
+/* a10/a11: out[k] = {dir.xyz, dist, color.xyz, 0, bounce_dir.xyz, 0} for hit point p[k], unit normal n[k],
+ * random pairs r[k] = (r0,r1,r2,r3) */
+int trg_sample(trg_ctx *ctx, const float *p3, const float *n3, const float *r4, size_t n, float *out12);
+
+/* --- N1: ACES tonemap + sRGB of the accumulation buffer to RGBA8 (PostProcessing.metal:44-57;
+ *     common.h:36-43,163-171).  flip_y != 0 writes the top image row first (PNG order). */
+int trg_postprocess(trg_ctx *ctx, uint8_t *rgba8, int flip_y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRG_H */

@@ -1,0 +1,98 @@
+"""Builds the in-tree native libraries with hipcc (gfx950 only):
+
+  toyraygun_amd/lib/libtoyraygun_hip.so   HIP kernels + the C ABI of include/trg.h
+  toyraygun_amd/lib/libtoyraygun.so       host C++ plugin surface (Engine/Renderer/Scene/HipRenderer)
+  toyraygun_amd/lib/toyraygun_cornell     demo app following the reference main.cpp call order
+
+hipcc cross-compiles without a GPU.  The .so files are git-ignored but travel to the GPU box.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+HOST = os.path.join(CSRC, "host")
+LIB = os.path.join(HERE, "lib")
+OBJ = os.path.join(HERE, "build")
+ROOT = os.path.dirname(HERE)
+ARCH = "gfx950"
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: the HIP extension cannot be built")
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd, verbose):
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def _glob(d, exts):
+    return sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith(exts)) if os.path.isdir(d) else []
+
+
+def build(force=False, verbose=False):
+    os.makedirs(LIB, exist_ok=True)
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = _hipcc()
+    headers = _glob(CSRC, (".h",)) + _glob(os.path.join(ROOT, "include"), (".h",)) + \
+        _glob(os.path.join(ROOT, "include", "toyraygun"), (".h",)) + _glob(os.path.join(ROOT, "include", "bx"), (".h",)) + \
+        _glob(HOST, (".h",)) + [os.path.abspath(__file__)]
+    common = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include")]
+    dev = ["--offload-arch=" + ARCH]
+
+    objs = []
+    units = [
+        ("trg_kernels_fast.o", os.path.join(CSRC, "trg_kernels.hip"), dev + ["-DTRG_STRICT=0"]),
+        ("trg_kernels_strict.o", os.path.join(CSRC, "trg_kernels.hip"), dev + ["-DTRG_STRICT=1", "-ffp-contract=off"]),
+        ("trg_capi.o", os.path.join(CSRC, "trg_capi.cpp"), ["-x", "hip", "--offload-arch=" + ARCH]),
+        ("bvh_build.o", os.path.join(CSRC, "bvh_build.cpp"), ["-x", "hip", "--offload-arch=" + ARCH]),
+    ]
+    for name, src, extra in units:
+        o = os.path.join(OBJ, name)
+        if force or _newer(o, [src] + headers):
+            _run([hipcc] + common + extra + ["-c", src, "-o", o], verbose)
+        objs.append(o)
+    hip_so = os.path.join(LIB, "libtoyraygun_hip.so")
+    if force or _newer(hip_so, objs):
+        _run([hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", hip_so] + objs, verbose)
+
+    # host C++ plugin surface (pure host code; links against the C ABI only)
+    host_srcs = _glob(HOST, (".cpp",))
+    host_so = os.path.join(LIB, "libtoyraygun.so")
+    if host_srcs:
+        hobjs = []
+        for src in host_srcs:
+            if os.path.basename(src) == "main_cornell.cpp":
+                continue
+            o = os.path.join(OBJ, "host_" + os.path.basename(src)[:-4] + ".o")
+            if force or _newer(o, [src] + headers):
+                _run(["g++"] + common + ["-fno-exceptions", "-fno-rtti", "-c", src, "-o", o], verbose)
+            hobjs.append(o)
+        if force or _newer(host_so, hobjs + [hip_so]):
+            _run(["g++", "-shared", "-fPIC", "-o", host_so] + hobjs +
+                 ["-L" + LIB, "-ltoyraygun_hip", "-Wl,-rpath,$ORIGIN"], verbose)
+        app_src = os.path.join(HOST, "main_cornell.cpp")
+        app = os.path.join(LIB, "toyraygun_cornell")
+        if os.path.exists(app_src) and (force or _newer(app, [app_src, host_so] + headers)):
+            _run(["g++"] + common + ["-fno-exceptions", "-fno-rtti", app_src, "-o", app, "-L" + LIB,
+                                     "-ltoyraygun", "-ltoyraygun_hip", "-Wl,-rpath,$ORIGIN"], verbose)
+    return hip_so
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)
+    print("built", LIB)

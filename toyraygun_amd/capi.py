@@ -1,0 +1,234 @@
+"""ctypes binding of the C ABI in include/trg.h (libtoyraygun_hip.so).
+
+This is the only way Python reaches the renderer: there is no Python or CPU fallback.  Loading fails
+loudly (ImportError/OSError) when the HIP library has not been built, and trg_create fails loudly
+when no gfx950 device is visible.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+HIP_SO = os.path.join(LIB_DIR, "libtoyraygun_hip.so")
+
+OK = 0
+ERR_INVALID, ERR_NOMEM, ERR_DEVICE, ERR_NODEV, ERR_RANGE = -22, -12, -5, -19, -34
+OPT_STRICT, OPT_COUNTERS, OPT_FORCE_GLOBAL, OPT_TIMING = 1, 2, 3, 4
+MATERIAL_DEFAULT, MATERIAL_EMISSIVE = 1, 2
+MAX_BOUNCES = 15
+SEED_OFFSETS = 0x5EED0001
+
+
+class Uniforms(C.Structure):
+    """trg_uniforms: the 176-byte shader Uniforms block (runtime/shaders/common.h:14-34)."""
+    _fields_ = [
+        ("width", C.c_uint32), ("height", C.c_uint32), ("frameIndex", C.c_uint32), ("_pad", C.c_uint32),
+        ("cam_pos", C.c_float * 4),
+        ("inv_view_proj", C.c_float * 16),
+        ("light_pos", C.c_float * 4), ("light_forward", C.c_float * 4), ("light_right", C.c_float * 4),
+        ("light_up", C.c_float * 4), ("light_color", C.c_float * 4),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("primary_rays", C.c_uint64), ("bounce_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("shaded_hits", C.c_uint64),
+        ("node_fetches", C.c_uint64), ("tri_tests", C.c_uint64),
+        ("last_render_ms", C.c_double), ("total_render_ms", C.c_double),
+        ("renders", C.c_uint32), ("bvh_nodes", C.c_uint32), ("bvh_depth", C.c_uint32), ("bvh_leaves", C.c_uint32),
+        ("scene_in_lds", C.c_uint32), ("lds_bytes", C.c_uint32),
+        ("scene_bytes", C.c_uint64),
+    ]
+
+    @property
+    def rays(self):
+        return self.primary_rays + self.bounce_rays + self.shadow_rays
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+RAY_DTYPE = np.dtype([("origin", "<f4", 3), ("mask", "<u4"), ("direction", "<f4", 3),
+                      ("maxDistance", "<f4"), ("color", "<f4", 4)])
+ISECT_DTYPE = np.dtype([("distance", "<f4"), ("primitiveIndex", "<i4"), ("coordinates", "<f4", 2)])
+assert C.sizeof(Uniforms) == 176 and RAY_DTYPE.itemsize == 48 and ISECT_DTYPE.itemsize == 16
+
+# every symbol include/trg.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+_SYMBOLS = [
+    ("trg_create", C.c_int, [C.POINTER(_P), C.c_int, C.c_uint32, C.c_uint32]),
+    ("trg_destroy", None, [_P]),
+    ("trg_last_error", C.c_char_p, [_P]),
+    ("trg_load_scene", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint32, C.c_uint32]),
+    ("trg_set_uniforms", C.c_int, [_P, C.POINTER(Uniforms)]),
+    ("trg_set_pixel_offsets", C.c_int, [_P, _P]),
+    ("trg_set_pixel_offsets_seed", C.c_int, [_P, C.c_uint32]),
+    ("trg_render", C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    ("trg_read_accum", C.c_int, [_P, _P]),
+    ("trg_get_stats", C.c_int, [_P, C.POINTER(Stats)]),
+    ("trg_reset_stats", C.c_int, [_P]),
+    ("trg_set_option", C.c_int, [_P, C.c_int, C.c_int64]),
+    ("trg_bind_accum", C.c_int, [_P, _P]),
+    ("trg_accum_device_ptr", C.c_int, [_P, C.POINTER(_P)]),
+    ("trg_set_stream", C.c_int, [_P, _P]),
+    ("trg_sync", C.c_int, [_P]),
+    ("trg_trace", C.c_int, [_P, _P, C.c_size_t, C.c_int, _P]),
+    ("trg_halton", C.c_int, [_P, _P, _P, C.c_size_t, _P]),
+    ("trg_raygen", C.c_int, [_P, C.c_uint32, _P]),
+    ("trg_sample", C.c_int, [_P, _P, _P, _P, C.c_size_t, _P]),
+    ("trg_postprocess", C.c_int, [_P, _P, C.c_int]),
+]
+SYMBOL_NAMES = [s[0] for s in _SYMBOLS]
+
+_lib = None
+
+
+def load():
+    """dlopen libtoyraygun_hip.so and bind every symbol of include/trg.h.  No fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(HIP_SO):
+            raise ImportError(
+                "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  toyraygun_amd has no CPU fallback." % HIP_SO)
+        L = C.CDLL(HIP_SO, mode=C.RTLD_GLOBAL)
+        for name, res, args in _SYMBOLS:
+            fn = getattr(L, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class TrgError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "trg error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _ptr(a):
+    return a.ctypes.data if a is not None else None
+
+
+class Context:
+    """One rendering context on one GPU (trg_ctx)."""
+
+    def __init__(self, width, height, device=0):
+        self.L = load()
+        self.w, self.h = int(width), int(height)
+        self.device = device
+        h = _P()
+        rc = self.L.trg_create(C.byref(h), device, self.w, self.h)
+        if rc != OK:
+            raise TrgError(rc, (self.L.trg_last_error(None) or b"").decode())
+        self.h_ctx = h
+
+    def close(self):
+        if getattr(self, "h_ctx", None):
+            self.L.trg_destroy(self.h_ctx)
+            self.h_ctx = None
+
+    __del__ = close
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise TrgError(rc, (self.L.trg_last_error(self.h_ctx) or b"").decode())
+
+    # ---- scene / uniforms / offsets ----
+    def load_scene(self, positions, normals, colors, indices, material_ids):
+        pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+        nrm = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+        col = np.ascontiguousarray(colors, np.float32).reshape(-1, 3)
+        idx = np.ascontiguousarray(indices, np.uint32).reshape(-1)
+        mat = np.ascontiguousarray(material_ids, np.uint32).reshape(-1)
+        nt = mat.shape[0]
+        if idx.shape[0] != 3 * nt or nrm.shape[0] != 3 * nt or col.shape[0] != 3 * nt:
+            raise ValueError("expected 3*n_tris indices/normals/colors for %d triangles" % nt)
+        self._chk(self.L.trg_load_scene(self.h_ctx, _ptr(pos), _ptr(nrm), _ptr(col), _ptr(idx), _ptr(mat), pos.shape[0], nt))
+
+    def set_uniforms(self, u):
+        if not isinstance(u, Uniforms):
+            raw = bytes(u) if not isinstance(u, (bytes, bytearray)) else u
+            if len(raw) != 176:
+                raise ValueError("uniforms must be 176 bytes")
+            u = Uniforms.from_buffer_copy(raw)
+        self._chk(self.L.trg_set_uniforms(self.h_ctx, C.byref(u)))
+
+    def set_pixel_offsets(self, offsets):
+        off = np.ascontiguousarray(offsets, np.uint32).reshape(-1)
+        if off.shape[0] != self.w * self.h:
+            raise ValueError("offsets must have width*height entries")
+        self._chk(self.L.trg_set_pixel_offsets(self.h_ctx, _ptr(off)))
+
+    def set_pixel_offsets_seed(self, seed=SEED_OFFSETS):
+        self._chk(self.L.trg_set_pixel_offsets_seed(self.h_ctx, seed))
+
+    def set_option(self, opt, value):
+        self._chk(self.L.trg_set_option(self.h_ctx, opt, int(value)))
+
+    # ---- the hot path ----
+    def render(self, frame_begin, spp, bounces, row0=0, rows=None):
+        rows = self.h - row0 if rows is None else rows
+        self._chk(self.L.trg_render(self.h_ctx, frame_begin, spp, bounces, row0, rows))
+
+    def read_accum(self):
+        out = np.empty((self.h, self.w, 4), np.float32)
+        self._chk(self.L.trg_read_accum(self.h_ctx, _ptr(out)))
+        return out
+
+    def stats(self):
+        st = Stats()
+        self._chk(self.L.trg_get_stats(self.h_ctx, C.byref(st)))
+        return st
+
+    def reset_stats(self):
+        self._chk(self.L.trg_reset_stats(self.h_ctx))
+
+    def sync(self):
+        self._chk(self.L.trg_sync(self.h_ctx))
+
+    def bind_accum(self, device_ptr):
+        self._chk(self.L.trg_bind_accum(self.h_ctx, device_ptr))
+
+    def accum_device_ptr(self):
+        p = _P()
+        self._chk(self.L.trg_accum_device_ptr(self.h_ctx, C.byref(p)))
+        return p.value
+
+    def set_stream(self, hip_stream):
+        self._chk(self.L.trg_set_stream(self.h_ctx, hip_stream))
+
+    # ---- stage-level entry points ----
+    def trace(self, rays, any_hit=False):
+        rays = np.ascontiguousarray(rays, RAY_DTYPE)
+        n = rays.shape[0]
+        out = np.zeros(n, np.float32 if any_hit else ISECT_DTYPE)
+        self._chk(self.L.trg_trace(self.h_ctx, _ptr(rays), n, 1 if any_hit else 0, _ptr(out)))
+        return out
+
+    def halton(self, i, d):
+        i = np.ascontiguousarray(i, np.uint32).reshape(-1)
+        d = np.ascontiguousarray(d, np.uint32).reshape(-1)
+        out = np.zeros(i.shape[0], np.float32)
+        self._chk(self.L.trg_halton(self.h_ctx, _ptr(i), _ptr(d), i.shape[0], _ptr(out)))
+        return out
+
+    def raygen(self, frame_index):
+        out = np.zeros(self.w * self.h, RAY_DTYPE)
+        self._chk(self.L.trg_raygen(self.h_ctx, frame_index, _ptr(out)))
+        return out
+
+    def sample(self, p, n, r):
+        p = np.ascontiguousarray(p, np.float32).reshape(-1, 3)
+        n = np.ascontiguousarray(n, np.float32).reshape(-1, 3)
+        r = np.ascontiguousarray(r, np.float32).reshape(-1, 4)
+        out = np.zeros((p.shape[0], 12), np.float32)
+        self._chk(self.L.trg_sample(self.h_ctx, _ptr(p), _ptr(n), _ptr(r), p.shape[0], _ptr(out)))
+        return out
+
+    def postprocess(self, flip_y=True):
+        out = np.empty((self.h, self.w, 4), np.uint8)
+        self._chk(self.L.trg_postprocess(self.h_ctx, _ptr(out), 1 if flip_y else 0))
+        return out

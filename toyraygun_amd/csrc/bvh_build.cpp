@@ -1,0 +1,219 @@
+// bvh_build.cpp -- binned-SAH BVH2 builder, flattened into the "two child boxes per node" layout the
+// gfx950 traversal kernel reads with four 16-byte loads (see bvh_build.h).
+#include "bvh_build.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace trg {
+namespace {
+
+constexpr int kBins = 16;
+constexpr uint32_t kMaxLeaf = 4;     // leaf encoding allows 8
+constexpr uint32_t kSahDepthCap = 24; // below this depth switch to balanced median splits
+constexpr float kInf = std::numeric_limits<float>::infinity();
+
+struct Box {
+    float lo[3] = { kInf, kInf, kInf }, hi[3] = { -kInf, -kInf, -kInf };
+    void grow(const float *p) { for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); } }
+    void grow(const Box &b) { for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], b.lo[a]); hi[a] = std::max(hi[a], b.hi[a]); } }
+    float half_area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (!(dx >= 0.f) || !(dy >= 0.f) || !(dz >= 0.f)) return 0.f;
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct Prim { Box b; float c[3]; uint32_t id; };
+
+struct BuildNode {
+    Box box;
+    int32_t child[2] = { -1, -1 };  // build-node indices, or -1
+    uint32_t first = 0, count = 0;  // leaf range in prims[]
+    bool leaf = false;
+};
+
+struct Builder {
+    std::vector<Prim> prims;
+    std::vector<BuildNode> nodes;
+    uint32_t depth = 0, leaves = 0, max_leaf = 0;
+
+    int32_t make_leaf(const Box &box, uint32_t first, uint32_t count, uint32_t d) {
+        BuildNode n; n.box = box; n.first = first; n.count = count; n.leaf = true;
+        nodes.push_back(n);
+        depth = std::max(depth, d); ++leaves; max_leaf = std::max(max_leaf, count);
+        return (int32_t)nodes.size() - 1;
+    }
+
+    int32_t build(uint32_t first, uint32_t count, uint32_t d) {
+        Box box, cbox;
+        for (uint32_t i = 0; i < count; ++i) { box.grow(prims[first + i].b); cbox.grow(prims[first + i].c); }
+        if (count <= 1) return make_leaf(box, first, count, d);
+
+        int axis = 0;
+        float ext[3] = { cbox.hi[0] - cbox.lo[0], cbox.hi[1] - cbox.lo[1], cbox.hi[2] - cbox.lo[2] };
+        if (ext[1] > ext[axis]) axis = 1;
+        if (ext[2] > ext[axis]) axis = 2;
+
+        uint32_t mid = 0;
+        bool have_split = false;
+        if (d < kSahDepthCap && ext[axis] > 0.f) {
+            // binned SAH over all three axes
+            float best_cost = kInf; int best_axis = -1, best_bin = -1;
+            for (int a = 0; a < 3; ++a) {
+                if (!(ext[a] > 0.f)) continue;
+                Box bb[kBins]; uint32_t bc[kBins] = { 0 };
+                const float scale = (float)kBins / ext[a];
+                for (uint32_t i = 0; i < count; ++i) {
+                    const Prim &p = prims[first + i];
+                    int b = std::min(kBins - 1, std::max(0, (int)((p.c[a] - cbox.lo[a]) * scale)));
+                    bb[b].grow(p.b); ++bc[b];
+                }
+                float right_area[kBins]; uint32_t right_cnt[kBins];
+                Box acc; uint32_t cnt = 0;
+                for (int b = kBins - 1; b > 0; --b) { acc.grow(bb[b]); cnt += bc[b]; right_area[b] = acc.half_area(); right_cnt[b] = cnt; }
+                acc = Box(); cnt = 0;
+                for (int b = 0; b < kBins - 1; ++b) {
+                    acc.grow(bb[b]); cnt += bc[b];
+                    if (cnt == 0 || right_cnt[b + 1] == 0) continue;
+                    float cost = acc.half_area() * (float)cnt + right_area[b + 1] * (float)right_cnt[b + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; }
+                }
+            }
+            if (best_axis >= 0) {
+                const float leaf_cost = box.half_area() * (float)count;
+                // node traversal cost 1 box-pair test ~ 1.2 triangle tests
+                const float split_cost = 1.2f * box.half_area() + best_cost;
+                if (count <= kMaxLeaf && leaf_cost <= split_cost) return make_leaf(box, first, count, d);
+                const float scale = (float)kBins / ext[best_axis];
+                const float lo = cbox.lo[best_axis];
+                auto it = std::partition(prims.begin() + first, prims.begin() + first + count, [&](const Prim &p) {
+                    int b = std::min(kBins - 1, std::max(0, (int)((p.c[best_axis] - lo) * scale)));
+                    return b <= best_bin;
+                });
+                mid = (uint32_t)(it - (prims.begin() + first));
+                have_split = mid > 0 && mid < count;
+            }
+        }
+        if (!have_split) {
+            if (count <= kMaxLeaf && (ext[axis] <= 0.f || d >= kSahDepthCap)) return make_leaf(box, first, count, d);
+            // balanced median split (also the fallback for coincident centroids)
+            mid = count / 2;
+            std::nth_element(prims.begin() + first, prims.begin() + first + mid, prims.begin() + first + count,
+                             [axis](const Prim &a, const Prim &b) {
+                                 if (a.c[axis] != b.c[axis]) return a.c[axis] < b.c[axis];
+                                 return a.id < b.id;
+                             });
+        }
+        const int32_t me = (int32_t)nodes.size();
+        nodes.emplace_back();
+        nodes[me].box = box;
+        const int32_t l = build(first, mid, d + 1);
+        const int32_t r = build(first + mid, count - mid, d + 1);
+        nodes[me].child[0] = l; nodes[me].child[1] = r;
+        return me;
+    }
+};
+
+inline float bits_f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+
+}  // namespace
+
+void build_bvh(const float *pos, const uint32_t *idx, const uint32_t *masks, uint32_t ntris, Bvh &out) {
+    Builder B;
+    B.prims.resize(ntris);
+    Box scene;
+    for (uint32_t k = 0; k < ntris; ++k) {
+        Prim &p = B.prims[k];
+        p.id = k;
+        for (int j = 0; j < 3; ++j) p.b.grow(&pos[(size_t)idx[k * 3 + j] * 3]);
+        for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * (p.b.lo[a] + p.b.hi[a]);
+        scene.grow(p.b);
+    }
+    B.nodes.reserve((size_t)ntris * 2 + 2);
+    int32_t root = ntris ? B.build(0, ntris, 0) : -1;
+
+    // Conservative padding: the slab test and the triangle test round differently; every box is
+    // widened by far more than that so a triangle the Moeller-Trumbore test accepts is always reached.
+    float diag = 0.f;
+    if (ntris) diag = std::max({ scene.hi[0] - scene.lo[0], scene.hi[1] - scene.lo[1], scene.hi[2] - scene.lo[2] });
+    const float pad = 2e-5f * std::max(diag, 1e-3f);
+
+    // ---- flatten: inner build nodes become device nodes, in depth-first order ----
+    std::vector<int32_t> dev_index(B.nodes.size(), -1);
+    uint32_t n_inner = 0;
+    // if the root is a leaf (or the scene is empty) synthesise an inner root
+    const bool synth_root = (root < 0) || B.nodes[root].leaf;
+    {
+        std::vector<int32_t> st;
+        if (!synth_root) st.push_back(root);
+        while (!st.empty()) {
+            int32_t n = st.back(); st.pop_back();
+            dev_index[n] = (int32_t)n_inner++;
+            // push right first so that the left child is laid out right after its parent
+            for (int c = 1; c >= 0; --c) { int32_t ch = B.nodes[n].child[c]; if (ch >= 0 && !B.nodes[ch].leaf) st.push_back(ch); }
+        }
+    }
+    out.n_nodes = synth_root ? 1 : n_inner;
+    out.nodes.assign((size_t)out.n_nodes * 4, F4{ 0, 0, 0, 0 });
+    out.tris.resize((size_t)ntris * 3);
+    out.n_leaves = B.leaves; out.depth = B.depth + (synth_root ? 1 : 0); out.max_leaf = B.max_leaf;
+
+    // triangle records in leaf (prims[]) order
+    for (uint32_t i = 0; i < ntris; ++i) {
+        const uint32_t k = B.prims[i].id;
+        const float *a = &pos[(size_t)idx[k * 3 + 0] * 3], *b = &pos[(size_t)idx[k * 3 + 1] * 3], *c = &pos[(size_t)idx[k * 3 + 2] * 3];
+        out.tris[(size_t)i * 3 + 0] = F4{ a[0], a[1], a[2], bits_f(k) };
+        out.tris[(size_t)i * 3 + 1] = F4{ b[0] - a[0], b[1] - a[1], b[2] - a[2], bits_f(masks[k]) };
+        out.tris[(size_t)i * 3 + 2] = F4{ c[0] - a[0], c[1] - a[1], c[2] - a[2], 0.f };
+    }
+
+    auto padded = [&](Box b) { for (int a = 0; a < 3; ++a) { b.lo[a] -= pad; b.hi[a] += pad; } return b; };
+    auto leaf_ref = [](uint32_t first, uint32_t count) { return ~(int32_t)((first << 3) | (count - 1)); };
+    auto put = [&](uint32_t di, const Box &b0, int32_t r0, const Box &b1, int32_t r1) {
+        F4 *n = &out.nodes[(size_t)di * 4];
+        n[0] = F4{ b0.lo[0], b0.hi[0], b0.lo[1], b0.hi[1] };
+        n[1] = F4{ b1.lo[0], b1.hi[0], b1.lo[1], b1.hi[1] };
+        n[2] = F4{ b0.lo[2], b0.hi[2], b1.lo[2], b1.hi[2] };
+        n[3] = F4{ bits_f((uint32_t)r0), bits_f((uint32_t)r1), 0.f, 0.f };
+    };
+    auto child_ref = [&](int32_t ch, Box &box) -> int32_t {
+        const BuildNode &n = B.nodes[ch];
+        box = padded(n.box);
+        return n.leaf ? leaf_ref(n.first, n.count) : dev_index[ch];
+    };
+    if (synth_root) {
+        // The kernel always starts at an inner node.  A scene that is a single leaf gets a root whose
+        // two children split that leaf (a 1-triangle scene lists the triangle twice: harmless, the
+        // tie-break keeps the first); an empty scene gets one never-matching record (mask 0).
+        if (ntris == 0) {
+            out.tris.assign(3, F4{ 0, 0, 0, 0 });
+            Box z; const float o[3] = { 0, 0, 0 }; z.grow(o);
+            put(0, z, leaf_ref(0, 1), z, leaf_ref(0, 1));
+        } else {
+            const Box b = padded(B.nodes[root].box);
+            const uint32_t n0 = (ntris + 1) / 2, n1 = ntris - n0;
+            put(0, b, leaf_ref(0, n0), b, n1 ? leaf_ref(n0, n1) : leaf_ref(0, n0));
+        }
+    } else {
+        for (size_t n = 0; n < B.nodes.size(); ++n) {
+            if (dev_index[n] < 0) continue;
+            Box b0, b1;
+            const int32_t r0 = child_ref(B.nodes[n].child[0], b0), r1 = child_ref(B.nodes[n].child[1], b1);
+            put((uint32_t)dev_index[n], b0, r0, b1, r1);
+        }
+    }
+
+    // SAH cost (reporting only)
+    double cost = 0.0;
+    if (!synth_root) {
+        const double ra = B.nodes[root].box.half_area();
+        if (ra > 0)
+            for (const BuildNode &n : B.nodes) cost += (n.leaf ? (double)n.count : 1.2) * n.box.half_area() / ra;
+    }
+    out.sah_cost = cost;
+}
+
+}  // namespace trg

@@ -1,0 +1,35 @@
+// bvh_build.h -- host-side acceleration-structure build for the HIP intersector.
+//
+// Replaces what the reference delegates to closed vendor code:
+// MPSTriangleAccelerationStructure rebuild (src/engine/Metal/MetalRenderer.mm:272-279) /
+// DXR BuildRaytracingAccelerationStructure (src/engine/D3D12/D3D12Renderer.cpp:285-391).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace trg {
+
+struct F4 { float x, y, z, w; };
+
+// Device layout (see DESIGN.md "Data layout in HBM"):
+//  node i = 4 x float4 (64 B, one coalesced line half):
+//    n[0] = (c0.lo.x, c0.hi.x, c0.lo.y, c0.hi.y)
+//    n[1] = (c1.lo.x, c1.hi.x, c1.lo.y, c1.hi.y)
+//    n[2] = (c0.lo.z, c0.hi.z, c1.lo.z, c1.hi.z)
+//    n[3] = (bits child0, bits child1, 0, 0)   child >= 0: inner node index
+//                                               child <  0: leaf, ~child = (firstTri << 3) | (count-1)
+//  every node has two children; the root is always an inner node (bvh_build.cpp synthesises one).
+//  triangle record k (leaf order) = 3 x float4 (48 B):
+//    t[0] = (v0.xyz, bits primitiveIndex)  t[1] = (e1.xyz, bits mask)  t[2] = (e2.xyz, 0)
+struct Bvh {
+    std::vector<F4> nodes;  // 4 per node
+    std::vector<F4> tris;   // 3 per triangle
+    uint32_t n_nodes = 0, n_leaves = 0, depth = 0, max_leaf = 0;
+    double sah_cost = 0.0;
+};
+
+// positions3: nverts*3 floats; indices: ntris*3; masks: ntris (the reference's materialID buffer,
+// MetalRenderer.mm:276).  Deterministic for a given input.
+void build_bvh(const float *positions3, const uint32_t *indices, const uint32_t *masks, uint32_t ntris, Bvh &out);
+
+}  // namespace trg

@@ -1,0 +1,414 @@
+// trg_capi.cpp -- the C ABI of include/trg.h: context, scene upload + BVH build, launches, stats.
+// Host-only C++ (HIP runtime API); the kernels live in trg_kernels.hip.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/trg.h"
+#include "bvh_build.h"
+#include "trg_kernels.h"
+
+using namespace trg;
+
+struct trg_ctx {
+    int device = 0;
+    uint32_t w = 0, h = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float *accum_own = nullptr, *accum = nullptr;
+    uint32_t *offsets = nullptr;
+    unsigned long long *counters = nullptr;
+    unsigned char *blob = nullptr;
+    SceneDesc sc{};
+    bool scene_loaded = false, have_uniforms = false, have_offsets = false;
+    trg_uniforms u{};
+    bool opt_strict = false, opt_counters = false, opt_force_global = false, opt_timing = true;
+    uint32_t bvh_nodes = 0, bvh_depth = 0, bvh_leaves = 0;
+    double last_ms = 0.0, total_ms = 0.0;
+    uint32_t renders = 0;
+    std::string err;
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(trg_ctx *c, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_err = buf;
+    return code;
+}
+#define HIPCHK(c, expr)                                                                                    \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) return fail((c), TRG_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+static inline uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
+
+struct LdsPlan { bool lds_scene; uint32_t stack_off, red_off, total; };
+static int plan_lds(trg_ctx *c, LdsPlan &p) {
+    const uint32_t levels = c->bvh_depth + 2;
+    p.lds_scene = !c->opt_force_global && c->sc.blob_bytes <= kMaxLdsScene;
+    p.stack_off = p.lds_scene ? align16(c->sc.blob_bytes) : 0u;
+    p.red_off = p.stack_off + levels * kBlock * 4u;
+    p.total = p.red_off + 4u * 8u * 4u;
+    if (p.total > 64u * 1024u)
+        return fail(c, TRG_ERR_RANGE, "BVH depth %u needs %u B of LDS per workgroup (limit 65536)", c->bvh_depth, p.total);
+    return TRG_OK;
+}
+
+extern "C" {
+
+const char *trg_last_error(trg_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int trg_create(trg_ctx **out, int device, uint32_t width, uint32_t height) {
+    if (!out || width == 0 || height == 0 || (uint64_t)width * height > 0x7FFFFFFFull)
+        return fail(nullptr, TRG_ERR_INVALID, "trg_create: bad arguments (%ux%u)", width, height);
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, TRG_ERR_NODEV, "trg_create: no HIP device visible (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(nullptr, TRG_ERR_INVALID, "trg_create: device %d out of range (%d devices)", device, ndev);
+    hipDeviceProp_t prop;
+    HIPCHK(nullptr, hipGetDeviceProperties(&prop, device));
+    if (!strstr(prop.gcnArchName, "gfx950"))
+        return fail(nullptr, TRG_ERR_NODEV, "trg_create: device %d is %s; kernels are built for gfx950 only", device, prop.gcnArchName);
+    HIPCHK(nullptr, hipSetDevice(device));
+    trg_ctx *c = new (std::nothrow) trg_ctx;
+    if (!c) return fail(nullptr, TRG_ERR_NOMEM, "trg_create: out of host memory");
+    c->device = device; c->w = width; c->h = height;
+    const size_t npix = (size_t)width * height;
+    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->accum_own, npix * 16);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->offsets, npix * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->counters, sizeof(unsigned long long) * kCounterSlots * kCounterWords);
+    if (e == hipSuccess) e = hipMemset(c->accum_own, 0, npix * 16);
+    if (e == hipSuccess) e = hipMemset(c->counters, 0, sizeof(unsigned long long) * kCounterSlots * kCounterWords);
+    if (e != hipSuccess) {
+        const int rc = fail(nullptr, e == hipErrorOutOfMemory ? TRG_ERR_NOMEM : TRG_ERR_DEVICE, "trg_create: %s", hipGetErrorString(e));
+        trg_destroy(c);
+        return rc;
+    }
+    c->stream = c->own_stream;
+    c->accum = c->accum_own;
+    *out = c;
+    return TRG_OK;
+}
+
+void trg_destroy(trg_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    if (c->blob) (void)hipFree(c->blob);
+    if (c->counters) (void)hipFree(c->counters);
+    if (c->offsets) (void)hipFree(c->offsets);
+    if (c->accum_own) (void)hipFree(c->accum_own);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int trg_load_scene(trg_ctx *c, const float *pos, const float *nrm, const float *col, const uint32_t *idx,
+                   const uint32_t *mat, uint32_t n_verts, uint32_t n_tris) {
+    if (!c) return TRG_ERR_INVALID;
+    if (n_tris && (!pos || !nrm || !col || !idx || !mat)) return fail(c, TRG_ERR_INVALID, "trg_load_scene: null buffer");
+    if (n_tris >= (1u << 28)) return fail(c, TRG_ERR_RANGE, "trg_load_scene: too many triangles (%u)", n_tris);
+    for (size_t i = 0; i < (size_t)n_tris * 3; ++i)
+        if (idx[i] >= n_verts) return fail(c, TRG_ERR_INVALID, "trg_load_scene: index %u out of range (%u vertices) at %zu", idx[i], n_verts, i);
+    HIPCHK(c, hipSetDevice(c->device));
+
+    Bvh bvh;
+    build_bvh(pos, idx, mat, n_tris, bvh);
+
+    // Positions go through the index buffer (MPS vertexBuffer + indexBuffer, MetalRenderer.mm:274-275);
+    // normals and colours are read as attributes[triangle*3 + j], NOT through the index buffer
+    // (Raytracing.metal:104-108), so they are copied as they are.
+    const uint32_t nt_rec = (uint32_t)(bvh.tris.size() / 3);
+    SceneDesc sc{};
+    sc.n_nodes = bvh.n_nodes; sc.n_tris = n_tris;
+    sc.off_nodes = 0;
+    sc.off_tris = align16(sc.off_nodes + bvh.n_nodes * 64u);
+    sc.off_normals = align16(sc.off_tris + nt_rec * 48u);
+    sc.off_colors = align16(sc.off_normals + std::max(n_tris, 1u) * 36u);
+    sc.off_mats = align16(sc.off_colors + std::max(n_tris, 1u) * 36u);
+    sc.blob_bytes = align16(sc.off_mats + std::max(n_tris, 1u) * 4u);
+    std::vector<unsigned char> host(sc.blob_bytes, 0);
+    memcpy(&host[sc.off_nodes], bvh.nodes.data(), bvh.nodes.size() * sizeof(F4));
+    memcpy(&host[sc.off_tris], bvh.tris.data(), bvh.tris.size() * sizeof(F4));
+    float *hn = reinterpret_cast<float *>(&host[sc.off_normals]);
+    float *hc = reinterpret_cast<float *>(&host[sc.off_colors]);
+    if (n_tris) {
+        memcpy(hn, nrm, (size_t)n_tris * 36);
+        memcpy(hc, col, (size_t)n_tris * 36);
+    }
+    if (n_tris) memcpy(&host[sc.off_mats], mat, (size_t)n_tris * 4);
+
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->blob) { (void)hipFree(c->blob); c->blob = nullptr; c->scene_loaded = false; }
+    hipError_t e = hipMalloc((void **)&c->blob, sc.blob_bytes);
+    if (e != hipSuccess) return fail(c, TRG_ERR_NOMEM, "trg_load_scene: hipMalloc(%u) failed: %s", sc.blob_bytes, hipGetErrorString(e));
+    HIPCHK(c, hipMemcpy(c->blob, host.data(), sc.blob_bytes, hipMemcpyHostToDevice));
+    sc.blob = c->blob;
+    c->sc = sc;
+    c->bvh_nodes = bvh.n_nodes; c->bvh_depth = bvh.depth; c->bvh_leaves = bvh.n_leaves;
+    c->scene_loaded = true;
+    LdsPlan plan;
+    return plan_lds(c, plan);
+}
+
+int trg_set_uniforms(trg_ctx *c, const trg_uniforms *u) {
+    if (!c || !u) return TRG_ERR_INVALID;
+    if (u->width != c->w || u->height != c->h)
+        return fail(c, TRG_ERR_INVALID, "trg_set_uniforms: uniforms are %ux%u but the context is %ux%u", u->width, u->height, c->w, c->h);
+    c->u = *u;
+    c->have_uniforms = true;
+    return TRG_OK;
+}
+
+int trg_set_pixel_offsets(trg_ctx *c, const uint32_t *offsets) {
+    if (!c || !offsets) return TRG_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(c->offsets, offsets, (size_t)c->w * c->h * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_offsets = true;
+    return TRG_OK;
+}
+
+int trg_set_pixel_offsets_seed(trg_ctx *c, uint32_t seed) {
+    if (!c) return TRG_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, launch_offsets_fast(seed, c->w * c->h, c->offsets, c->stream));
+    c->have_offsets = true;
+    return TRG_OK;
+}
+
+int trg_render(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces, uint32_t row0, uint32_t rows) {
+    if (!c) return TRG_ERR_INVALID;
+    if (!c->scene_loaded) return fail(c, TRG_ERR_INVALID, "trg_render: no scene loaded");
+    if (!c->have_uniforms) return fail(c, TRG_ERR_INVALID, "trg_render: uniforms not set");
+    if (!c->have_offsets) return fail(c, TRG_ERR_INVALID, "trg_render: pixel offsets not set");
+    if (bounces > TRG_MAX_BOUNCES) return fail(c, TRG_ERR_RANGE, "trg_render: %u bounces > TRG_MAX_BOUNCES (%u)", bounces, TRG_MAX_BOUNCES);
+    if (row0 > c->h || rows > c->h - row0) return fail(c, TRG_ERR_INVALID, "trg_render: rows [%u,%u) outside the image (height %u)", row0, row0 + rows, c->h);
+    if ((uint64_t)frame_begin + spp > 0xFFFFFFFFull) return fail(c, TRG_ERR_INVALID, "trg_render: frame range overflows");
+    if (spp == 0 || rows == 0) { c->last_ms = 0.0; return TRG_OK; }
+    HIPCHK(c, hipSetDevice(c->device));
+    LdsPlan plan;
+    if (int rc = plan_lds(c, plan)) return rc;
+
+    RenderParams p{};
+    p.u = c->u;
+    p.sc = c->sc;
+    p.offsets = c->offsets;
+    p.accum = c->accum;
+    p.counters = c->counters;
+    p.frame_begin = frame_begin; p.spp = spp; p.bounces = bounces; p.row0 = row0; p.rows = rows;
+    p.tiles_x = (c->w + kTile - 1) / kTile;
+    p.stack_off = plan.stack_off; p.red_off = plan.red_off;
+    const uint32_t tiles_y = (rows + kTile - 1) / kTile;
+    const uint32_t grid = p.tiles_x * tiles_y;
+
+    if (c->opt_timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    hipError_t e = c->opt_strict ? launch_render_strict(p, plan.lds_scene, c->opt_counters, grid, plan.total, c->stream)
+                                 : launch_render_fast(p, plan.lds_scene, c->opt_counters, grid, plan.total, c->stream);
+    if (e != hipSuccess) return fail(c, TRG_ERR_DEVICE, "trg_render: launch failed: %s", hipGetErrorString(e));
+    c->renders++;
+    if (c->opt_timing) {
+        HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+        HIPCHK(c, hipEventSynchronize(c->ev1));
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        c->last_ms = ms;
+        c->total_ms += ms;
+    }
+    return TRG_OK;
+}
+
+int trg_read_accum(trg_ctx *c, float *rgba) {
+    if (!c || !rgba) return TRG_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(rgba, c->accum, (size_t)c->w * c->h * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return TRG_OK;
+}
+
+int trg_get_stats(trg_ctx *c, trg_stats *out) {
+    if (!c || !out) return TRG_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    unsigned long long host[kCounterSlots * kCounterWords];
+    HIPCHK(c, hipMemcpyAsync(host, c->counters, sizeof(host), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    unsigned long long sum[kCounterWords] = { 0 };
+    for (int s = 0; s < kCounterSlots; ++s)
+        for (int k = 0; k < kCounterWords; ++k) sum[k] += host[s * kCounterWords + k];
+    memset(out, 0, sizeof(*out));
+    out->primary_rays = sum[0]; out->bounce_rays = sum[1]; out->shadow_rays = sum[2]; out->shaded_hits = sum[3];
+    out->node_fetches = sum[4]; out->tri_tests = sum[5];
+    out->last_render_ms = c->last_ms; out->total_render_ms = c->total_ms; out->renders = c->renders;
+    out->bvh_nodes = c->bvh_nodes; out->bvh_depth = c->bvh_depth; out->bvh_leaves = c->bvh_leaves;
+    out->scene_bytes = c->sc.blob_bytes;
+    if (c->scene_loaded) {
+        LdsPlan plan;
+        if (plan_lds(c, plan) == TRG_OK) { out->scene_in_lds = plan.lds_scene ? 1u : 0u; out->lds_bytes = plan.total; }
+    }
+    return TRG_OK;
+}
+
+int trg_reset_stats(trg_ctx *c) {
+    if (!c) return TRG_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemsetAsync(c->counters, 0, sizeof(unsigned long long) * kCounterSlots * kCounterWords, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->last_ms = 0.0; c->total_ms = 0.0; c->renders = 0;
+    return TRG_OK;
+}
+
+int trg_set_option(trg_ctx *c, int option, int64_t value) {
+    if (!c) return TRG_ERR_INVALID;
+    switch (option) {
+    case TRG_OPT_STRICT: c->opt_strict = value != 0; break;
+    case TRG_OPT_COUNTERS: c->opt_counters = value != 0; break;
+    case TRG_OPT_FORCE_GLOBAL: c->opt_force_global = value != 0; break;
+    case TRG_OPT_TIMING: c->opt_timing = value != 0; break;
+    default: return fail(c, TRG_ERR_INVALID, "trg_set_option: unknown option %d", option);
+    }
+    return TRG_OK;
+}
+
+int trg_bind_accum(trg_ctx *c, void *device_ptr) {
+    if (!c) return TRG_ERR_INVALID;
+    if (device_ptr && ((uintptr_t)device_ptr & 15u)) return fail(c, TRG_ERR_INVALID, "trg_bind_accum: pointer must be 16-byte aligned");
+    c->accum = device_ptr ? static_cast<float *>(device_ptr) : c->accum_own;
+    return TRG_OK;
+}
+
+int trg_accum_device_ptr(trg_ctx *c, void **out) {
+    if (!c || !out) return TRG_ERR_INVALID;
+    *out = c->accum;
+    return TRG_OK;
+}
+
+int trg_set_stream(trg_ctx *c, void *hip_stream) {
+    if (!c) return TRG_ERR_INVALID;
+    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return TRG_OK;
+}
+
+int trg_sync(trg_ctx *c) {
+    if (!c) return TRG_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return TRG_OK;
+}
+
+// ---- stage-level entry points (host buffers in, host buffers out) ----
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 16); }
+};
+}  // namespace
+
+int trg_trace(trg_ctx *c, const trg_ray *rays, size_t n, int any_hit, void *out) {
+    if (!c || (n && (!rays || !out))) return TRG_ERR_INVALID;
+    if (!c->scene_loaded) return fail(c, TRG_ERR_INVALID, "trg_trace: no scene loaded");
+    if (n > 0x7FFFFFFFull) return fail(c, TRG_ERR_RANGE, "trg_trace: too many rays");
+    if (n == 0) return TRG_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    LdsPlan plan;
+    if (int rc = plan_lds(c, plan)) return rc;
+    DevBuf dr, dout;
+    const size_t out_bytes = n * (any_hit ? sizeof(float) : sizeof(trg_isect));
+    HIPCHK(c, dr.alloc(n * sizeof(trg_ray)));
+    HIPCHK(c, dout.alloc(out_bytes));
+    HIPCHK(c, hipMemcpyAsync(dr.p, rays, n * sizeof(trg_ray), hipMemcpyHostToDevice, c->stream));
+    TraceParams p{};
+    p.sc = c->sc; p.rays = static_cast<const trg_ray *>(dr.p); p.out = dout.p; p.n = (uint32_t)n; p.stack_off = plan.stack_off;
+    hipError_t e = c->opt_strict ? launch_trace_strict(p, plan.lds_scene, any_hit != 0, plan.total, c->stream)
+                                 : launch_trace_fast(p, plan.lds_scene, any_hit != 0, plan.total, c->stream);
+    if (e != hipSuccess) return fail(c, TRG_ERR_DEVICE, "trg_trace: launch failed: %s", hipGetErrorString(e));
+    HIPCHK(c, hipMemcpyAsync(out, dout.p, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return TRG_OK;
+}
+
+int trg_halton(trg_ctx *c, const uint32_t *i, const uint32_t *d, size_t n, float *out) {
+    if (!c || (n && (!i || !d || !out)) || n > 0x7FFFFFFFull) return TRG_ERR_INVALID;
+    if (n == 0) return TRG_OK;
+    for (size_t k = 0; k < n; ++k)
+        if (d[k] >= 64) return fail(c, TRG_ERR_RANGE, "trg_halton: dimension %u >= 64", d[k]);
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf di, dd, dout;
+    HIPCHK(c, di.alloc(n * 4)); HIPCHK(c, dd.alloc(n * 4)); HIPCHK(c, dout.alloc(n * 4));
+    HIPCHK(c, hipMemcpyAsync(di.p, i, n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dd.p, d, n * 4, hipMemcpyHostToDevice, c->stream));
+    hipError_t e = c->opt_strict ? launch_halton_strict((const uint32_t *)di.p, (const uint32_t *)dd.p, (uint32_t)n, (float *)dout.p, c->stream)
+                                 : launch_halton_fast((const uint32_t *)di.p, (const uint32_t *)dd.p, (uint32_t)n, (float *)dout.p, c->stream);
+    if (e != hipSuccess) return fail(c, TRG_ERR_DEVICE, "trg_halton: launch failed: %s", hipGetErrorString(e));
+    HIPCHK(c, hipMemcpyAsync(out, dout.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return TRG_OK;
+}
+
+int trg_raygen(trg_ctx *c, uint32_t frameIndex, trg_ray *out) {
+    if (!c || !out) return TRG_ERR_INVALID;
+    if (!c->have_uniforms || !c->have_offsets) return fail(c, TRG_ERR_INVALID, "trg_raygen: uniforms / pixel offsets not set");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)c->w * c->h;
+    DevBuf dout;
+    HIPCHK(c, dout.alloc(n * sizeof(trg_ray)));
+    trg_uniforms u = c->u;
+    u.frameIndex = frameIndex;
+    hipError_t e = c->opt_strict ? launch_raygen_strict(u, c->offsets, (trg_ray *)dout.p, c->stream)
+                                 : launch_raygen_fast(u, c->offsets, (trg_ray *)dout.p, c->stream);
+    if (e != hipSuccess) return fail(c, TRG_ERR_DEVICE, "trg_raygen: launch failed: %s", hipGetErrorString(e));
+    HIPCHK(c, hipMemcpyAsync(out, dout.p, n * sizeof(trg_ray), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return TRG_OK;
+}
+
+int trg_sample(trg_ctx *c, const float *p3, const float *n3, const float *r4, size_t n, float *out12) {
+    if (!c || (n && (!p3 || !n3 || !r4 || !out12)) || n > 0x0FFFFFFFull) return TRG_ERR_INVALID;
+    if (!c->have_uniforms) return fail(c, TRG_ERR_INVALID, "trg_sample: uniforms not set");
+    if (n == 0) return TRG_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf dp, dn, dr, dout;
+    HIPCHK(c, dp.alloc(n * 12)); HIPCHK(c, dn.alloc(n * 12)); HIPCHK(c, dr.alloc(n * 16)); HIPCHK(c, dout.alloc(n * 48));
+    HIPCHK(c, hipMemcpyAsync(dp.p, p3, n * 12, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dn.p, n3, n * 12, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dr.p, r4, n * 16, hipMemcpyHostToDevice, c->stream));
+    hipError_t e = c->opt_strict ? launch_sample_strict(c->u, (const float *)dp.p, (const float *)dn.p, (const float *)dr.p, (uint32_t)n, (float *)dout.p, c->stream)
+                                 : launch_sample_fast(c->u, (const float *)dp.p, (const float *)dn.p, (const float *)dr.p, (uint32_t)n, (float *)dout.p, c->stream);
+    if (e != hipSuccess) return fail(c, TRG_ERR_DEVICE, "trg_sample: launch failed: %s", hipGetErrorString(e));
+    HIPCHK(c, hipMemcpyAsync(out12, dout.p, n * 48, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return TRG_OK;
+}
+
+int trg_postprocess(trg_ctx *c, uint8_t *rgba8, int flip_y) {
+    if (!c || !rgba8) return TRG_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)c->w * c->h;
+    DevBuf dout;
+    HIPCHK(c, dout.alloc(n * 4));
+    hipError_t e = c->opt_strict ? launch_postprocess_strict(c->accum, c->w, c->h, (uint8_t *)dout.p, flip_y, c->stream)
+                                 : launch_postprocess_fast(c->accum, c->w, c->h, (uint8_t *)dout.p, flip_y, c->stream);
+    if (e != hipSuccess) return fail(c, TRG_ERR_DEVICE, "trg_postprocess: launch failed: %s", hipGetErrorString(e));
+    HIPCHK(c, hipMemcpyAsync(rgba8, dout.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return TRG_OK;
+}
+
+}  // extern "C"

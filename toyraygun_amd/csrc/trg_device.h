@@ -1,0 +1,408 @@
+// trg_device.h -- device-side building blocks of the gfx950 path-tracing megakernel.
+//
+// Compiled twice (see build.py): TRG_STRICT=1 with -ffp-contract=off reproduces the CPU oracle's IEEE
+// arithmetic operation for operation (parity/debug build); TRG_STRICT=0 is the shipped build (FMA
+// contraction, v_rcp/v_rsq in the traversal).  Reference citations are file:line under the reference
+// tree; the arithmetic order of every shading function follows the shader source text.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/trg.h"
+
+#ifndef TRG_STRICT
+#define TRG_STRICT 0
+#endif
+
+#define TRG_DEV __device__ __forceinline__
+
+namespace trgdev {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+struct V3 { float x, y, z; };
+TRG_DEV V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+TRG_DEV V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+TRG_DEV V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+TRG_DEV V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+TRG_DEV V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+TRG_DEV V3 operator*(float s, V3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+TRG_DEV V3 neg(V3 a) { return mk(-a.x, -a.y, -a.z); }
+TRG_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+TRG_DEV V3 cross(V3 a, V3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+// normalize(v) = v * (1 / sqrt(dot(v,v))): the oracle's definition (oracle/trg_oracle.c normalize3).
+TRG_DEV V3 normalize(V3 a) {
+#if TRG_STRICT
+    const float inv = 1.0f / sqrtf(dot(a, a));
+#else
+    const float inv = __builtin_amdgcn_rsqf(dot(a, a));
+#endif
+    return a * inv;
+}
+TRG_DEV float saturate(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+TRG_DEV float rcp_fast(float x) {
+#if TRG_STRICT
+    return 1.0f / x;
+#else
+    return __builtin_amdgcn_rcpf(x);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// Halton (a5): runtime/shaders/common.h:51-75, prime table extended per SURVEY F5.
+//   reference recurrence:  f = f * invB;  r = r + f * (i % b);  i = i / b;   while (i > 0)
+// Device form: the base is a compile-time constant, so f_k = fl(f_{k-1} * fl(1/b)) is a literal and
+// i / b is a multiply-high; the loop runs the fixed digit count of a 32-bit index: once i reaches 0
+// the remaining terms add f_k * 0 = +0, which leaves r unchanged, so the value is bit-identical to the
+// data-dependent loop.  Never contracted, in either build.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ constexpr uint32_t halton_prime(uint32_t d) {
+    constexpr uint32_t p[64] = { 2,   3,   5,   7,   11,  13,  17,  19,  23,  29,  31,  37,  41,  43,  47,  53,
+                                 59,  61,  67,  71,  73,  79,  83,  89,  97,  101, 103, 107, 109, 113, 127, 131,
+                                 137, 139, 149, 151, 157, 163, 167, 173, 179, 181, 191, 193, 197, 199, 211, 223,
+                                 227, 229, 233, 239, 241, 251, 257, 263, 269, 271, 277, 281, 283, 293, 307, 311 };
+    return p[d & 63];
+}
+__host__ __device__ constexpr int halton_digits(uint32_t b) {
+    int n = 0;
+    uint64_t v = 1;
+    while (v <= 0xFFFFFFFFull) { v *= b; ++n; }
+    return n;  // smallest n with b^n > 2^32-1
+}
+template <uint32_t B>
+struct HaltonTab {
+    float f[33];
+    constexpr HaltonTab() : f{} {
+        const float invB = 1.0f / (float)B;
+        float v = 1.0f;
+        for (int k = 0; k < 33; ++k) { v = v * invB; f[k] = v; }
+    }
+};
+template <uint32_t D>
+TRG_DEV float halton_c(uint32_t i) {
+#pragma clang fp contract(off)
+    constexpr uint32_t B = halton_prime(D);
+    constexpr int N = halton_digits(B);
+    constexpr HaltonTab<B> tab{};
+    float r = 0.0f;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const uint32_t q = i / B;
+        const uint32_t dig = i - q * B;
+        const float t = tab.f[k] * (float)dig;
+        r = r + t;
+        i = q;
+    }
+    return r;
+}
+// the two raygen dimensions (Raytracing.metal:67-68)
+TRG_DEV void halton_pixel(uint32_t i, float &r0, float &r1) { r0 = halton_c<0>(i); r1 = halton_c<1>(i); }
+// the four dimensions 2 + 4*bounce + {0,1,2,3} of one shading event (Raytracing.metal:165-166,188-189);
+// `bounce` is wave-uniform so this is a scalar branch.
+template <int BNC>
+TRG_DEV void halton4_c(uint32_t i, float r[4]) {
+    r[0] = halton_c<2 + 4 * BNC + 0>(i);
+    r[1] = halton_c<2 + 4 * BNC + 1>(i);
+    r[2] = halton_c<2 + 4 * BNC + 2>(i);
+    r[3] = halton_c<2 + 4 * BNC + 3>(i);
+}
+TRG_DEV void halton4(uint32_t i, uint32_t bounce, float r[4]) {
+    switch (bounce) {
+    case 0: halton4_c<0>(i, r); break;
+    case 1: halton4_c<1>(i, r); break;
+    case 2: halton4_c<2>(i, r); break;
+    case 3: halton4_c<3>(i, r); break;
+    case 4: halton4_c<4>(i, r); break;
+    case 5: halton4_c<5>(i, r); break;
+    case 6: halton4_c<6>(i, r); break;
+    case 7: halton4_c<7>(i, r); break;
+    case 8: halton4_c<8>(i, r); break;
+    case 9: halton4_c<9>(i, r); break;
+    case 10: halton4_c<10>(i, r); break;
+    case 11: halton4_c<11>(i, r); break;
+    case 12: halton4_c<12>(i, r); break;
+    case 13: halton4_c<13>(i, r); break;
+    default: halton4_c<14>(i, r); break;
+    }
+}
+// any dimension, per-lane (test entry trg_halton): the same halton_c<D> instantiations the megakernel uses
+TRG_DEV float halton_any(uint32_t i, uint32_t d) {
+    switch (d & 63u) {
+    case 0: return halton_c<0>(i);
+    case 1: return halton_c<1>(i);
+    case 2: return halton_c<2>(i);
+    case 3: return halton_c<3>(i);
+    case 4: return halton_c<4>(i);
+    case 5: return halton_c<5>(i);
+    case 6: return halton_c<6>(i);
+    case 7: return halton_c<7>(i);
+    case 8: return halton_c<8>(i);
+    case 9: return halton_c<9>(i);
+    case 10: return halton_c<10>(i);
+    case 11: return halton_c<11>(i);
+    case 12: return halton_c<12>(i);
+    case 13: return halton_c<13>(i);
+    case 14: return halton_c<14>(i);
+    case 15: return halton_c<15>(i);
+    case 16: return halton_c<16>(i);
+    case 17: return halton_c<17>(i);
+    case 18: return halton_c<18>(i);
+    case 19: return halton_c<19>(i);
+    case 20: return halton_c<20>(i);
+    case 21: return halton_c<21>(i);
+    case 22: return halton_c<22>(i);
+    case 23: return halton_c<23>(i);
+    case 24: return halton_c<24>(i);
+    case 25: return halton_c<25>(i);
+    case 26: return halton_c<26>(i);
+    case 27: return halton_c<27>(i);
+    case 28: return halton_c<28>(i);
+    case 29: return halton_c<29>(i);
+    case 30: return halton_c<30>(i);
+    case 31: return halton_c<31>(i);
+    case 32: return halton_c<32>(i);
+    case 33: return halton_c<33>(i);
+    case 34: return halton_c<34>(i);
+    case 35: return halton_c<35>(i);
+    case 36: return halton_c<36>(i);
+    case 37: return halton_c<37>(i);
+    case 38: return halton_c<38>(i);
+    case 39: return halton_c<39>(i);
+    case 40: return halton_c<40>(i);
+    case 41: return halton_c<41>(i);
+    case 42: return halton_c<42>(i);
+    case 43: return halton_c<43>(i);
+    case 44: return halton_c<44>(i);
+    case 45: return halton_c<45>(i);
+    case 46: return halton_c<46>(i);
+    case 47: return halton_c<47>(i);
+    case 48: return halton_c<48>(i);
+    case 49: return halton_c<49>(i);
+    case 50: return halton_c<50>(i);
+    case 51: return halton_c<51>(i);
+    case 52: return halton_c<52>(i);
+    case 53: return halton_c<53>(i);
+    case 54: return halton_c<54>(i);
+    case 55: return halton_c<55>(i);
+    case 56: return halton_c<56>(i);
+    case 57: return halton_c<57>(i);
+    case 58: return halton_c<58>(i);
+    case 59: return halton_c<59>(i);
+    case 60: return halton_c<60>(i);
+    case 61: return halton_c<61>(i);
+    case 62: return halton_c<62>(i);
+    case 63: return halton_c<63>(i);
+    }
+    return 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// sin/cos of phi in [0, 2*pi] (common.h:82-85).  The reference calls Metal's cos()/sin(), whose
+// rounding is implementation-defined; the project's device definition is this fixed polynomial,
+// restated operation for operation by the oracle (orc_sincos_portable).  Never contracted.
+// ---------------------------------------------------------------------------------------------
+TRG_DEV void trg_sincos(float phi, float &s_out, float &c_out) {
+#pragma clang fp contract(off)
+    const float two_over_pi = 0x1.45f306p-1f;
+    const float pio2_hi = 0x1.92p+0f;
+    const float pio2_mid = 0x1.fb5444p-12f;
+    const float pio2_lo = 0x1.68c2p-39f;
+    const float kf = rintf(phi * two_over_pi);
+    const int k = (int)kf;
+    float r = phi - kf * pio2_hi;
+    r = r - kf * pio2_mid;
+    r = r - kf * pio2_lo;
+    const float z = r * r;
+    float ps = -1.9515295891e-4f * z + 8.3321608736e-3f;
+    ps = ps * z - 1.6666654611e-1f;
+    const float sn = (ps * z) * r + r;
+    float pc = 2.443315711809948e-5f * z - 1.388731625493765e-3f;
+    pc = pc * z + 4.166664568298827e-2f;
+    const float cs = ((pc * z) * z - 0.5f * z) + 1.0f;
+    const int q = k & 3;
+    const float s = (q == 0) ? sn : (q == 1) ? cs : (q == 2) ? -sn : -cs;
+    const float c = (q == 0) ? cs : (q == 1) ? -sn : (q == 2) ? -cs : sn;
+    s_out = s;
+    c_out = c;
+}
+
+// common.h:80-91
+TRG_DEV V3 sample_cosine_hemisphere(float ux, float uy) {
+    const float PI_F = 3.1415926535898f;
+    const float phi = 2.0f * PI_F * ux;
+    float sin_phi, cos_phi;
+    trg_sincos(phi, sin_phi, cos_phi);
+    const float cos_theta = sqrtf(uy);
+    const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+    return mk(sin_theta * cos_phi, cos_theta, sin_theta * sin_phi);
+}
+// common.h:95-110
+TRG_DEV V3 align_hemisphere(V3 s, V3 n) {
+    const V3 up = n;
+    const V3 right = normalize(cross(n, mk(0.0072f, 1.0f, 0.0034f)));
+    const V3 forward = cross(right, up);
+    return s.x * right + s.y * up + s.z * forward;
+}
+struct LightSample { V3 dir; V3 color; float dist; };
+// common.h:119-159
+TRG_DEV LightSample sample_area_light(const trg_uniforms &u, float r0, float r1, V3 p, V3 n) {
+    LightSample ls;
+    const float ux = r0 * 2.0f - 1.0f, uy = r1 * 2.0f - 1.0f;
+    const V3 lp = mk(u.light_pos[0], u.light_pos[1], u.light_pos[2]);
+    const V3 lr = mk(u.light_right[0], u.light_right[1], u.light_right[2]);
+    const V3 lu = mk(u.light_up[0], u.light_up[1], u.light_up[2]);
+    const V3 lf = mk(u.light_forward[0], u.light_forward[1], u.light_forward[2]);
+    const V3 sp = lp + lr * ux + lu * uy;
+    V3 d = sp - p;
+    const float dist = sqrtf(dot(d, d));
+    const float inv = 1.0f / fmaxf(dist, 1e-3f);
+    d = d * inv;
+    V3 c = mk(u.light_color[0], u.light_color[1], u.light_color[2]);
+    c = c * (inv * inv);
+    c = c * saturate(dot(neg(d), lf));
+    c = c * saturate(dot(n, d));
+    ls.dir = d; ls.color = c; ls.dist = dist;
+    return ls;
+}
+
+// Raytracing.metal:41-91 (a6)
+TRG_DEV void raygen(const trg_uniforms &u, uint32_t x, uint32_t y, uint32_t hidx, V3 &org, V3 &dir) {
+    float r0, r1;
+    halton_pixel(hidx, r0, r1);
+    const float px = (float)x + r0, py = (float)y + r1;
+    float uvx = px / (float)u.width, uvy = py / (float)u.height;
+    uvx = uvx * 2.0f - 1.0f;
+    uvy = uvy * 2.0f - 1.0f;
+    const float *m = u.inv_view_proj;
+    float w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = uvx * m[j * 4 + 0] + uvy * m[j * 4 + 1] + 0.0f * m[j * 4 + 2] + 1.0f * m[j * 4 + 3];
+    const V3 cam = mk(u.cam_pos[0], u.cam_pos[1], u.cam_pos[2]);
+    const V3 world = mk(w[0] / w[3], w[1] / w[3], w[2] / w[3]);
+    org = cam;
+    dir = normalize(world - cam);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Intersector (a7 nearest, a12 any): replaces MPSRayIntersector (MetalRenderer.mm:265-279,427-437,
+// 466-475).  Contract = oracle/trg_oracle.c "INTERSECTION CONTRACT".
+// ---------------------------------------------------------------------------------------------
+struct SceneView {
+    const v4f *nodes;       // 4 per node
+    const v4f *tris;        // 3 per triangle, leaf order
+    const float *normals;   // 9 per triangle, ORIGINAL order (reference vertexNormals buffer)
+    const float *colors;    // 9 per triangle, ORIGINAL order (reference vertexColors buffer)
+    const uint32_t *mats;   // 1 per triangle, ORIGINAL order (reference triangleMasks buffer)
+};
+struct Hit { float t; int prim; float u, v; };  // u, v = Moeller-Trumbore weights of vertex 1 and 2
+struct Counters { uint32_t nodes, tris; };
+
+// One ray/triangle test.  Returns true when (u,v) are inside and t is in [0, tmax_ray].
+TRG_DEV bool tri_test(const v4f a, const v4f b, const v4f c, V3 o, V3 d, float tmax_ray, float &t, float &u, float &v) {
+    const V3 v0 = mk(a.x, a.y, a.z), e1 = mk(b.x, b.y, b.z), e2 = mk(c.x, c.y, c.z);
+    const V3 p = cross(d, e2);
+    const float det = dot(e1, p);
+    const float inv = rcp_fast(det);
+    const V3 tv = o - v0;
+    u = dot(tv, p) * inv;
+    const V3 q = cross(tv, e1);
+    v = dot(d, q) * inv;
+    t = dot(e2, q) * inv;
+    return (u >= 0.0f) && (v >= 0.0f) && ((u + v) <= 1.0f) && (t >= 0.0f) && (t <= tmax_ray);
+}
+
+// Per-lane stack in LDS, laid out [level][thread] so lane i always hits bank i%32 (no conflicts).
+template <int BLOCK>
+struct LdsStack {
+    int *base;  // already offset by the thread index
+    TRG_DEV void push(int sp, int v) { base[sp * BLOCK] = v; }
+    TRG_DEV int pop(int sp) { return base[sp * BLOCK]; }
+};
+
+template <bool ANY, bool COUNT, int BLOCK>
+TRG_DEV bool traverse(const SceneView &sc, V3 o, V3 d, float tmax_ray, uint32_t rmask, Hit &hit, LdsStack<BLOCK> stk,
+                      Counters &cnt) {
+    const float idx = rcp_fast(d.x), idy = rcp_fast(d.y), idz = rcp_fast(d.z);
+    const float oix = o.x * idx, oiy = o.y * idy, oiz = o.z * idz;
+    float best = tmax_ray;
+    bool found = false;
+    hit.t = -1.0f; hit.prim = -1; hit.u = 0.0f; hit.v = 0.0f;
+    int node = 0, sp = 0;
+    for (;;) {
+        while (node >= 0) {
+            const v4f *n = sc.nodes + node * 4;
+            const v4f n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+            if (COUNT) cnt.nodes++;
+            // slab tests; (b - o) * inv written as b*inv - o*inv so the fast build gets one fma each.
+            // fmin/fmax drop NaN (0 * inf), which only widens the interval: conservative.
+            const float ax0 = n0.x * idx - oix, ax1 = n0.y * idx - oix, ay0 = n0.z * idy - oiy, ay1 = n0.w * idy - oiy;
+            const float bx0 = n1.x * idx - oix, bx1 = n1.y * idx - oix, by0 = n1.z * idy - oiy, by1 = n1.w * idy - oiy;
+            const float az0 = n2.x * idz - oiz, az1 = n2.y * idz - oiz, bz0 = n2.z * idz - oiz, bz1 = n2.w * idz - oiz;
+            const float amin = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fmaxf(fminf(az0, az1), 0.0f));
+            const float amax = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fminf(fmaxf(az0, az1), best));
+            const float bmin = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fmaxf(fminf(bz0, bz1), 0.0f));
+            const float bmax = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fminf(fmaxf(bz0, bz1), best));
+            const bool ha = amin <= amax, hb = bmin <= bmax;
+            const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+            if (ha && hb) {
+                const bool swap = bmin < amin;
+                node = swap ? c1 : c0;
+                stk.push(sp++, swap ? c0 : c1);
+            } else if (ha) {
+                node = c0;
+            } else if (hb) {
+                node = c1;
+            } else {
+                if (sp == 0) return found;
+                node = stk.pop(--sp);
+            }
+        }
+        // leaf: ~node = (first << 3) | (count - 1)
+        const uint32_t code = (uint32_t)~node;
+        const uint32_t first = code >> 3, count = (code & 7u) + 1u;
+        for (uint32_t k = 0; k < count; ++k) {
+            const v4f *tr = sc.tris + (first + k) * 3;
+            const v4f a = tr[0], b = tr[1], c = tr[2];
+            const uint32_t tmask = (uint32_t)__float_as_int(b.w);
+            if ((tmask & rmask) == 0u) continue;
+            if (COUNT) cnt.tris++;
+            float t, u, v;
+            if (!tri_test(a, b, c, o, d, tmax_ray, t, u, v)) continue;
+            if (ANY) { hit.t = t; return true; }
+            const int prim = __float_as_int(a.w);
+            if (!found || t < best || (t == best && prim < hit.prim)) {
+                found = true; best = t;
+                hit.t = t; hit.prim = prim; hit.u = u; hit.v = v;
+            }
+        }
+        if (sp == 0) return found;
+        node = stk.pop(--sp);
+    }
+}
+
+// Raytracing.metal:95-112 with coordinates = (1-u-v, u): weights of vertex 0 and vertex 1
+TRG_DEV V3 interp_attr(const float *attr, int prim, float cx, float cy) {
+    const float cz = 1.0f - cx - cy;
+    const float *p = attr + prim * 9;
+    const V3 T0 = mk(p[0], p[1], p[2]), T1 = mk(p[3], p[4], p[5]), T2 = mk(p[6], p[7], p[8]);
+    return cx * T0 + cy * T1 + cz * T2;
+}
+
+// ACES + sRGB (N1): common.h:36-43,163-171
+TRG_DEV float aces_film(float x) {
+    const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+    return fminf(fmaxf((x * (a * x + b)) / (x * (c * x + d) + e), 0.0f), 1.0f);
+}
+TRG_DEV float to_srgb(float v) {
+    if (v < 0.0031308f) v *= 12.92f;
+    else v = 1.055f * powf(v, 1.0f / 2.4f) - 0.055f;
+    return v;
+}
+
+TRG_DEV uint32_t pcg_hash32(uint32_t v) {
+    const uint32_t state = v * 747796405u + 2891336453u;
+    const uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+
+}  // namespace trgdev

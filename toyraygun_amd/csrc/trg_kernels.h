@@ -1,0 +1,61 @@
+// trg_kernels.h -- host-visible launch interface of the HIP kernels (internal to libtoyraygun_hip.so).
+// Two implementations are linked in: *_fast (shipped) and *_strict (-ffp-contract=off parity build).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/trg.h"
+
+namespace trg {
+
+constexpr int kBlock = 256;        // threads per workgroup = 4 wavefronts of 64
+constexpr int kTile = 16;          // a workgroup renders a 16x16 pixel tile, one 8x8 sub-tile per wavefront
+constexpr int kCounterSlots = 64;  // ray counters are spread over 64 slots to avoid same-address atomics
+constexpr int kCounterWords = 8;   // primary, bounce, shadow, shaded, node_fetches, tri_tests, 2 spare
+constexpr uint32_t kMaxLdsScene = 40u * 1024u;  // scenes up to this size are staged in LDS per workgroup
+
+// The scene lives in ONE device allocation: [nodes | tris | normals | colors | mats], every section
+// 16-byte aligned, so a workgroup can stage it into LDS with a single stream of 16-byte copies.
+struct SceneDesc {
+    const unsigned char *blob;
+    uint32_t off_nodes, off_tris, off_normals, off_colors, off_mats, blob_bytes;
+    uint32_t n_nodes, n_tris;
+};
+
+struct RenderParams {
+    trg_uniforms u;
+    SceneDesc sc;
+    const uint32_t *offsets;       // width*height Halton index offsets
+    float *accum;                  // width*height float4, row 0 = scene bottom
+    unsigned long long *counters;  // kCounterSlots * kCounterWords
+    uint32_t frame_begin, spp, bounces, row0, rows, tiles_x;
+    uint32_t stack_off;            // byte offset of the traversal stacks in dynamic LDS
+    uint32_t red_off;              // byte offset of the counter-reduction scratch in dynamic LDS
+};
+
+struct TraceParams {
+    SceneDesc sc;
+    const trg_ray *rays;
+    void *out;  // trg_isect[n] or float[n]
+    uint32_t n;
+    uint32_t stack_off;
+};
+
+#define TRG_DECL_LAUNCHERS(SFX)                                                                                   \
+    hipError_t launch_render_##SFX(const RenderParams &p, bool lds_scene, bool counters, uint32_t grid,          \
+                                   size_t lds_bytes, hipStream_t s);                                             \
+    hipError_t launch_trace_##SFX(const TraceParams &p, bool lds_scene, bool any_hit, size_t lds_bytes,          \
+                                  hipStream_t s);                                                                \
+    hipError_t launch_halton_##SFX(const uint32_t *i, const uint32_t *d, uint32_t n, float *out, hipStream_t s); \
+    hipError_t launch_raygen_##SFX(const trg_uniforms &u, const uint32_t *offsets, trg_ray *out, hipStream_t s); \
+    hipError_t launch_sample_##SFX(const trg_uniforms &u, const float *p3, const float *n3, const float *r4,     \
+                                   uint32_t n, float *out12, hipStream_t s);                                     \
+    hipError_t launch_postprocess_##SFX(const float *accum, uint32_t w, uint32_t h, uint8_t *rgba8, int flip_y,  \
+                                        hipStream_t s);                                                          \
+    hipError_t launch_offsets_##SFX(uint32_t seed, uint32_t n, uint32_t *out, hipStream_t s);
+
+TRG_DECL_LAUNCHERS(fast)
+TRG_DECL_LAUNCHERS(strict)
+
+}  // namespace trg
