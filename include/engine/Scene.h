@@ -1,0 +1,33 @@
+// engine/Scene.h -- toyraygun::Scene (reference src/engine/Scene.h:14-35, Scene.cpp:13-129):
+// an unindexed triangle soup in five flat public vectors, filled through addCube / addPlane /
+// addAreaLight.  Same names, same layout, same flattening rules (a1 of SURVEY 8a).
+#pragma once
+#include <bx/math.h>
+#include <stdint.h>
+
+#include <vector>
+
+namespace toyraygun {
+
+class Scene {
+public:
+    std::vector<bx::Vec3> m_vertexBuffer;      // 3 per triangle, transformed positions
+    std::vector<uint32_t> m_indexBuffer;       // 0,1,2,... (identity)
+    std::vector<bx::Vec3> m_normalBuffer;      // 3 copies of the transformed, normalised face normal
+    std::vector<bx::Vec3> m_colorBuffer;       // 3 copies of the object colour
+    std::vector<uint32_t> m_materialIDBuffer;  // 1 per triangle: MATERIAL_DEFAULT / MATERIAL_EMISSIVE
+
+    void addCube(bx::Vec3 color, float *transformMtx);
+    void addPlane(bx::Vec3 color, float *transformMtx);
+    void addAreaLight(bx::Vec3 color, float *transformMtx);
+
+    // beyond the reference: an arbitrary indexed mesh with per-vertex normals
+    void addMesh(const bx::Vec3 *vertices, const bx::Vec3 *normals, const uint32_t *indices, int triangleCount,
+                 float *transformMtx, bx::Vec3 color, unsigned int materialID);
+
+protected:
+    void addGeometry(bx::Vec3 *vertices, uint32_t *indices, int triangleCount, float *transformMtx, bx::Vec3 color,
+                     unsigned int materialID);
+};
+
+}  // namespace toyraygun

@@ -137,6 +137,13 @@ int trg_raygen(trg_ctx *ctx, uint32_t frameIndex, trg_ray *out);
  * random pairs r[k] = (r0,r1,r2,r3) */
 int trg_sample(trg_ctx *ctx, const float *p3, const float *n3, const float *r4, size_t n, float *out12);
 
+/* host-only (no GPU): the acceleration structure trg_load_scene would build, flattened as DESIGN.md
+ * "Data layout in HBM" describes (16 floats per node, 12 floats per triangle record).  Pass NULL
+ * outputs to query the sizes. */
+int trg_debug_build_bvh(const float *positions3, const uint32_t *indices, const uint32_t *material_ids, uint32_t n_verts,
+                        uint32_t n_tris, float *nodes_out, uint32_t nodes_cap, float *tris_out, uint32_t tris_cap,
+                        uint32_t *n_nodes, uint32_t *n_tri_records, uint32_t *depth);
+
 /* --- N1: ACES tonemap + sRGB of the accumulation buffer to RGBA8 (PostProcessing.metal:44-57;
  *     common.h:36-43,163-171).  flip_y != 0 writes the top image row first (PNG order). */
 int trg_postprocess(trg_ctx *ctx, uint8_t *rgba8, int flip_y);

@@ -1,0 +1,470 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle.
+
+Bars (north_star / SURVEY 8d):
+  * integer / index work and the STRICT build (-ffp-contract=off): bit-exact against the oracle
+    (oracle in ORC_TRIG_PORTABLE mode, the device's sin/cos definition);
+  * the shipped FAST build (FMA contraction, v_rcp/v_rsq): per-pixel L2 on the linear float4 buffer,
+    RMSE <= 1e-3 and >= 99.9 % of pixels within 1e-4 * max(1, |ref|), against the oracle in its
+    faithful libm mode.
+Nothing here reads /root/reference.
+"""
+import numpy as np
+import pytest
+
+from tests.util import TOL_FRAC, TOL_RMSE, image_metrics, make_ctx
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi(built):
+    from toyraygun_amd import capi as c
+    c.load()
+    return c
+
+
+@pytest.fixture(scope="module")
+def ctx256(capi, O, cornell):
+    c = make_ctx(O, cornell, 256, 256, offsets=O.pixel_offsets(256, 256))
+    yield c
+    c.close()
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+# ------------------------------------------------------------------ a5 Halton
+def test_halton_bit_exact(capi, O, ctx256, golden):
+    rng = np.random.default_rng(3)
+    i = np.concatenate([golden["halton_i"], rng.integers(0, 2 ** 32, 4000, dtype=np.uint64).astype(np.uint32)])
+    ii, dd = np.repeat(i, 64), np.tile(np.arange(64, dtype=np.uint32), i.shape[0])
+    ref = np.array([O.halton(a, b) for a, b in zip(ii.tolist(), dd.tolist())], np.float32)
+    for strict in (0, 1):
+        ctx256.set_option(capi.OPT_STRICT, strict)
+        got = ctx256.halton(ii, dd)
+        assert np.array_equal(_bits(got), _bits(ref)), "halton differs (strict=%d)" % strict
+    n = golden["halton_i"].shape[0]
+    assert np.array_equal(_bits(got[: n * 64].reshape(n, 64)), _bits(golden["halton"]))
+    ctx256.set_option(capi.OPT_STRICT, 0)
+    with pytest.raises(capi.TrgError):
+        ctx256.halton([1], [64])
+    assert ctx256.halton([], []).shape == (0,)
+
+
+# ------------------------------------------------------------------ a6 raygen
+def test_raygen(capi, O, ctx256):
+    off = O.pixel_offsets(256, 256)
+    for f in (0, 3, 2 ** 32 - 1):   # the last one wraps offset + frameIndex mod 2^32
+        ref = np.zeros(256 * 256, O.RAY_DTYPE)
+        u = O.make_uniforms(256, 256, f)
+        L = O.lib()
+        import ctypes as C
+        dst = np.zeros((256, 256, 4), np.float32)
+        for y in range(0, 256, 5):
+            for x in range(0, 256, 3):
+                L.orc_raygen(C.byref(u), off.ctypes.data, ref.ctypes.data, dst.ctypes.data, x, y)
+        sel = np.zeros((256, 256), bool)
+        sel[0:256:5, 0:256:3] = True
+        sel = sel.reshape(-1)
+        ctx256.set_option(capi.OPT_STRICT, 1)
+        got = ctx256.raygen(f)
+        assert np.array_equal(got[sel].view(np.uint8), ref[sel].view(np.uint8)), "strict raygen differs at frame %d" % f
+        ctx256.set_option(capi.OPT_STRICT, 0)
+        got = ctx256.raygen(f)
+        np.testing.assert_allclose(got["direction"][sel], ref["direction"][sel], rtol=0, atol=3e-7)
+        assert np.array_equal(got["origin"][sel], ref["origin"][sel]) and (got["mask"] == 3).all() and np.isinf(got["maxDistance"]).all()
+
+
+# ------------------------------------------------------------------ a10 / a11 sampling
+def test_sampling(capi, O, ctx256, golden):
+    r, n, p = golden["sample_r"], golden["sample_n"], golden["sample_p"]
+    r4 = np.concatenate([r, r[::-1]], axis=1).astype(np.float32)
+    ctx256.set_option(capi.OPT_STRICT, 1)
+    got = ctx256.sample(p, n, r4)
+    assert np.array_equal(_bits(got[:, 0:3]), _bits(golden["sample_ldir"]))
+    assert np.array_equal(_bits(got[:, 3]), _bits(golden["sample_ldist"]))
+    assert np.array_equal(_bits(got[:, 4:7]), _bits(golden["sample_lcol"]))
+    # bounce direction for (r2, r3) = reversed grid, against the oracle's portable-trig definition
+    import ctypes as C
+    L = O.lib()
+    fp = C.POINTER(C.c_float)
+    O.set_trig_mode(O.TRIG_PORTABLE)
+    ref = np.zeros((r.shape[0], 3), np.float32)
+    for k in range(r.shape[0]):
+        rr, nn, h = r4[k, 2:4].copy(), n[k].copy(), np.zeros(3, np.float32)
+        L.orc_sample_cosine_hemisphere(rr.ctypes.data_as(fp), h.ctypes.data_as(fp))
+        L.orc_align_hemisphere(h.ctypes.data_as(fp), nn.ctypes.data_as(fp), ref[k].ctypes.data_as(fp))
+    O.set_trig_mode(O.TRIG_LIBM)
+    assert np.array_equal(_bits(got[:, 8:11]), _bits(ref))
+    ctx256.set_option(capi.OPT_STRICT, 0)
+    fast = ctx256.sample(p, n, r4)
+    np.testing.assert_allclose(fast, got, rtol=2e-6, atol=2e-6)
+
+
+# ------------------------------------------------------------------ a7 / a12 intersector
+def _rays(O, n, seed, lo=(-0.95, 0.05, -0.95), hi=(0.95, 1.9, 3.0)):
+    rng = np.random.default_rng(seed)
+    rays = np.zeros(n, O.RAY_DTYPE)
+    rays["origin"] = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    rays["direction"] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    rays["mask"] = rng.choice([1, 2, 3], n).astype(np.uint32)
+    rays["maxDistance"] = np.where(rng.random(n) < 0.25, rng.uniform(0.05, 3.0, n), np.inf).astype(np.float32)
+    rays["maxDistance"][rng.random(n) < 0.02] = -1.0
+    return rays
+
+
+def _adversarial_rays(O, scene):
+    """Rays aimed at shared edges, vertices, along axes, starting on surfaces, grazing."""
+    b = scene.buffers()
+    P = b["positions"].reshape(-1, 3, 3)[:36]
+    eye = np.array(O.EYE, np.float32)
+    targets = [P[:, 0], P[:, 1], P[:, 2], (P[:, 0] + P[:, 1]) / 2, (P[:, 1] + P[:, 2]) / 2, (P[:, 0] + P[:, 2]) / 2, P.mean(1)]
+    t = np.concatenate(targets).astype(np.float32)
+    n = t.shape[0]
+    rays = np.zeros(n + 12, O.RAY_DTYPE)
+    d = t - eye
+    rays["origin"][:n] = eye
+    rays["direction"][:n] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    axes = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], np.float32)
+    rays["origin"][n:n + 6] = [0.0, 1.0, 0.0]
+    rays["direction"][n:n + 6] = axes
+    rays["origin"][n + 6:n + 12] = [[0, 0, 0], [0, 2, 0], [-1, 1, 0], [1, 1, 0], [0, 1, -1], [0.1, 0.6, 0.5]]   # on surfaces
+    rays["direction"][n + 6:n + 12] = [[0, 1, 0], [0, -1, 0], [1, 0, 0], [-1, 0, 0], [0, 0, 1], [0, 1, 0]]
+    rays["mask"] = 3
+    rays["maxDistance"] = np.inf
+    return rays
+
+
+@pytest.mark.parametrize("force_global", [0, 1])
+def test_intersector(capi, O, cornell, ctx256, force_global):
+    ctx256.set_option(capi.OPT_FORCE_GLOBAL, force_global)
+    try:
+        rays = np.concatenate([_rays(O, 60000, 21), _adversarial_rays(O, cornell)])
+        ref = O.intersect_nearest(cornell, rays)
+        ref_any = O.intersect_any(cornell, rays)
+        # strict build: the triangle test is the oracle's arithmetic -> identical records
+        ctx256.set_option(capi.OPT_STRICT, 1)
+        got = ctx256.trace(rays)
+        assert np.array_equal(got.view(np.uint8), ref.view(np.uint8)), "strict nearest-hit differs from the oracle"
+        got_any = ctx256.trace(rays, any_hit=True)
+        assert np.array_equal(got_any >= 0, ref_any >= 0)
+        # fast build: same primitive except where the double-precision margin says fp32 cannot decide
+        ctx256.set_option(capi.OPT_STRICT, 0)
+        fast = ctx256.trace(rays)
+        diff = fast["primitiveIndex"] != ref["primitiveIndex"]
+        if diff.any():
+            _, _, margin = O.nearest_f64(cornell, rays[diff])
+            assert (margin < 1e-4).all()
+        assert diff.mean() < 2e-3
+        same = ~diff & (ref["primitiveIndex"] >= 0)
+        np.testing.assert_allclose(fast["distance"][same], ref["distance"][same], rtol=3e-6, atol=3e-6)
+        np.testing.assert_allclose(fast["coordinates"][same], ref["coordinates"][same], rtol=0, atol=2e-5)
+        fast_any = ctx256.trace(rays, any_hit=True)
+        assert ((fast_any >= 0) != (ref_any >= 0)).mean() < 2e-3
+        inactive = rays["maxDistance"] < 0
+        assert (fast["distance"][inactive] < 0).all() and (fast["primitiveIndex"][inactive] == -1).all() and (fast_any[inactive] < 0).all()
+        assert ctx256.trace(rays[:0]).shape == (0,)
+    finally:
+        ctx256.set_option(capi.OPT_FORCE_GLOBAL, 0)
+        ctx256.set_option(capi.OPT_STRICT, 0)
+
+
+def test_intersector_large_scene_in_hbm(capi, O):
+    """A scene too big for LDS (2,628 triangles) takes the global-memory traversal; the oracle uses its own BVH."""
+    scene = O.OracleScene.cornell_lattice(6)
+    c = make_ctx(O, scene, 64, 64)
+    try:
+        st = c.stats()
+        assert st.scene_in_lds == 0 and st.bvh_depth <= 40
+        rays = _rays(O, 40000, 8, hi=(0.95, 1.9, 0.95))
+        ref = O.intersect_nearest(scene, rays)
+        c.set_option(capi.OPT_STRICT, 1)
+        got = c.trace(rays)
+        assert np.array_equal(got.view(np.uint8), ref.view(np.uint8))
+        assert np.array_equal(c.trace(rays, any_hit=True) >= 0, O.intersect_any(scene, rays) >= 0)
+    finally:
+        c.close()
+
+
+def test_degenerate_scenes(capi, O):
+    """Empty scene and a single triangle (the BVH builder synthesises the root)."""
+    u = O.make_uniforms(32, 32)
+    c = capi.Context(32, 32)
+    try:
+        c.set_uniforms(O.uniforms_bytes(u))
+        c.set_pixel_offsets_seed()
+        z3, zi = np.zeros((0, 3), np.float32), np.zeros(0, np.uint32)
+        c.load_scene(z3, z3, z3, zi, zi)
+        c.render(0, 2, 3)
+        img = c.read_accum()
+        assert (img[..., :3] == 0).all() and (img[..., 3] == 1).all()
+        st = c.stats()
+        assert st.primary_rays == 32 * 32 * 2 and st.shadow_rays == 0 and st.bounce_rays == 0
+        # one big emissive triangle in front of the camera: hit pixels are exactly the light colour
+        tri = np.array([[-5, -5, 0], [5, -5, 0], [0, 8, 0]], np.float32)
+        nrm = np.tile(np.array([[0, 0, 1]], np.float32), (3, 1))
+        c.load_scene(tri, nrm, np.ones((3, 3), np.float32), [0, 1, 2], [2])
+        c.render(0, 1, 3)
+        img = c.read_accum()
+        assert (img[..., :3] == 1.0).all()
+    finally:
+        c.close()
+
+
+# ------------------------------------------------------------------ whole path
+@pytest.mark.parametrize("w,h,spp,bounces", [(256, 256, 1, 1), (96, 64, 4, 3), (48, 32, 2, 8), (33, 17, 3, 15)])
+def test_render_strict_is_bit_exact(capi, O, cornell, w, h, spp, bounces):
+    off = O.pixel_offsets(w, h)
+    c = make_ctx(O, cornell, w, h, offsets=off)
+    try:
+        O.set_trig_mode(O.TRIG_PORTABLE)
+        ref, st = O.render(cornell, w, h, spp, bounces, offsets=off)
+        c.set_option(capi.OPT_STRICT, 1)
+        c.render(0, spp, bounces)
+        img, gs = c.read_accum(), c.stats()
+        assert np.array_equal(_bits(img), _bits(ref))
+        assert (gs.primary_rays, gs.bounce_rays, gs.shadow_rays, gs.shaded_hits) == (st.primary_rays, st.bounce_rays, st.shadow_rays, st.shaded_hits)
+    finally:
+        O.set_trig_mode(O.TRIG_LIBM)
+        c.close()
+
+
+def test_render_c1_fast_within_tolerance_and_golden(capi, O, cornell, ctx256, golden):
+    """Config C1: 256x256, 1 spp, 1 bounce."""
+    off = O.pixel_offsets(256, 256)
+    ref, st = O.render(cornell, 256, 256, 1, 1, offsets=off)
+    ctx256.set_option(capi.OPT_STRICT, 0)
+    ctx256.reset_stats()
+    ctx256.render(0, 1, 1)
+    img, gs = ctx256.read_accum(), ctx256.stats()
+    rmse, frac_ok, worst = image_metrics(img, ref)
+    assert rmse <= TOL_RMSE and frac_ok >= TOL_FRAC, (rmse, frac_ok, worst)
+    rmse, frac_ok, _ = image_metrics(img, golden["frame_c1_256_1spp_1b"])
+    assert rmse <= TOL_RMSE and frac_ok >= TOL_FRAC
+    assert gs.rays == st.rays == int(golden["rays_c1"][:3].sum())
+    assert (img[..., 3] == 1.0).all()
+
+
+@pytest.mark.parametrize("w,h,spp,bounces", [(128, 96, 16, 3), (64, 64, 8, 8)])
+def test_render_fast_within_tolerance(capi, O, cornell, w, h, spp, bounces):
+    off = O.pixel_offsets(w, h)
+    c = make_ctx(O, cornell, w, h, offsets=off)
+    try:
+        ref, st = O.render(cornell, w, h, spp, bounces, offsets=off)
+        c.render(0, spp, bounces)
+        img, gs = c.read_accum(), c.stats()
+        rmse, frac_ok, worst = image_metrics(img, ref)
+        assert rmse <= TOL_RMSE and frac_ok >= TOL_FRAC, (rmse, frac_ok, worst)
+        assert abs(gs.rays - st.rays) <= 1e-4 * st.rays
+    finally:
+        c.close()
+
+
+def test_golden_frames_on_gpu(capi, O, cornell, golden):
+    c = make_ctx(O, cornell, 64, 64)
+    try:
+        c.set_option(capi.OPT_STRICT, 1)
+        c.render(0, 4, 3)
+        d = np.abs(c.read_accum() - golden["frame_64_4spp_3b_portable"])
+        assert (d.max(-1) > 1e-5).mean() < 0.002
+        assert c.stats().rays == int(golden["rays_64_4spp_3b_portable"][:3].sum())
+    finally:
+        c.close()
+
+
+def test_continuation_bands_and_determinism(capi, O, cornell):
+    """Size-independent properties: frames [0,6) == [0,2)+[2,6); union of row bands == full frame;
+    repeated launches are bitwise identical; LDS-resident and HBM-resident scenes agree bitwise."""
+    w, h = 80, 48
+    c = make_ctx(O, cornell, w, h)
+    try:
+        for strict in (0, 1):
+            c.set_option(capi.OPT_STRICT, strict)
+            c.render(0, 6, 3)
+            full = c.read_accum()
+            c.render(0, 6, 3)
+            assert np.array_equal(_bits(full), _bits(c.read_accum()))
+            c.render(0, 2, 3)
+            c.render(2, 4, 3)
+            assert np.array_equal(_bits(full), _bits(c.read_accum()))
+            c.render(0, 1, 3)            # clobber, then rebuild from uneven bands
+            for row0, rows in ((0, 7), (7, 16), (23, 1), (24, 24)):
+                c.render(0, 6, 3, row0, rows)
+            assert np.array_equal(_bits(full), _bits(c.read_accum()))
+            # other kernel instantiations (scene in HBM, counters on): bitwise equal in the strict build;
+            # in the fast build the compiler may contract differently per instantiation -> tolerance
+            def same(img):
+                if strict:
+                    return np.array_equal(_bits(full), _bits(img))
+                rmse, frac_ok, _ = image_metrics(img, full)
+                return rmse <= TOL_RMSE and frac_ok >= TOL_FRAC
+            c.set_option(capi.OPT_FORCE_GLOBAL, 1)
+            c.render(0, 6, 3)
+            assert same(c.read_accum())
+            c.set_option(capi.OPT_FORCE_GLOBAL, 0)
+            c.set_option(capi.OPT_COUNTERS, 1)
+            c.reset_stats()
+            c.render(0, 6, 3)
+            st = c.stats()
+            assert same(c.read_accum())
+            assert st.node_fetches > st.rays and st.tri_tests > 0
+            c.set_option(capi.OPT_COUNTERS, 0)
+    finally:
+        c.close()
+
+
+def test_full_size_c2_properties(capi, O, cornell):
+    """Config C2 (1920x1080, 16 spp, 3 bounces) at full size: invariants of the whole frame plus an exact
+    comparison of 24 sampled rows against the oracle (the oracle renders bands independently)."""
+    w, h, spp, bnc = 1920, 1080, 16, 3
+    c = make_ctx(O, cornell, w, h)
+    try:
+        c.render(0, spp, bnc)
+        img, st = c.read_accum(), c.stats()
+        assert np.isfinite(img).all() and (img[..., 3] == 1.0).all() and (img[..., :3] >= 0).all()
+        assert st.primary_rays == w * h * spp and st.shadow_rays == st.shaded_hits
+        assert st.bounce_rays <= st.shaded_hits and st.rays <= 2 * bnc * w * h * spp
+        # the side bars (outside the box opening: |x_ndc| > ~0.6 at 16:9) never hit anything
+        assert (img[:, :300, :3] == 0).all() and (img[:, -300:, :3] == 0).all()
+        # left wall red, right wall green (row 0 = scene bottom)
+        left, right = img[400:700, 480:560, :3].mean((0, 1)), img[400:700, 1360:1440, :3].mean((0, 1))
+        assert left[0] > 3 * left[1] and right[1] > 2 * right[0]
+        # light texels are exactly the light colour and sit in the upper half
+        ys, _ = np.where((img[..., :3] == 1.0).all(-1))
+        assert ys.size > 1000 and ys.min() > h // 2
+        off = O.pixel_offsets(w, h)
+        acc = np.zeros((h, w, 4), np.float32)
+        rows = [(40, 8), (536, 8), (1000, 8)]
+        for r0, n in rows:
+            O.render(cornell, w, h, spp, bnc, row0=r0, rows=n, accum=acc, offsets=off)
+        got = np.concatenate([img[r0:r0 + n] for r0, n in rows])
+        ref = np.concatenate([acc[r0:r0 + n] for r0, n in rows])
+        rmse, frac_ok, worst = image_metrics(got, ref)
+        assert rmse <= TOL_RMSE and frac_ok >= TOL_FRAC, (rmse, frac_ok, worst)
+    finally:
+        c.close()
+
+
+def test_invalid_material_is_magenta(capi, O):
+    s = O.OracleScene()
+    m = np.eye(4, dtype=np.float32)
+    quad = np.array([[-3, -3, 0], [3, -3, 0], [3, 3, 0], [-3, 3, 0]], np.float32) + np.array([0, 1, 0], np.float32)
+    s.add_geometry(quad, [0, 1, 2, 0, 2, 3], m, (0.5, 0.5, 0.5), 3)   # neither DEFAULT nor EMISSIVE
+    c = make_ctx(O, s, 32, 32)
+    try:
+        for strict, mode in ((1, O.TRIG_PORTABLE), (0, O.TRIG_LIBM)):
+            O.set_trig_mode(mode)
+            ref, _ = O.render(s, 32, 32, 2, 3, offsets=O.pixel_offsets(32, 32))
+            c.set_option(capi.OPT_STRICT, strict)
+            c.render(0, 2, 3)
+            img = c.read_accum()
+            assert np.array_equal(_bits(img), _bits(ref))
+        assert (img[..., :3] == np.array([1, 0, 1], np.float32)).all()
+    finally:
+        O.set_trig_mode(O.TRIG_LIBM)
+        c.close()
+
+
+def test_error_behaviour(capi, O, cornell):
+    c = capi.Context(64, 48)
+    try:
+        with pytest.raises(capi.TrgError) as e:
+            c.render(0, 1, 3)
+        assert e.value.code == capi.ERR_INVALID and "scene" in str(e.value)
+        b = cornell.buffers()
+        c.load_scene(b["positions"], b["normals"], b["colors"], b["indices"], b["material_ids"])
+        with pytest.raises(capi.TrgError):
+            c.render(0, 1, 3)                      # no uniforms yet
+        with pytest.raises(capi.TrgError):
+            c.set_uniforms(O.uniforms_bytes(O.make_uniforms(32, 32)))   # wrong size
+        c.set_uniforms(O.uniforms_bytes(O.make_uniforms(64, 48)))
+        with pytest.raises(capi.TrgError):
+            c.render(0, 1, 3)                      # no pixel offsets yet
+        c.set_pixel_offsets_seed()
+        for args in ((0, 1, 16), (0, 1, 3, 40, 9), (0, 1, 3, 49, 0), (2 ** 32 - 1, 2, 3)):
+            with pytest.raises(capi.TrgError):
+                c.render(*args)
+        c.render(0, 0, 3)                          # zero samples / rows: a no-op, not an error
+        c.render(0, 1, 3, 10, 0)
+        bad = b["indices"].copy()
+        bad[5] = 1000
+        with pytest.raises(capi.TrgError):
+            c.load_scene(b["positions"], b["normals"], b["colors"], bad, b["material_ids"])
+        with pytest.raises(capi.TrgError):
+            capi.Context(16, 16, device=99)
+    finally:
+        c.close()
+
+
+# ------------------------------------------------------------------ plugin surface + N1
+def test_reference_app_call_sequence(capi, O, cornell, tmp_path):
+    """Engine -> shaders -> renderer.init -> camera -> loadScene -> renderFrame loop (main.cpp:21-95): the
+    progressive 1-sample-per-renderFrame loop equals one batched launch bit for bit, and the oracle within tolerance."""
+    from toyraygun_amd import host
+    w, h, frames = 160, 120, 8
+    png = str(tmp_path / "app.png")
+    prog, _, rays_p = host.run_app(w, h, frames, 3, batch=False, png_path=png)
+    batch, _, rays_b = host.run_app(w, h, frames, 3, batch=True)
+    assert np.array_equal(_bits(prog), _bits(batch)) and rays_p == rays_b
+    ref, st = O.render(cornell, w, h, frames, 3)
+    rmse, frac_ok, worst = image_metrics(prog, ref)
+    assert rmse <= TOL_RMSE and frac_ok >= TOL_FRAC, (rmse, frac_ok, worst)
+    assert abs(rays_p - st.rays) <= 1e-4 * st.rays
+    from PIL import Image
+    im = np.asarray(Image.open(png).convert("RGBA"))
+    assert im.shape == (h, w, 4)
+    want = O.postprocess(prog, flip_y=True)
+    assert np.abs(im.astype(int) - want.astype(int)).max() <= 1
+
+
+def test_postprocess_matches_oracle(capi, O, cornell):
+    c = make_ctx(O, cornell, 96, 64)
+    try:
+        c.render(0, 8, 3)
+        acc = c.read_accum()
+        for flip in (True, False):
+            got, want = c.postprocess(flip_y=flip), O.postprocess(acc, flip_y=flip)
+            assert np.abs(got.astype(int) - want.astype(int)).max() <= 1
+            assert (got[..., 3] == 255).all()
+    finally:
+        c.close()
+
+
+def test_external_accum_buffer_and_stream(capi, O, cornell):
+    """trg_bind_accum / trg_set_stream: render straight into a torch tensor on torch's stream."""
+    import torch
+    w, h = 64, 40
+    c = make_ctx(O, cornell, w, h)
+    try:
+        c.render(0, 3, 3)
+        want = c.read_accum()
+        frame = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda:0")
+        c.bind_accum(frame.data_ptr())
+        stream = torch.cuda.Stream()
+        c.set_stream(stream.cuda_stream)
+        c.render(0, 3, 3)
+        stream.synchronize()
+        assert np.array_equal(_bits(frame.cpu().numpy()), _bits(want))
+        assert c.accum_device_ptr() == frame.data_ptr()
+        c.bind_accum(None)
+        c.set_stream(None)
+    finally:
+        c.close()
+
+
+def test_single_rank_distributed_renderer(capi, O, cornell):
+    from toyraygun_amd.dist import DistributedRenderer
+    r = DistributedRenderer(64, 32, 0)
+    try:
+        r.load_scene(cornell.buffers())
+        r.ctx.set_uniforms(O.uniforms_bytes(O.make_uniforms(64, 32)))
+        r.ctx.set_pixel_offsets_seed()
+        frame = r.render(0, 2, 3)
+        r.synchronize()
+        ref, _ = O.render(cornell, 64, 32, 2, 3)
+        rmse, frac_ok, _ = image_metrics(frame.cpu().numpy(), ref)
+        assert rmse <= TOL_RMSE and frac_ok >= TOL_FRAC
+    finally:
+        r.close()

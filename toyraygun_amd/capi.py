@@ -79,6 +79,8 @@ _SYMBOLS = [
     ("trg_raygen", C.c_int, [_P, C.c_uint32, _P]),
     ("trg_sample", C.c_int, [_P, _P, _P, _P, C.c_size_t, _P]),
     ("trg_postprocess", C.c_int, [_P, _P, C.c_int]),
+    ("trg_debug_build_bvh", C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32,
+                                      C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
 ]
 SYMBOL_NAMES = [s[0] for s in _SYMBOLS]
 
@@ -232,3 +234,23 @@ class Context:
         out = np.empty((self.h, self.w, 4), np.uint8)
         self._chk(self.L.trg_postprocess(self.h_ctx, _ptr(out), 1 if flip_y else 0))
         return out
+
+
+def debug_build_bvh(positions, indices, material_ids):
+    """Host-only BVH build (no GPU): returns (nodes[n,16] float32, tris[m,12] float32, depth)."""
+    L = load()
+    pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+    idx = np.ascontiguousarray(indices, np.uint32).reshape(-1)
+    mat = np.ascontiguousarray(material_ids, np.uint32).reshape(-1)
+    nn, nr, dp = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    rc = L.trg_debug_build_bvh(_ptr(pos), _ptr(idx), _ptr(mat), pos.shape[0], mat.shape[0], None, 0, None, 0,
+                               C.byref(nn), C.byref(nr), C.byref(dp))
+    if rc != OK:
+        raise TrgError(rc, "trg_debug_build_bvh")
+    nodes = np.zeros((nn.value, 16), np.float32)
+    tris = np.zeros((nr.value, 12), np.float32)
+    rc = L.trg_debug_build_bvh(_ptr(pos), _ptr(idx), _ptr(mat), pos.shape[0], mat.shape[0], _ptr(nodes), nn.value,
+                               _ptr(tris), nr.value, C.byref(nn), C.byref(nr), C.byref(dp))
+    if rc != OK:
+        raise TrgError(rc, "trg_debug_build_bvh")
+    return nodes, tris, dp.value

@@ -1,0 +1,117 @@
+// HipRenderer.cpp -- toyraygun::Renderer backend for MI355X (see include/engine/HipRenderer.h).
+// Everything that touches the GPU goes through the C ABI of include/trg.h.
+#include "engine/HipRenderer.h"
+
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "png_writer.h"
+#include "trg.h"
+
+namespace toyraygun {
+
+HipRenderer::HipRenderer() : m_ctx(nullptr), m_bounces(3), m_offsetSeed(0x5EED0001u), m_sceneLoaded(false) {}
+HipRenderer::~HipRenderer() { destroy(); }
+
+bool HipRenderer::init() {
+    Renderer::init();  // width/height/aspect from the Engine (Renderer.cpp:18-27)
+    if (m_ctx) { trg_destroy(m_ctx); m_ctx = nullptr; }
+    const int rc = trg_create(&m_ctx, Engine::instance()->getDevice(), (uint32_t)m_width, (uint32_t)m_height);
+    if (rc != TRG_OK) {
+        printf("HipRenderer: %s\n", trg_last_error(nullptr));
+        m_ctx = nullptr;
+        return false;
+    }
+    // the reference creates the random-offset texture in resize() (MetalRenderer.mm:323-335)
+    if (trg_set_pixel_offsets_seed(m_ctx, m_offsetSeed) != TRG_OK) {
+        printf("HipRenderer: %s\n", trg_last_error(m_ctx));
+        return false;
+    }
+    m_frameIndex = 0;  // MetalRenderer.mm:337
+    m_sceneLoaded = false;
+    return true;
+}
+
+void HipRenderer::destroy() {
+    if (m_ctx) trg_destroy(m_ctx);
+    m_ctx = nullptr;
+    m_sceneLoaded = false;
+}
+
+void HipRenderer::loadScene(Scene *scene) {
+    if (!m_ctx || !scene) return;
+    static_assert(sizeof(bx::Vec3) == 12, "bx::Vec3 must be 3 packed floats");
+    const uint32_t nTris = (uint32_t)scene->m_materialIDBuffer.size();
+    const uint32_t nVerts = (uint32_t)scene->m_vertexBuffer.size();
+    const float *pos = nVerts ? &scene->m_vertexBuffer[0].x : nullptr;
+    const float *nrm = nVerts ? &scene->m_normalBuffer[0].x : nullptr;
+    const float *col = nVerts ? &scene->m_colorBuffer[0].x : nullptr;
+    const uint32_t *idx = nVerts ? &scene->m_indexBuffer[0] : nullptr;
+    const uint32_t *mat = nTris ? &scene->m_materialIDBuffer[0] : nullptr;
+    if (trg_load_scene(m_ctx, pos, nrm, col, idx, mat, nVerts, nTris) != TRG_OK) {
+        printf("HipRenderer: %s\n", trg_last_error(m_ctx));
+        m_sceneLoaded = false;
+        return;
+    }
+    m_sceneLoaded = true;
+}
+
+// MetalRenderer.mm:340-371: inverse view-projection, fixed ceiling light, frame index.
+void HipRenderer::fillUniforms(Uniforms *u) {
+    memset(u, 0, sizeof(*u));
+    float viewProj[16], invViewProj[16];
+    getViewProjMtx(viewProj);
+    bx::mtxInverse(invViewProj, viewProj);
+    u->camera.position.set(getCameraPosition());
+    u->camera.invViewProjMtx.set(invViewProj);
+    u->light.position.set(bx::Vec3(0.0f, 1.98f, 0.0f));
+    u->light.forward.set(bx::Vec3(0.0f, -1.0f, 0.0f));
+    u->light.right.set(bx::Vec3(0.25f, 0.0f, 0.0f));
+    u->light.up.set(bx::Vec3(0.0f, 0.0f, 0.25f));
+    u->light.color.set(bx::Vec3(1.0f, 1.0f, 1.0f));
+    u->width = (unsigned int)m_width;
+    u->height = (unsigned int)m_height;
+    u->frameIndex = (unsigned int)m_frameIndex;
+}
+
+bool HipRenderer::renderFrames(unsigned int frames) {
+    if (!m_ctx || !m_sceneLoaded || frames == 0) return false;
+    Uniforms u;
+    fillUniforms(&u);
+    static_assert(sizeof(Uniforms) == sizeof(trg_uniforms), "Uniforms / trg_uniforms layout mismatch");
+    if (trg_set_uniforms(m_ctx, reinterpret_cast<const trg_uniforms *>(&u)) != TRG_OK ||
+        trg_render(m_ctx, (uint32_t)m_frameIndex, frames, m_bounces, 0, (uint32_t)m_height) != TRG_OK) {
+        printf("HipRenderer: %s\n", trg_last_error(m_ctx));
+        return false;
+    }
+    m_frameIndex += (int)frames;  // uniforms->frameIndex = _frameIndex++ (MetalRenderer.mm:363), once per frame
+    return true;
+}
+
+void HipRenderer::renderFrame() { renderFrames(1); }
+
+void HipRenderer::setBounces(unsigned int bounces) { m_bounces = bounces; }
+void HipRenderer::setOffsetSeed(uint32_t seed) {
+    m_offsetSeed = seed;
+    if (m_ctx) trg_set_pixel_offsets_seed(m_ctx, seed);
+}
+bool HipRenderer::readAccumulation(float *rgbaOut) { return m_ctx && trg_read_accum(m_ctx, rgbaOut) == TRG_OK; }
+bool HipRenderer::savePNG(const char *path) {
+    if (!m_ctx) return false;
+    std::vector<uint8_t> rgba((size_t)m_width * m_height * 4);
+    if (trg_postprocess(m_ctx, rgba.data(), 1) != TRG_OK) return false;
+    return trg_host::write_png_rgba8(path, rgba.data(), m_width, m_height);
+}
+double HipRenderer::getLastRenderMs() const {
+    trg_stats st;
+    return (m_ctx && trg_get_stats(m_ctx, &st) == TRG_OK) ? st.last_render_ms : 0.0;
+}
+uint64_t HipRenderer::getRayCount() const {
+    trg_stats st;
+    return (m_ctx && trg_get_stats(m_ctx, &st) == TRG_OK) ? st.primary_rays + st.bounce_rays + st.shadow_rays : 0;
+}
+const char *HipRenderer::getLastError() const { return trg_last_error(m_ctx); }
+
+}  // namespace toyraygun

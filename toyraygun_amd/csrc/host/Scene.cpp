@@ -1,0 +1,84 @@
+// Scene.cpp -- toyraygun::Scene geometry builders (a1 of SURVEY 8a; reference src/engine/Scene.cpp:13-129).
+#include "engine/Scene.h"
+
+#include "engine/Renderer.h"
+
+namespace toyraygun {
+namespace {
+
+// unit cube corners, bit 0 = +x, bit 1 = +y, bit 2 = +z (Scene.cpp:13-22)
+bx::Vec3 corner(int i) { return bx::Vec3((i & 1) ? 0.5f : -0.5f, (i & 2) ? 0.5f : -0.5f, (i & 4) ? 0.5f : -0.5f); }
+
+bx::Vec3 transformed(const bx::Vec3 &v, const float *mtx, float w) {
+    const float in[4] = { v.x, v.y, v.z, w };
+    float out[4];
+    bx::vec4MulMtx(out, in, mtx);
+    return bx::Vec3(out[0], out[1], out[2]);
+}
+
+// the quad both addPlane and addAreaLight use: the cube's bottom face (corners 0,1,5,4), two
+// triangles wound 0-2-1 / 0-3-2 (Scene.cpp:60-92)
+void quad(bx::Vec3 *verts, uint32_t *tris) {
+    const int sel[4] = { 0, 1, 5, 4 };
+    for (int i = 0; i < 4; ++i) verts[i] = corner(sel[i]);
+    const uint32_t t[6] = { 0, 2, 1, 0, 3, 2 };
+    for (int i = 0; i < 6; ++i) tris[i] = t[i];
+}
+
+}  // namespace
+
+void Scene::addCube(bx::Vec3 color, float *transformMtx) {
+    bx::Vec3 verts[8];
+    for (int i = 0; i < 8; ++i) verts[i] = corner(i);
+    // face order and winding of Scene.cpp:37-55: -x, +x, -y, +y, -z, +z
+    uint32_t tris[36] = { 0, 4, 6, 0, 6, 2, 1, 3, 7, 1, 7, 5, 0, 1, 5, 0, 5, 4,
+                          2, 6, 7, 2, 7, 3, 0, 2, 3, 0, 3, 1, 4, 5, 7, 4, 7, 6 };
+    addGeometry(verts, tris, 12, transformMtx, color, MATERIAL_DEFAULT);
+}
+
+void Scene::addPlane(bx::Vec3 color, float *transformMtx) {
+    bx::Vec3 verts[4];
+    uint32_t tris[6];
+    quad(verts, tris);
+    addGeometry(verts, tris, 2, transformMtx, color, MATERIAL_DEFAULT);
+}
+
+void Scene::addAreaLight(bx::Vec3 color, float *transformMtx) {
+    bx::Vec3 verts[4];
+    uint32_t tris[6];
+    quad(verts, tris);
+    addGeometry(verts, tris, 2, transformMtx, color, MATERIAL_EMISSIVE);
+}
+
+// Flattening rule (Scene.cpp:102-129): per triangle, the face normal is taken from the UNtransformed
+// corners, pushed through the matrix with w = 0 and re-normalised; each corner gets its own vertex.
+void Scene::addGeometry(bx::Vec3 *vertices, uint32_t *indices, int triangleCount, float *transformMtx, bx::Vec3 color,
+                        unsigned int materialID) {
+    for (int t = 0; t < triangleCount; ++t) {
+        const uint32_t *tri = &indices[t * 3];
+        const bx::Vec3 faceNormal = bx::calcNormal(vertices[tri[0]], vertices[tri[1]], vertices[tri[2]]);
+        for (int c = 0; c < 3; ++c) {
+            m_vertexBuffer.push_back(transformed(vertices[tri[c]], transformMtx, 1.0f));
+            m_indexBuffer.push_back((uint32_t)(m_vertexBuffer.size() - 1));
+            m_normalBuffer.push_back(bx::normalize(transformed(faceNormal, transformMtx, 0.0f)));
+            m_colorBuffer.push_back(color);
+        }
+        m_materialIDBuffer.push_back(materialID);
+    }
+}
+
+void Scene::addMesh(const bx::Vec3 *vertices, const bx::Vec3 *normals, const uint32_t *indices, int triangleCount,
+                    float *transformMtx, bx::Vec3 color, unsigned int materialID) {
+    for (int t = 0; t < triangleCount; ++t) {
+        const uint32_t *tri = &indices[t * 3];
+        for (int c = 0; c < 3; ++c) {
+            m_vertexBuffer.push_back(transformed(vertices[tri[c]], transformMtx, 1.0f));
+            m_indexBuffer.push_back((uint32_t)(m_vertexBuffer.size() - 1));
+            m_normalBuffer.push_back(bx::normalize(transformed(normals[tri[c]], transformMtx, 0.0f)));
+            m_colorBuffer.push_back(color);
+        }
+        m_materialIDBuffer.push_back(materialID);
+    }
+}
+
+}  // namespace toyraygun

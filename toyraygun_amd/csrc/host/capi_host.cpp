@@ -1,0 +1,146 @@
+// capi_host.cpp -- flat C entry points over the C++ plugin surface, so the Python tests can drive
+// Engine / Renderer / Scene / HipRenderer exactly the way the reference app does (main.cpp:16-98).
+// Test plumbing for libtoyraygun.so; the product boundary is include/trg.h.
+#include <string.h>
+
+#include "cornellBox.h"
+#include "engine/Engine.h"
+#include "engine/HipRenderer.h"
+#include "engine/Renderer.h"
+#include "engine/Shader.h"
+#include "engine/Texture.h"
+
+using namespace toyraygun;
+
+extern "C" {
+
+// ---- scene (a1) ----
+void *trh_scene_new() { return new Scene(); }
+void *trh_scene_cornell() { return createCornellBoxScene(); }
+void trh_scene_free(void *s) { delete static_cast<Scene *>(s); }
+void trh_scene_add(void *s, int kind, const float *color3, const float *mtx16) {
+    Scene *sc = static_cast<Scene *>(s);
+    float m[16];
+    memcpy(m, mtx16, sizeof(m));
+    const bx::Vec3 c(color3[0], color3[1], color3[2]);
+    if (kind == 0) sc->addCube(c, m);
+    else if (kind == 1) sc->addPlane(c, m);
+    else sc->addAreaLight(c, m);
+}
+void trh_scene_add_mesh(void *s, const float *verts3, const float *normals3, const uint32_t *indices, int triCount,
+                        const float *mtx16, const float *color3, unsigned int materialID) {
+    float m[16];
+    memcpy(m, mtx16, sizeof(m));
+    static_cast<Scene *>(s)->addMesh(reinterpret_cast<const bx::Vec3 *>(verts3), reinterpret_cast<const bx::Vec3 *>(normals3),
+                                     indices, triCount, m, bx::Vec3(color3[0], color3[1], color3[2]), materialID);
+}
+unsigned int trh_scene_counts(void *s, unsigned int *nTris) {
+    Scene *sc = static_cast<Scene *>(s);
+    if (nTris) *nTris = (unsigned int)sc->m_materialIDBuffer.size();
+    return (unsigned int)sc->m_vertexBuffer.size();
+}
+void trh_scene_copy(void *s, float *pos, float *nrm, float *col, uint32_t *idx, uint32_t *mat) {
+    Scene *sc = static_cast<Scene *>(s);
+    const size_t nv = sc->m_vertexBuffer.size(), nt = sc->m_materialIDBuffer.size();
+    if (nv) {
+        memcpy(pos, &sc->m_vertexBuffer[0], nv * 12);
+        memcpy(nrm, &sc->m_normalBuffer[0], nv * 12);
+        memcpy(col, &sc->m_colorBuffer[0], nv * 12);
+        memcpy(idx, &sc->m_indexBuffer[0], nv * 4);
+    }
+    if (nt) memcpy(mat, &sc->m_materialIDBuffer[0], nt * 4);
+}
+
+// ---- bx matrices (a2) ----
+void trh_mtx_srt(float *m, const float *s3, const float *r3, const float *t3) {
+    bx::mtxSRT(m, s3[0], s3[1], s3[2], r3[0], r3[1], r3[2], t3[0], t3[1], t3[2]);
+}
+void trh_mtx_inverse(float *out, const float *in) { bx::mtxInverse(out, in); }
+
+// ---- camera + uniforms without a GPU (a2, a3): a Renderer subclass that only does the host math ----
+namespace {
+struct CameraProbe : public HipRenderer {
+    void setup(int w, int h) { m_width = w; m_height = h; m_aspectRatio = float(w) / float(h); }
+    void setFrame(int f) { m_frameIndex = f; }
+};
+}  // namespace
+void trh_uniforms(int w, int h, int frameIndex, const float *eye3, const float *at3, void *uniforms176, float *viewProj16) {
+    CameraProbe r;
+    r.setup(w, h);
+    r.setCameraPosition(bx::Vec3(eye3[0], eye3[1], eye3[2]));
+    r.setCameraLookAt(bx::Vec3(at3[0], at3[1], at3[2]));
+    r.setFrame(frameIndex);
+    Uniforms u;
+    r.fillUniforms(&u);
+    memcpy(uniforms176, &u, sizeof(u));
+    if (viewProj16) r.getViewProjMtx(viewProj16);
+}
+
+// ---- random texture (a4) ----
+void trh_random_texture(int w, int h, uint32_t seed, uint32_t *out) {
+    Texture t = Texture::generateRandomTexture(w, h, 4, seed);
+    memcpy(out, t.getBufferPointer(), t.getBufferSize());
+    t.destroy();
+}
+
+// ---- the reference app's call sequence (main.cpp:21-95), headless ----
+// returns 0 on success; negative = the step that failed
+int trh_run_app(int w, int h, int frames, int bounces, int batch, int device, float *accumOut, const char *pngPath,
+                double *msOut, unsigned long long *raysOut) {
+    Engine *engine = Engine::instance();
+    engine->setDevice(device);
+    engine->init(w, h);
+    engine->setFrameBudget(frames);
+
+    const char *names[3] = { "Raytracing", "Accumulate", "PostProcessing" };
+    Shader *shaders[3];
+    for (int i = 0; i < 3; ++i) {
+        shaders[i] = Engine::createShader();
+        if (!shaders[i]->load(names[i])) return -1;
+    }
+    shaders[0]->addFunction("raygen", ShaderFunctionType::RayGen);
+    shaders[0]->addFunction("primaryHit", ShaderFunctionType::ClosestHit);
+    shaders[0]->addFunction("primaryMiss", ShaderFunctionType::Miss);
+    shaders[0]->addFunction("shadowHit", ShaderFunctionType::ShadowHit);
+    shaders[0]->addFunction("shadowMiss", ShaderFunctionType::ShadowMiss);
+    shaders[1]->addFunction("accumulate", ShaderFunctionType::Compute);
+    shaders[2]->addFunction("vert", ShaderFunctionType::Vertex);
+    shaders[2]->addFunction("frag", ShaderFunctionType::Fragment);
+    if (!shaders[0]->compile(ShaderType::Raytrace) || !shaders[1]->compile(ShaderType::Compute) ||
+        !shaders[2]->compile(ShaderType::Graphics))
+        return -2;
+
+    Renderer *renderer = Engine::createRenderer();
+    if (!renderer->init()) return -3;
+    for (int i = 0; i < 3; ++i) renderer->addShader(shaders[i]);
+    renderer->setCameraPosition(bx::Vec3(0.0f, 1.0f, 3.38f));
+    renderer->setCameraLookAt(bx::Vec3(0.0f, 1.0f, -1.0f));
+
+    Scene *scene = createCornellBoxScene();
+    renderer->loadScene(scene);
+    delete scene;  // loadScene borrows only for the call
+
+    HipRenderer *hip = static_cast<HipRenderer *>(renderer);
+    hip->setBounces((unsigned int)bounces);
+    int rc = 0;
+    if (batch) {
+        if (!hip->renderFrames((unsigned int)frames)) rc = -4;
+    } else {
+        while (!engine->hasQuit()) {  // main.cpp:91-95
+            engine->pollEvents();
+            if (engine->hasQuit()) break;
+            renderer->renderFrame();
+        }
+        if (hip->getFrameIndex() != frames) rc = -4;
+    }
+    if (rc == 0 && accumOut && !hip->readAccumulation(accumOut)) rc = -5;
+    if (rc == 0 && pngPath && pngPath[0] && !hip->savePNG(pngPath)) rc = -6;
+    if (msOut) *msOut = hip->getLastRenderMs();
+    if (raysOut) *raysOut = hip->getRayCount();
+    renderer->destroy();
+    delete renderer;
+    for (int i = 0; i < 3; ++i) delete shaders[i];
+    return rc;
+}
+
+}  // extern "C"

@@ -312,6 +312,32 @@ int trg_sync(trg_ctx *c) {
     return TRG_OK;
 }
 
+// ---- host-only introspection: build the BVH exactly as trg_load_scene does and hand back the flattened
+//      arrays (no GPU needed).  nodes_out: 16 floats per node, tris_out: 12 floats per record; either may be
+//      NULL to query sizes only. ----
+int trg_debug_build_bvh(const float *positions3, const uint32_t *indices, const uint32_t *material_ids, uint32_t n_verts,
+                        uint32_t n_tris, float *nodes_out, uint32_t nodes_cap, float *tris_out, uint32_t tris_cap,
+                        uint32_t *n_nodes, uint32_t *n_tri_records, uint32_t *depth) {
+    if (n_tris && (!positions3 || !indices || !material_ids)) return TRG_ERR_INVALID;
+    for (size_t i = 0; i < (size_t)n_tris * 3; ++i)
+        if (indices[i] >= n_verts) return TRG_ERR_INVALID;
+    Bvh bvh;
+    build_bvh(positions3, indices, material_ids, n_tris, bvh);
+    const uint32_t nrec = (uint32_t)(bvh.tris.size() / 3);
+    if (n_nodes) *n_nodes = bvh.n_nodes;
+    if (n_tri_records) *n_tri_records = nrec;
+    if (depth) *depth = bvh.depth;
+    if (nodes_out) {
+        if (nodes_cap < bvh.n_nodes) return TRG_ERR_RANGE;
+        memcpy(nodes_out, bvh.nodes.data(), (size_t)bvh.n_nodes * 64);
+    }
+    if (tris_out) {
+        if (tris_cap < nrec) return TRG_ERR_RANGE;
+        memcpy(tris_out, bvh.tris.data(), (size_t)nrec * 48);
+    }
+    return TRG_OK;
+}
+
 // ---- stage-level entry points (host buffers in, host buffers out) ----
 namespace {
 struct DevBuf {

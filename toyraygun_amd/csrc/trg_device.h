@@ -322,7 +322,13 @@ struct LdsStack {
 template <bool ANY, bool COUNT, int BLOCK>
 TRG_DEV bool traverse(const SceneView &sc, V3 o, V3 d, float tmax_ray, uint32_t rmask, Hit &hit, LdsStack<BLOCK> stk,
                       Counters &cnt) {
-    const float idx = rcp_fast(d.x), idy = rcp_fast(d.y), idz = rcp_fast(d.z);
+    // Reciprocal direction with zero components pushed to +-1e-30: the slab products stay finite (no
+    // inf - inf = NaN whose fmin/fmax would pick the wrong endpoint), and a ray that moves 1e-30 per
+    // unit t along an axis is parallel to the slab for every practical purpose.
+    const float dx = fabsf(d.x) < 1e-30f ? copysignf(1e-30f, d.x) : d.x;
+    const float dy = fabsf(d.y) < 1e-30f ? copysignf(1e-30f, d.y) : d.y;
+    const float dz = fabsf(d.z) < 1e-30f ? copysignf(1e-30f, d.z) : d.z;
+    const float idx = rcp_fast(dx), idy = rcp_fast(dy), idz = rcp_fast(dz);
     const float oix = o.x * idx, oiy = o.y * idy, oiz = o.z * idz;
     float best = tmax_ray;
     bool found = false;
@@ -334,7 +340,8 @@ TRG_DEV bool traverse(const SceneView &sc, V3 o, V3 d, float tmax_ray, uint32_t 
             const v4f n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
             if (COUNT) cnt.nodes++;
             // slab tests; (b - o) * inv written as b*inv - o*inv so the fast build gets one fma each.
-            // fmin/fmax drop NaN (0 * inf), which only widens the interval: conservative.
+            // Boxes are padded by 2e-5 x scene extent on the host, far more than the rounding of these
+            // products, so a triangle the Moeller-Trumbore test accepts is never culled.
             const float ax0 = n0.x * idx - oix, ax1 = n0.y * idx - oix, ay0 = n0.z * idy - oiy, ay1 = n0.w * idy - oiy;
             const float bx0 = n1.x * idx - oix, bx1 = n1.y * idx - oix, by0 = n1.z * idy - oiy, by1 = n1.w * idy - oiy;
             const float az0 = n2.x * idz - oiz, az1 = n2.y * idz - oiz, bz0 = n2.z * idz - oiz, bz1 = n2.w * idz - oiz;

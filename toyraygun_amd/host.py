@@ -1,0 +1,129 @@
+"""ctypes binding of libtoyraygun.so: the host-side C++ mirror of the reference's plugin surface
+(Engine / Renderer / Scene / Shader / HipRenderer, include/engine/*.h) through its flat test shim
+(toyraygun_amd/csrc/host/capi_host.cpp).  Scene building and camera math run on the CPU; anything that
+renders needs the GPU library and a gfx950 device.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import capi
+
+HOST_SO = os.path.join(capi.LIB_DIR, "libtoyraygun.so")
+_lib = None
+
+SYMBOL_NAMES = ["trh_scene_new", "trh_scene_cornell", "trh_scene_free", "trh_scene_add", "trh_scene_add_mesh",
+                "trh_scene_counts", "trh_scene_copy", "trh_mtx_srt", "trh_mtx_inverse", "trh_uniforms",
+                "trh_random_texture", "trh_run_app"]
+
+
+def load():
+    global _lib
+    if _lib is None:
+        capi.load()  # libtoyraygun.so depends on libtoyraygun_hip.so
+        if not os.path.exists(HOST_SO):
+            raise ImportError("%s is missing: run __graft_entry__.build()" % HOST_SO)
+        L = C.CDLL(HOST_SO)
+        P, F = C.c_void_p, C.c_void_p
+        L.trh_scene_new.restype = P
+        L.trh_scene_cornell.restype = P
+        L.trh_scene_free.argtypes = [P]
+        L.trh_scene_add.argtypes = [P, C.c_int, F, F]
+        L.trh_scene_add_mesh.argtypes = [P, F, F, F, C.c_int, F, F, C.c_uint]
+        L.trh_scene_counts.argtypes = [P, C.POINTER(C.c_uint)]
+        L.trh_scene_counts.restype = C.c_uint
+        L.trh_scene_copy.argtypes = [P, F, F, F, F, F]
+        L.trh_mtx_srt.argtypes = [F, F, F, F]
+        L.trh_mtx_inverse.argtypes = [F, F]
+        L.trh_uniforms.argtypes = [C.c_int, C.c_int, C.c_int, F, F, F, F]
+        L.trh_random_texture.argtypes = [C.c_int, C.c_int, C.c_uint32, F]
+        L.trh_run_app.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, F, C.c_char_p,
+                                  C.POINTER(C.c_double), C.POINTER(C.c_ulonglong)]
+        L.trh_run_app.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+class Scene:
+    """toyraygun::Scene (include/engine/Scene.h)."""
+    KINDS = {"cube": 0, "plane": 1, "light": 2}
+
+    def __init__(self, handle=None):
+        self.L = load()
+        self.h = handle if handle is not None else self.L.trh_scene_new()
+
+    @classmethod
+    def cornell_box(cls):
+        return cls(load().trh_scene_cornell())
+
+    def __del__(self):
+        try:
+            self.L.trh_scene_free(self.h)
+        except Exception:
+            pass
+
+    def add(self, kind, color, mtx):
+        c, m = _f32(color), _f32(mtx).reshape(16)
+        self.L.trh_scene_add(self.h, self.KINDS[kind], c.ctypes.data, m.ctypes.data)
+
+    def add_mesh(self, verts, normals, tri_idx, mtx, color, material_id):
+        v, n, m, c = _f32(verts), _f32(normals), _f32(mtx).reshape(16), _f32(color)
+        t = np.ascontiguousarray(tri_idx, np.uint32)
+        self.L.trh_scene_add_mesh(self.h, v.ctypes.data, n.ctypes.data, t.ctypes.data, t.size // 3, m.ctypes.data,
+                                  c.ctypes.data, material_id)
+
+    def buffers(self):
+        nt = C.c_uint()
+        nv = self.L.trh_scene_counts(self.h, C.byref(nt))
+        nt = nt.value
+        out = dict(positions=np.zeros((nv, 3), np.float32), normals=np.zeros((nv, 3), np.float32),
+                   colors=np.zeros((nv, 3), np.float32), indices=np.zeros(nv, np.uint32),
+                   material_ids=np.zeros(nt, np.uint32))
+        self.L.trh_scene_copy(self.h, out["positions"].ctypes.data, out["normals"].ctypes.data, out["colors"].ctypes.data,
+                              out["indices"].ctypes.data, out["material_ids"].ctypes.data)
+        return out
+
+
+def mtx_srt(scale, rot, pos):
+    m = np.zeros(16, np.float32)
+    s, r, t = _f32(scale), _f32(rot), _f32(pos)  # keep the temporaries alive across the call
+    load().trh_mtx_srt(m.ctypes.data, s.ctypes.data, r.ctypes.data, t.ctypes.data)
+    return m
+
+
+def mtx_inverse(m):
+    out = np.zeros(16, np.float32)
+    src = _f32(m).reshape(16)
+    load().trh_mtx_inverse(out.ctypes.data, src.ctypes.data)
+    return out
+
+
+def uniforms(w, h, frame_index=0, eye=(0.0, 1.0, 3.38), at=(0.0, 1.0, -1.0)):
+    """(176-byte Uniforms block, viewProj[16]) as HipRenderer::fillUniforms builds them."""
+    raw = np.zeros(176, np.uint8)
+    vp = np.zeros(16, np.float32)
+    e, a = _f32(eye), _f32(at)
+    load().trh_uniforms(w, h, frame_index, e.ctypes.data, a.ctypes.data, raw.ctypes.data, vp.ctypes.data)
+    return capi.Uniforms.from_buffer_copy(raw.tobytes()), vp
+
+
+def random_texture(w, h, seed=capi.SEED_OFFSETS):
+    out = np.zeros(w * h, np.uint32)
+    load().trh_random_texture(w, h, seed, out.ctypes.data)
+    return out
+
+
+def run_app(w, h, frames, bounces=3, batch=False, device=0, png_path=None):
+    """Drive the reference app's call sequence headlessly; returns (accum[h,w,4], last_ms, rays)."""
+    acc = np.zeros((h, w, 4), np.float32)
+    ms, rays = C.c_double(), C.c_ulonglong()
+    rc = load().trh_run_app(w, h, frames, bounces, 1 if batch else 0, device, acc.ctypes.data,
+                            png_path.encode() if png_path else None, C.byref(ms), C.byref(rays))
+    if rc != 0:
+        raise RuntimeError("trh_run_app failed at step %d" % rc)
+    return acc, ms.value, rays.value
