@@ -19,6 +19,9 @@
 extern "C" {
 #endif
 
+/* the library is built with -fvisibility=hidden: only these entry points are exported */
+#define TRG_API __attribute__((visibility("default")))
+
 #define TRG_OK 0
 #define TRG_ERR_INVALID (-22)  /* bad argument / call order        */
 #define TRG_ERR_NOMEM (-12)    /* device or host allocation failed */
@@ -64,6 +67,9 @@ typedef struct trg_stats {
     /* filled only while TRG_OPT_COUNTERS is on: 64-byte node fetches (= 2 BVH2-equivalent boxes
      * each) and ray/triangle tests */
     uint64_t node_fetches, tri_tests;
+    /* wave-level loop trips of the traversal (TRG_OPT_COUNTERS): node_fetches / (64 * wave_node_iters) is the
+     * lane utilisation of the node loop, likewise for triangles */
+    uint64_t wave_node_iters, wave_tri_iters;
     double last_render_ms;  /* HIP-event time of the kernels of the last trg_render, on its stream */
     double total_render_ms; /* sum over renders since reset */
     uint32_t renders;       /* trg_render calls since reset */
@@ -75,14 +81,19 @@ enum trg_option {
     TRG_OPT_STRICT = 1,       /* 1: run the -ffp-contract=off kernels that match the oracle bit for bit (debug/parity); 0 (default): fast kernels */
     TRG_OPT_COUNTERS = 2,     /* 1: count node fetches / triangle tests (slower) */
     TRG_OPT_FORCE_GLOBAL = 3, /* 1: keep the scene in HBM even if it would fit in LDS */
-    TRG_OPT_TIMING = 4        /* 1 (default): bracket trg_render with HIP events (forces a stream sync) */
+    TRG_OPT_TIMING = 4,       /* 1 (default): bracket trg_render with HIP events (forces a stream sync) */
+    TRG_OPT_KERNEL = 5        /* which megakernel trg_render launches: TRG_KERNEL_DIRECT (default) or TRG_KERNEL_POOL */
+};
+enum trg_kernel {
+    TRG_KERNEL_DIRECT = 0,    /* one path per lane, rays traced by the lane that owns the pixel */
+    TRG_KERNEL_POOL = 1       /* workgroup path pool: ballot/prefix-compacted ray queues drained by all lanes */
 };
 
 /* --- lifetime: replaces MetalRenderer::init / resize (src/engine/Metal/MetalRenderer.mm:282-338,557-574):
  *     allocates the float4 accumulation target and the per-pixel Halton-offset texture. */
-int trg_create(trg_ctx **out, int device, uint32_t width, uint32_t height);
-void trg_destroy(trg_ctx *ctx);
-const char *trg_last_error(trg_ctx *ctx); /* ctx may be NULL: error of the last failed trg_create */
+TRG_API int trg_create(trg_ctx **out, int device, uint32_t width, uint32_t height);
+TRG_API void trg_destroy(trg_ctx *ctx);
+TRG_API const char *trg_last_error(trg_ctx *ctx); /* ctx may be NULL: error of the last failed trg_create */
 
 /* --- scene upload + acceleration-structure build: replaces MetalRenderer::loadScene
  *     (MetalRenderer.mm:204-280), i.e. the five memcpy at :245-249 and the MPS
@@ -93,60 +104,60 @@ const char *trg_last_error(trg_ctx *ctx); /* ctx may be NULL: error of the last 
  *     n_tris entries and doubles as the per-primitive ray mask (MetalRenderer.mm:276).  In the
  *     reference n_verts == 3*n_tris and indices is the identity.  All inputs are copied; nothing is
  *     retained. */
-int trg_load_scene(trg_ctx *ctx, const float *positions3, const float *normals3, const float *colors3,
+TRG_API int trg_load_scene(trg_ctx *ctx, const float *positions3, const float *normals3, const float *colors3,
                    const uint32_t *indices, const uint32_t *material_ids, uint32_t n_verts, uint32_t n_tris);
 
 /* --- per-frame uniforms: replaces MetalRenderer updateUniforms (MetalRenderer.mm:340-371).
  *     frameIndex in the struct is ignored by trg_render (it iterates its own range). */
-int trg_set_uniforms(trg_ctx *ctx, const trg_uniforms *u);
+TRG_API int trg_set_uniforms(trg_ctx *ctx, const trg_uniforms *u);
 
 /* --- per-pixel Halton index offsets: replaces the R32Uint random texture filled by
  *     Texture::generateRandomTexture (src/engine/Texture.cpp:16-29; MetalRenderer.mm:315-335). */
-int trg_set_pixel_offsets(trg_ctx *ctx, const uint32_t *offsets /* width*height, host */);
-int trg_set_pixel_offsets_seed(trg_ctx *ctx, uint32_t seed); /* offset(x,y) = pcg_hash32(seed ^ (y*w+x)) on the device */
+TRG_API int trg_set_pixel_offsets(trg_ctx *ctx, const uint32_t *offsets /* width*height, host */);
+TRG_API int trg_set_pixel_offsets_seed(trg_ctx *ctx, uint32_t seed); /* offset(x,y) = pcg_hash32(seed ^ (y*w+x)) on the device */
 
 /* --- the hot path: replaces the body of MetalRenderer render: (MetalRenderer.mm:400-515): raygen, then
  *     `bounces` x [nearest-hit, primaryHit, any-hit, shadowHit], then accumulate, for frames
  *     frameIndexBegin .. frameIndexBegin+spp-1 over image rows [row0, row0+rows), in ONE launch.
  *     Result: running average in the float4 accumulation buffer (row 0 = scene bottom).  If
  *     frameIndexBegin > 0 the buffer must hold the average of frames [0, frameIndexBegin). */
-int trg_render(trg_ctx *ctx, uint32_t frameIndexBegin, uint32_t spp, uint32_t bounces, uint32_t row0, uint32_t rows);
+TRG_API int trg_render(trg_ctx *ctx, uint32_t frameIndexBegin, uint32_t spp, uint32_t bounces, uint32_t row0, uint32_t rows);
 
 /* --- read back the accumulation target (what the reference hands to its blit pass,
  *     MetalRenderer.mm:538): width*height*4 floats, host memory. */
-int trg_read_accum(trg_ctx *ctx, float *rgba);
+TRG_API int trg_read_accum(trg_ctx *ctx, float *rgba);
 
-int trg_get_stats(trg_ctx *ctx, trg_stats *out);
-int trg_reset_stats(trg_ctx *ctx);
-int trg_set_option(trg_ctx *ctx, int option, int64_t value);
+TRG_API int trg_get_stats(trg_ctx *ctx, trg_stats *out);
+TRG_API int trg_reset_stats(trg_ctx *ctx);
+TRG_API int trg_set_option(trg_ctx *ctx, int option, int64_t value);
 
 /* --- plumbing for multi-GPU / framework interop (no reference equivalent) */
-int trg_bind_accum(trg_ctx *ctx, void *device_ptr); /* use caller-owned device memory (width*height*16 B) as the accumulation buffer; NULL restores the internal one */
-int trg_accum_device_ptr(trg_ctx *ctx, void **out);
-int trg_set_stream(trg_ctx *ctx, void *hip_stream); /* NULL = the context's own stream */
-int trg_sync(trg_ctx *ctx);
+TRG_API int trg_bind_accum(trg_ctx *ctx, void *device_ptr); /* use caller-owned device memory (width*height*16 B) as the accumulation buffer; NULL restores the internal one */
+TRG_API int trg_accum_device_ptr(trg_ctx *ctx, void **out);
+TRG_API int trg_set_stream(trg_ctx *ctx, void *hip_stream); /* NULL = the context's own stream */
+TRG_API int trg_sync(trg_ctx *ctx);
 
 /* --- stage-level entry points used by the parity tests (each isolates one SURVEY 8a row) */
 /* a7 / a12: the intersector alone.  any_hit=0: out = trg_isect[n]; any_hit=1: out = float[n] distance (<0: unoccluded). */
-int trg_trace(trg_ctx *ctx, const trg_ray *rays, size_t n, int any_hit, void *out);
+TRG_API int trg_trace(trg_ctx *ctx, const trg_ray *rays, size_t n, int any_hit, void *out);
 /* a5: halton(i[k], d[k]) */
-int trg_halton(trg_ctx *ctx, const uint32_t *i, const uint32_t *d, size_t n, float *out);
+TRG_API int trg_halton(trg_ctx *ctx, const uint32_t *i, const uint32_t *d, size_t n, float *out);
 /* a6: primary rays of one frame for the whole image (width*height trg_ray) */
-int trg_raygen(trg_ctx *ctx, uint32_t frameIndex, trg_ray *out);
+TRG_API int trg_raygen(trg_ctx *ctx, uint32_t frameIndex, trg_ray *out);
 /* a10/a11: out[k] = {dir.xyz, dist, color.xyz, 0, bounce_dir.xyz, 0} for hit point p[k], unit normal n[k],
  * random pairs r[k] = (r0,r1,r2,r3) */
-int trg_sample(trg_ctx *ctx, const float *p3, const float *n3, const float *r4, size_t n, float *out12);
+TRG_API int trg_sample(trg_ctx *ctx, const float *p3, const float *n3, const float *r4, size_t n, float *out12);
 
 /* host-only (no GPU): the acceleration structure trg_load_scene would build, flattened as DESIGN.md
  * "Data layout in HBM" describes (16 floats per node, 12 floats per triangle record).  Pass NULL
  * outputs to query the sizes. */
-int trg_debug_build_bvh(const float *positions3, const uint32_t *indices, const uint32_t *material_ids, uint32_t n_verts,
+TRG_API int trg_debug_build_bvh(const float *positions3, const uint32_t *indices, const uint32_t *material_ids, uint32_t n_verts,
                         uint32_t n_tris, float *nodes_out, uint32_t nodes_cap, float *tris_out, uint32_t tris_cap,
                         uint32_t *n_nodes, uint32_t *n_tri_records, uint32_t *depth);
 
 /* --- N1: ACES tonemap + sRGB of the accumulation buffer to RGBA8 (PostProcessing.metal:44-57;
  *     common.h:36-43,163-171).  flip_y != 0 writes the top image row first (PNG order). */
-int trg_postprocess(trg_ctx *ctx, uint8_t *rgba8, int flip_y);
+TRG_API int trg_postprocess(trg_ctx *ctx, uint8_t *rgba8, int flip_y);
 
 #ifdef __cplusplus
 }

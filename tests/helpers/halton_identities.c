@@ -1,0 +1,35 @@
+#include <stdio.h>
+#include <stdint.h>
+#include <math.h>
+static const uint32_t P[64] = {2,3,5,7,11,13,17,19,23,29,31,37,41,43,47,53,59,61,67,71,73,79,83,89,97,101,103,107,109,113,127,131,137,139,149,151,157,163,167,173,179,181,191,193,197,199,211,223,227,229,233,239,241,251,257,263,269,271,277,281,283,293,307,311};
+int main(){
+  long bad=0;
+  for(int d=1; d<64; ++d){
+    uint32_t b=P[d]; float bf=(float)b, rcp=1.0f/bf, h=0.5f/bf;
+    uint32_t lim = 1u<<22;
+    #pragma omp parallel for reduction(+:bad)
+    for(uint32_t n=0;n<lim;++n){
+      float nf=(float)n;
+      float q=floorf((nf+0.5f)*rcp);
+      float dg=fmaf(-q,bf,nf);
+      if((uint32_t)q!=n/b || (uint32_t)dg!=n%b || dg<0) bad++;
+    }
+  }
+  printf("bad=%ld\n",bad);
+  // base-2 closed form vs loop, sampled + structured
+  long bad2=0;
+  #pragma omp parallel for reduction(+:bad2)
+  for(uint64_t t=0;t<(1ull<<32);t+=4099){
+    uint32_t i=(uint32_t)t;
+    // reference loop
+    float f=1.0f, r=0; uint32_t x=i; while(x){ f=f*0.5f; r=r+f*(float)(x&1); x>>=1; }
+    uint32_t rev=0; for(int k=0;k<32;++k) if(i>>k&1) rev|=1u<<(31-k);
+    uint32_t lz = rev? __builtin_clz(rev):32;
+    uint32_t drop = lz<8? 8-lz:0;
+    uint32_t kept=(rev>>drop)<<drop;
+    float c=(float)kept*0x1p-32f;
+    if(drop){ uint32_t tie=(rev>>(drop-1))&1, lsb=(rev>>drop)&1; if(tie&lsb){ union{uint32_t u; float f;} u; u.u=(127-lz-24)<<23; c+=u.f; } }
+    if(c!=r) bad2++;
+  }
+  printf("bad2=%ld\n",bad2);
+}

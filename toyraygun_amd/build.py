@@ -52,6 +52,7 @@ def build(force=False, verbose=False):
         _glob(os.path.join(ROOT, "include", "toyraygun"), (".h",)) + _glob(os.path.join(ROOT, "include", "bx"), (".h",)) + \
         _glob(HOST, (".h",)) + [os.path.abspath(__file__)]
     common = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include")]
+    hidden = ["-fvisibility=hidden"]
     dev = ["--offload-arch=" + ARCH]
 
     objs = []
@@ -64,7 +65,7 @@ def build(force=False, verbose=False):
     for name, src, extra in units:
         o = os.path.join(OBJ, name)
         if force or _newer(o, [src] + headers):
-            _run([hipcc] + common + extra + ["-c", src, "-o", o], verbose)
+            _run([hipcc] + common + hidden + extra + ["-c", src, "-o", o], verbose)
         objs.append(o)
     hip_so = os.path.join(LIB, "libtoyraygun_hip.so")
     if force or _newer(hip_so, objs):

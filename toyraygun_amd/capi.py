@@ -15,7 +15,8 @@ HIP_SO = os.path.join(LIB_DIR, "libtoyraygun_hip.so")
 
 OK = 0
 ERR_INVALID, ERR_NOMEM, ERR_DEVICE, ERR_NODEV, ERR_RANGE = -22, -12, -5, -19, -34
-OPT_STRICT, OPT_COUNTERS, OPT_FORCE_GLOBAL, OPT_TIMING = 1, 2, 3, 4
+OPT_STRICT, OPT_COUNTERS, OPT_FORCE_GLOBAL, OPT_TIMING, OPT_KERNEL = 1, 2, 3, 4, 5
+KERNEL_DIRECT, KERNEL_POOL = 0, 1
 MATERIAL_DEFAULT, MATERIAL_EMISSIVE = 1, 2
 MAX_BOUNCES = 15
 SEED_OFFSETS = 0x5EED0001
@@ -35,7 +36,7 @@ class Uniforms(C.Structure):
 class Stats(C.Structure):
     _fields_ = [
         ("primary_rays", C.c_uint64), ("bounce_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("shaded_hits", C.c_uint64),
-        ("node_fetches", C.c_uint64), ("tri_tests", C.c_uint64),
+        ("node_fetches", C.c_uint64), ("tri_tests", C.c_uint64), ("wave_node_iters", C.c_uint64), ("wave_tri_iters", C.c_uint64),
         ("last_render_ms", C.c_double), ("total_render_ms", C.c_double),
         ("renders", C.c_uint32), ("bvh_nodes", C.c_uint32), ("bvh_depth", C.c_uint32), ("bvh_leaves", C.c_uint32),
         ("scene_in_lds", C.c_uint32), ("lds_bytes", C.c_uint32),

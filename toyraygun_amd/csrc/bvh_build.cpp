@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -11,7 +12,8 @@ namespace trg {
 namespace {
 
 constexpr int kBins = 16;
-constexpr uint32_t kMaxLeaf = 4;     // leaf encoding allows 8
+uint32_t kMaxLeaf = 4;               // leaf encoding allows 8 (tunable: TRG_BVH_MAXLEAF)
+float kTravCost = 1.2f;               // SAH cost of one node visit relative to one triangle test (TRG_BVH_TRAVCOST)
 constexpr uint32_t kSahDepthCap = 24; // below this depth switch to balanced median splits
 constexpr float kInf = std::numeric_limits<float>::infinity();
 
@@ -85,7 +87,7 @@ struct Builder {
             if (best_axis >= 0) {
                 const float leaf_cost = box.half_area() * (float)count;
                 // node traversal cost 1 box-pair test ~ 1.2 triangle tests
-                const float split_cost = 1.2f * box.half_area() + best_cost;
+                const float split_cost = kTravCost * box.half_area() + best_cost;
                 if (count <= kMaxLeaf && leaf_cost <= split_cost) return make_leaf(box, first, count, d);
                 const float scale = (float)kBins / ext[best_axis];
                 const float lo = cbox.lo[best_axis];
@@ -122,6 +124,8 @@ inline float bits_f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 }  // namespace
 
 void build_bvh(const float *pos, const uint32_t *idx, const uint32_t *masks, uint32_t ntris, Bvh &out) {
+    if (const char *e = getenv("TRG_BVH_MAXLEAF")) kMaxLeaf = (uint32_t)std::min(8, std::max(1, atoi(e)));
+    if (const char *e = getenv("TRG_BVH_TRAVCOST")) kTravCost = (float)atof(e);
     Builder B;
     B.prims.resize(ntris);
     Box scene;

@@ -29,6 +29,7 @@ struct trg_ctx {
     bool scene_loaded = false, have_uniforms = false, have_offsets = false;
     trg_uniforms u{};
     bool opt_strict = false, opt_counters = false, opt_force_global = false, opt_timing = true;
+    int opt_kernel = TRG_KERNEL_DIRECT;
     uint32_t bvh_nodes = 0, bvh_depth = 0, bvh_leaves = 0;
     double last_ms = 0.0, total_ms = 0.0;
     uint32_t renders = 0;
@@ -54,15 +55,21 @@ static int fail(trg_ctx *c, int code, const char *fmt, ...) {
 
 static inline uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
 
-struct LdsPlan { bool lds_scene; uint32_t stack_off, red_off, total; };
-static int plan_lds(trg_ctx *c, LdsPlan &p) {
+struct LdsPlan { bool lds_scene; uint32_t stack_off, red_off, pool_off, total; };
+static int plan_lds(trg_ctx *c, LdsPlan &p, bool pool = false) {
     const uint32_t levels = c->bvh_depth + 2;
     p.lds_scene = !c->opt_force_global && c->sc.blob_bytes <= kMaxLdsScene;
     p.stack_off = p.lds_scene ? align16(c->sc.blob_bytes) : 0u;
     p.red_off = p.stack_off + levels * kBlock * 4u;
-    p.total = p.red_off + 4u * 8u * 4u;
-    if (p.total > 64u * 1024u)
-        return fail(c, TRG_ERR_RANGE, "BVH depth %u needs %u B of LDS per workgroup (limit 65536)", c->bvh_depth, p.total);
+    p.pool_off = align16(p.red_off + 4u * 8u * 4u);
+    p.total = p.pool_off;
+    if (pool) {
+        const uint32_t slots = (uint32_t)kBlock * (uint32_t)kPoolS;
+        p.total = p.pool_off + slots * kPoolSlotBytes + 4u * slots * 2u + 16u;  // slots, two lists of 2P u16, counters
+    }
+    const uint32_t limit = pool ? 160u * 1024u : 64u * 1024u;
+    if (p.total > limit)
+        return fail(c, TRG_ERR_RANGE, "BVH depth %u needs %u B of LDS per workgroup (limit %u)", c->bvh_depth, p.total, limit);
     return TRG_OK;
 }
 
@@ -165,7 +172,7 @@ int trg_load_scene(trg_ctx *c, const float *pos, const float *nrm, const float *
     c->bvh_nodes = bvh.n_nodes; c->bvh_depth = bvh.depth; c->bvh_leaves = bvh.n_leaves;
     c->scene_loaded = true;
     LdsPlan plan;
-    return plan_lds(c, plan);
+    return plan_lds(c, plan, c->opt_kernel == TRG_KERNEL_POOL);
 }
 
 int trg_set_uniforms(trg_ctx *c, const trg_uniforms *u) {
@@ -204,8 +211,9 @@ int trg_render(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces,
     if ((uint64_t)frame_begin + spp > 0xFFFFFFFFull) return fail(c, TRG_ERR_INVALID, "trg_render: frame range overflows");
     if (spp == 0 || rows == 0) { c->last_ms = 0.0; return TRG_OK; }
     HIPCHK(c, hipSetDevice(c->device));
+    const bool pool = c->opt_kernel == TRG_KERNEL_POOL;
     LdsPlan plan;
-    if (int rc = plan_lds(c, plan)) return rc;
+    if (int rc = plan_lds(c, plan, pool)) return rc;
 
     RenderParams p{};
     p.u = c->u;
@@ -215,13 +223,18 @@ int trg_render(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces,
     p.counters = c->counters;
     p.frame_begin = frame_begin; p.spp = spp; p.bounces = bounces; p.row0 = row0; p.rows = rows;
     p.tiles_x = (c->w + kTile - 1) / kTile;
-    p.stack_off = plan.stack_off; p.red_off = plan.red_off;
+    p.stack_off = plan.stack_off; p.red_off = plan.red_off; p.pool_off = plan.pool_off;
     const uint32_t tiles_y = (rows + kTile - 1) / kTile;
     const uint32_t grid = p.tiles_x * tiles_y;
 
     if (c->opt_timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    hipError_t e = c->opt_strict ? launch_render_strict(p, plan.lds_scene, c->opt_counters, grid, plan.total, c->stream)
-                                 : launch_render_fast(p, plan.lds_scene, c->opt_counters, grid, plan.total, c->stream);
+    hipError_t e;
+    if (pool)
+        e = c->opt_strict ? launch_render_pool_strict(p, plan.lds_scene, c->opt_counters, grid, plan.total, c->stream)
+                          : launch_render_pool_fast(p, plan.lds_scene, c->opt_counters, grid, plan.total, c->stream);
+    else
+        e = c->opt_strict ? launch_render_strict(p, plan.lds_scene, c->opt_counters, grid, plan.total, c->stream)
+                          : launch_render_fast(p, plan.lds_scene, c->opt_counters, grid, plan.total, c->stream);
     if (e != hipSuccess) return fail(c, TRG_ERR_DEVICE, "trg_render: launch failed: %s", hipGetErrorString(e));
     c->renders++;
     if (c->opt_timing) {
@@ -255,12 +268,13 @@ int trg_get_stats(trg_ctx *c, trg_stats *out) {
     memset(out, 0, sizeof(*out));
     out->primary_rays = sum[0]; out->bounce_rays = sum[1]; out->shadow_rays = sum[2]; out->shaded_hits = sum[3];
     out->node_fetches = sum[4]; out->tri_tests = sum[5];
+    out->wave_node_iters = sum[6]; out->wave_tri_iters = sum[7];
     out->last_render_ms = c->last_ms; out->total_render_ms = c->total_ms; out->renders = c->renders;
     out->bvh_nodes = c->bvh_nodes; out->bvh_depth = c->bvh_depth; out->bvh_leaves = c->bvh_leaves;
     out->scene_bytes = c->sc.blob_bytes;
     if (c->scene_loaded) {
         LdsPlan plan;
-        if (plan_lds(c, plan) == TRG_OK) { out->scene_in_lds = plan.lds_scene ? 1u : 0u; out->lds_bytes = plan.total; }
+        if (plan_lds(c, plan, c->opt_kernel == TRG_KERNEL_POOL) == TRG_OK) { out->scene_in_lds = plan.lds_scene ? 1u : 0u; out->lds_bytes = plan.total; }
     }
     return TRG_OK;
 }
@@ -281,6 +295,10 @@ int trg_set_option(trg_ctx *c, int option, int64_t value) {
     case TRG_OPT_COUNTERS: c->opt_counters = value != 0; break;
     case TRG_OPT_FORCE_GLOBAL: c->opt_force_global = value != 0; break;
     case TRG_OPT_TIMING: c->opt_timing = value != 0; break;
+    case TRG_OPT_KERNEL:
+        if (value != TRG_KERNEL_DIRECT && value != TRG_KERNEL_POOL) return fail(c, TRG_ERR_INVALID, "trg_set_option: unknown kernel %lld", (long long)value);
+        c->opt_kernel = (int)value;
+        break;
     default: return fail(c, TRG_ERR_INVALID, "trg_set_option: unknown option %d", option);
     }
     return TRG_OK;

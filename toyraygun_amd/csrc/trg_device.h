@@ -51,10 +51,10 @@ TRG_DEV float rcp_fast(float x) {
 // ---------------------------------------------------------------------------------------------
 // Halton (a5): runtime/shaders/common.h:51-75, prime table extended per SURVEY F5.
 //   reference recurrence:  f = f * invB;  r = r + f * (i % b);  i = i / b;   while (i > 0)
-// Device form: the base is a compile-time constant, so f_k = fl(f_{k-1} * fl(1/b)) is a literal and
-// i / b is a multiply-high; the loop runs the fixed digit count of a 32-bit index: once i reaches 0
-// the remaining terms add f_k * 0 = +0, which leaves r unchanged, so the value is bit-identical to the
-// data-dependent loop.  Never contracted, in either build.
+// Device form: the base is a compile-time constant, so f_k = fl(f_{k-1} * fl(1/b)) is a literal; the loop
+// runs the fixed digit count of a 32-bit index: once the quotient reaches 0 the remaining terms add
+// f_k * 0 = +0, which leaves r unchanged, so the value is bit-identical to the data-dependent loop.
+// Never contracted, in either build.
 // ---------------------------------------------------------------------------------------------
 __host__ __device__ constexpr uint32_t halton_prime(uint32_t d) {
     constexpr uint32_t p[64] = { 2,   3,   5,   7,   11,  13,  17,  19,  23,  29,  31,  37,  41,  43,  47,  53,
@@ -78,22 +78,74 @@ struct HaltonTab {
         for (int k = 0; k < 33; ++k) { v = v * invB; f[k] = v; }
     }
 };
+// Device evaluation of one dimension, bit-identical to the reference loop (validated exhaustively on the
+// CPU by tests/helpers/halton_identities.c):
+//  * base 2: closed form.  The running sum keeps the exponent of its first (largest) term, so every later
+//    term is either a multiple of the ulp (added exactly), exactly half an ulp (one round-to-even tie) or
+//    below half an ulp (dropped): bit-reverse, keep 24 bits from the leading one, resolve the single tie.
+//  * odd primes: ONE integer division splits i = hi * b^k1 + lo with lo, hi < 2^22; below 2^22 the digits
+//    come out of pure fp32 arithmetic -- q = floor((n + 0.5) * fl(1/b)) is exactly n div b there, and
+//    d = fma(q, -b, n) is exact -- six full-rate VALU instructions per digit, every constant a literal or
+//    an inline operand (no registers), instead of two quarter-rate integer multiplies.  The products
+//    f_k * d and the sums r + t are never contracted.
+__host__ __device__ constexpr int halton_lo_digits(uint32_t b) {
+    int k = 0;
+    uint64_t v = 1;
+    while (v * b <= (1ull << 22)) { v *= b; ++k; }
+    return k;  // largest k with b^k <= 2^22
+}
+__host__ __device__ constexpr uint32_t halton_pow(uint32_t b, int k) {
+    uint32_t v = 1;
+    for (int j = 0; j < k; ++j) v *= b;
+    return v;
+}
 template <uint32_t D>
 TRG_DEV float halton_c(uint32_t i) {
 #pragma clang fp contract(off)
+#ifdef TRG_EXP_NOHALTON  // timing-only ablation: a cheap hash instead of the radical inverse
+    return (float)((i * 2654435761u + D * 40503u) >> 8) * 0x1p-24f;
+#endif
     constexpr uint32_t B = halton_prime(D);
-    constexpr int N = halton_digits(B);
-    constexpr HaltonTab<B> tab{};
-    float r = 0.0f;
+    if constexpr (B == 2) {
+        const uint32_t rev = __brev(i);
+        const uint32_t lz = rev ? (uint32_t)__clz((int)rev) : 32u;
+        const uint32_t drop = lz < 8u ? 8u - lz : 0u;
+        const uint32_t kept = (rev >> drop) << drop;
+        float r = (float)kept * 0x1p-32f;
+        if (drop) {
+            const uint32_t tie = (rev >> (drop - 1u)) & 1u, lsb = (rev >> drop) & 1u;
+            if (tie & lsb) r = r + __uint_as_float((127u - lz - 24u) << 23);
+        }
+        return r;
+    } else {
+        constexpr int N = halton_digits(B);
+        constexpr int K1 = halton_lo_digits(B);
+        constexpr uint32_t B1 = halton_pow(B, K1);
+        constexpr HaltonTab<B> tab{};
+        constexpr float bf = (float)B, rcp = 1.0f / (float)B;
+        const uint32_t hi = i / B1;
+        const uint32_t lo = i - hi * B1;
+        float r = 0.0f;
+        float n = (float)lo;
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-        const uint32_t q = i / B;
-        const uint32_t dig = i - q * B;
-        const float t = tab.f[k] * (float)dig;
-        r = r + t;
-        i = q;
+        for (int k = 0; k < K1; ++k) {
+            const float q = __builtin_floorf((n + 0.5f) * rcp);
+            const float dig = __builtin_fmaf(q, -bf, n);
+            const float t = tab.f[k] * dig;
+            r = r + t;
+            n = q;
+        }
+        n = (float)hi;
+#pragma unroll
+        for (int k = K1; k < N; ++k) {
+            const float q = __builtin_floorf((n + 0.5f) * rcp);
+            const float dig = __builtin_fmaf(q, -bf, n);
+            const float t = tab.f[k] * dig;
+            r = r + t;
+            n = q;
+        }
+        return r;
     }
-    return r;
 }
 // the two raygen dimensions (Raytracing.metal:67-68)
 TRG_DEV void halton_pixel(uint32_t i, float &r0, float &r1) { r0 = halton_c<0>(i); r1 = halton_c<1>(i); }
@@ -295,7 +347,7 @@ struct SceneView {
     const uint32_t *mats;   // 1 per triangle, ORIGINAL order (reference triangleMasks buffer)
 };
 struct Hit { float t; int prim; float u, v; };  // u, v = Moeller-Trumbore weights of vertex 1 and 2
-struct Counters { uint32_t nodes, tris; };
+struct Counters { uint32_t nodes, tris, wnodes, wtris; };  // per-lane work and wave-level iterations (first active lane counts)
 
 // One ray/triangle test.  Returns true when (u,v) are inside and t is in [0, tmax_ray].
 TRG_DEV bool tri_test(const v4f a, const v4f b, const v4f c, V3 o, V3 d, float tmax_ray, float &t, float &u, float &v) {
@@ -319,71 +371,212 @@ struct LdsStack {
     TRG_DEV int pop(int sp) { return base[sp * BLOCK]; }
 };
 
-template <bool ANY, bool COUNT, int BLOCK>
-TRG_DEV bool traverse(const SceneView &sc, V3 o, V3 d, float tmax_ray, uint32_t rmask, Hit &hit, LdsStack<BLOCK> stk,
-                      Counters &cnt) {
+constexpr int kNodeDone = (int)0x80000000;  // "traversal finished" marker in the node register (never a valid leaf code)
+
+TRG_DEV uint32_t mbcnt64(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// Per-ray traversal state, resumable: the queue tracer parks a ray in these registers while other lanes refill.
+struct Trav {
+    V3 o, d;
+    float idx, idy, idz, oix, oiy, oiz;  // reciprocal direction and origin * reciprocal direction
+    float tmax, best;
+    uint32_t rmask;
+    Hit hit;
+    bool found;
+    int node, sp;
+};
+
+TRG_DEV void trav_begin(Trav &tv, V3 o, V3 d, float tmax, uint32_t rmask) {
     // Reciprocal direction with zero components pushed to +-1e-30: the slab products stay finite (no
     // inf - inf = NaN whose fmin/fmax would pick the wrong endpoint), and a ray that moves 1e-30 per
     // unit t along an axis is parallel to the slab for every practical purpose.
     const float dx = fabsf(d.x) < 1e-30f ? copysignf(1e-30f, d.x) : d.x;
     const float dy = fabsf(d.y) < 1e-30f ? copysignf(1e-30f, d.y) : d.y;
     const float dz = fabsf(d.z) < 1e-30f ? copysignf(1e-30f, d.z) : d.z;
-    const float idx = rcp_fast(dx), idy = rcp_fast(dy), idz = rcp_fast(dz);
-    const float oix = o.x * idx, oiy = o.y * idy, oiz = o.z * idz;
-    float best = tmax_ray;
-    bool found = false;
-    hit.t = -1.0f; hit.prim = -1; hit.u = 0.0f; hit.v = 0.0f;
-    int node = 0, sp = 0;
+    tv.o = o; tv.d = d;
+    tv.idx = rcp_fast(dx); tv.idy = rcp_fast(dy); tv.idz = rcp_fast(dz);
+    tv.oix = o.x * tv.idx; tv.oiy = o.y * tv.idy; tv.oiz = o.z * tv.idz;
+    tv.tmax = tmax; tv.best = tmax; tv.rmask = rmask;
+    tv.hit.t = -1.0f; tv.hit.prim = -1; tv.hit.u = 0.0f; tv.hit.v = 0.0f;
+    tv.found = false;
+    tv.node = 0; tv.sp = 0;
+}
+
+// One inner-node step: test both child boxes, descend into the nearer hit child, push the other, or pop.
+// Written with selects and two predicated LDS stack accesses instead of a four-way branch: the branchy
+// form spent more scalar instructions on exec-mask bookkeeping than vector instructions on the boxes.
+template <bool COUNT, int BLOCK>
+TRG_DEV void trav_node_step(const SceneView &sc, Trav &tv, LdsStack<BLOCK> stk, Counters &cnt) {
+    const v4f *n = sc.nodes + tv.node * 4;
+    const v4f n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+    if (COUNT) { cnt.nodes++; if (mbcnt64(__ballot(1)) == 0) cnt.wnodes++; }
+    // slab tests; (b - o) * inv written as b*inv - o*inv so the fast build gets one fma each.
+    // Boxes are padded by 2e-5 x scene extent on the host, far more than the rounding of these
+    // products, so a triangle the Moeller-Trumbore test accepts is never culled.
+    const float ax0 = n0.x * tv.idx - tv.oix, ax1 = n0.y * tv.idx - tv.oix, ay0 = n0.z * tv.idy - tv.oiy, ay1 = n0.w * tv.idy - tv.oiy;
+    const float bx0 = n1.x * tv.idx - tv.oix, bx1 = n1.y * tv.idx - tv.oix, by0 = n1.z * tv.idy - tv.oiy, by1 = n1.w * tv.idy - tv.oiy;
+    const float az0 = n2.x * tv.idz - tv.oiz, az1 = n2.y * tv.idz - tv.oiz, bz0 = n2.z * tv.idz - tv.oiz, bz1 = n2.w * tv.idz - tv.oiz;
+    const float amin = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fmaxf(fminf(az0, az1), 0.0f));
+    const float amax = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fminf(fmaxf(az0, az1), tv.best));
+    const float bmin = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fmaxf(fminf(bz0, bz1), 0.0f));
+    const float bmax = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fminf(fmaxf(bz0, bz1), tv.best));
+    const bool ha = amin <= amax, hb = bmin <= bmax;
+    const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+    const bool both = ha && hb, none = !(ha || hb);
+    const bool first1 = hb && (!ha || bmin < amin);  // child 1 is the (nearer) one to enter
+    const int nearc = first1 ? c1 : c0, farc = first1 ? c0 : c1;
+    if (both) stk.push(tv.sp, farc);
+    int sp = tv.sp + (both ? 1 : 0);
+    int next = nearc;
+    if (none) {
+        const bool empty = sp == 0;
+        sp -= empty ? 0 : 1;
+        const int popped = stk.pop(sp);  // when empty this reads level 0 (in bounds) and is discarded
+        next = empty ? kNodeDone : popped;
+    }
+    tv.node = next; tv.sp = sp;
+}
+
+// One leaf: test its 1..8 triangles.  ~node = (first << 3) | (count - 1).  Returns with tv.node = next node or kNodeDone.
+template <bool COUNT, int BLOCK>
+TRG_DEV void trav_leaf_step(const SceneView &sc, Trav &tv, bool any, LdsStack<BLOCK> stk, Counters &cnt) {
+    const uint32_t code = (uint32_t)~tv.node;
+    const uint32_t first = code >> 3, count = (code & 7u) + 1u;
+    bool stop = false;
+    for (uint32_t k = 0; k < count; ++k) {
+        const v4f *tr = sc.tris + (first + k) * 3;
+        const v4f a = tr[0], b = tr[1], c = tr[2];
+        const bool masked_in = (((uint32_t)__float_as_int(b.w)) & tv.rmask) != 0u;
+        if (COUNT) { if (masked_in) cnt.tris++; if (mbcnt64(__ballot(1)) == 0) cnt.wtris++; }
+        float t, u, v;
+        const bool ok = tri_test(a, b, c, tv.o, tv.d, tv.tmax, t, u, v) && masked_in;
+        const int prim = __float_as_int(a.w);
+        const bool take = ok && (any || !tv.found || t < tv.best || (t == tv.best && prim < tv.hit.prim));
+        tv.found = tv.found || ok;
+        tv.best = (take && !any) ? t : tv.best;
+        tv.hit.t = take ? t : tv.hit.t;
+        tv.hit.prim = take ? prim : tv.hit.prim;
+        tv.hit.u = take ? u : tv.hit.u;
+        tv.hit.v = take ? v : tv.hit.v;
+        if (any && ok) { stop = true; break; }
+    }
+    const bool empty = tv.sp == 0;
+    int sp = tv.sp - ((stop || empty) ? 0 : 1);
+    const int popped = stk.pop(sp);
+    tv.node = (stop || empty) ? kNodeDone : popped;
+    tv.sp = sp;
+}
+
+// Nearest-hit (ANY=false) or any-hit (ANY=true) query for one ray per lane.
+template <bool ANY, bool COUNT, int BLOCK>
+TRG_DEV bool traverse(const SceneView &sc, V3 o, V3 d, float tmax_ray, uint32_t rmask, Hit &hit, LdsStack<BLOCK> stk,
+                      Counters &cnt) {
+    Trav tv;
+    trav_begin(tv, o, d, tmax_ray, rmask);
     for (;;) {
-        while (node >= 0) {
-            const v4f *n = sc.nodes + node * 4;
-            const v4f n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
-            if (COUNT) cnt.nodes++;
-            // slab tests; (b - o) * inv written as b*inv - o*inv so the fast build gets one fma each.
-            // Boxes are padded by 2e-5 x scene extent on the host, far more than the rounding of these
-            // products, so a triangle the Moeller-Trumbore test accepts is never culled.
-            const float ax0 = n0.x * idx - oix, ax1 = n0.y * idx - oix, ay0 = n0.z * idy - oiy, ay1 = n0.w * idy - oiy;
-            const float bx0 = n1.x * idx - oix, bx1 = n1.y * idx - oix, by0 = n1.z * idy - oiy, by1 = n1.w * idy - oiy;
-            const float az0 = n2.x * idz - oiz, az1 = n2.y * idz - oiz, bz0 = n2.z * idz - oiz, bz1 = n2.w * idz - oiz;
-            const float amin = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fmaxf(fminf(az0, az1), 0.0f));
-            const float amax = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fminf(fmaxf(az0, az1), best));
-            const float bmin = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fmaxf(fminf(bz0, bz1), 0.0f));
-            const float bmax = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fminf(fmaxf(bz0, bz1), best));
-            const bool ha = amin <= amax, hb = bmin <= bmax;
-            const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-            if (ha && hb) {
-                const bool swap = bmin < amin;
-                node = swap ? c1 : c0;
-                stk.push(sp++, swap ? c0 : c1);
-            } else if (ha) {
-                node = c0;
-            } else if (hb) {
-                node = c1;
-            } else {
-                if (sp == 0) return found;
-                node = stk.pop(--sp);
+        while (tv.node >= 0) trav_node_step<COUNT, BLOCK>(sc, tv, stk, cnt);
+        if (tv.node == kNodeDone) break;
+        trav_leaf_step<COUNT, BLOCK>(sc, tv, ANY, stk, cnt);
+        if (tv.node == kNodeDone) break;
+    }
+    hit = tv.hit;
+    return tv.found;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Queue-draining tracer for the path-pool megakernel (render_pool_kernel).
+//
+// A workgroup keeps a pool of path slots in LDS; a compacted list names the rays to trace this phase
+// (nearest-hit rays of the current bounce and any-hit shadow rays of the previous one, mixed).  Every
+// lane of every wavefront is a worker: when it has no ray it takes the next list entry (one LDS atomic
+// per wavefront per refill, slots handed out with a ballot / mbcnt prefix), traverses, writes the result
+// to the slot and comes back for more.  Lanes whose rays end early therefore do not idle until the
+// slowest lane of the wavefront is done -- the reason secondary rays ran at 23-46 % lane utilisation in
+// the one-ray-per-lane kernel.  A refill is attempted only when >= kRefillMin lanes are idle (or all are).
+//
+// Slot layout (float4 arrays in LDS, P = slots per workgroup):
+//   R0[s] = (origin.xyz, maxDistance)   R1[s] = (direction.xyz, bits mask)      nearest-hit ray
+//   SH[s] = (shadow direction.xyz, shadow maxDistance; set to -1 by the tracer when occluded);
+//           the shadow ray starts at R0[s].xyz (same origin as the next bounce ray); tracers never write R0/R1
+//   H[s]  = (t or -1, bits primitiveIndex, u, v)                                 nearest-hit result
+// List entry = slot | (kind << 15), kind 0 = nearest, 1 = shadow (any-hit, mask 1).
+// ---------------------------------------------------------------------------------------------
+#ifndef TRG_REFILL_MIN
+#define TRG_REFILL_MIN 16
+#endif
+constexpr int kRefillMin = TRG_REFILL_MIN;
+
+struct PoolView {
+    v4f *R0, *R1, *SH, *H;
+};
+
+template <bool COUNT, int BLOCK>
+TRG_DEV void trace_queue(const SceneView &sc, const PoolView pv, const unsigned short *list, uint32_t count,
+                         uint32_t *head, LdsStack<BLOCK> stk, Counters &cnt) {
+    const uint32_t lane = threadIdx.x & 63u;
+    bool busy = false, exhausted = false, any = false;
+    uint32_t slot = 0;
+    Trav tv;
+    trav_begin(tv, mk(0.0f, 0.0f, 0.0f), mk(0.0f, 0.0f, 1.0f), 0.0f, 0u);
+    tv.node = kNodeDone;
+    for (;;) {
+        // ---- refill: idle lanes take the next list entries ----
+        const uint64_t idle = __ballot(!busy);
+        if (!exhausted && idle != 0ull) {
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            const int leader = __ffsll((long long)idle) - 1;
+            uint32_t base = 0;
+            if ((int)lane == leader) base = atomicAdd(head, n_idle);
+            base = (uint32_t)__shfl((int)base, leader, 64);
+            if (base + n_idle >= count) exhausted = true;
+            const uint32_t my = base + mbcnt64(idle);
+            if (!busy && my < count) {
+                const uint32_t e = list[my];
+                slot = e & 0x7FFFu;
+                any = (e >> 15) != 0u;
+                const v4f r0 = pv.R0[slot];  // the shadow ray starts where the next ray starts
+                const v4f r1 = any ? pv.SH[slot] : pv.R1[slot];
+                trav_begin(tv, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), any ? r1.w : r0.w,
+                           any ? 1u : (uint32_t)__float_as_int(r1.w));
+                busy = true;
             }
         }
-        // leaf: ~node = (first << 3) | (count - 1)
-        const uint32_t code = (uint32_t)~node;
-        const uint32_t first = code >> 3, count = (code & 7u) + 1u;
-        for (uint32_t k = 0; k < count; ++k) {
-            const v4f *tr = sc.tris + (first + k) * 3;
-            const v4f a = tr[0], b = tr[1], c = tr[2];
-            const uint32_t tmask = (uint32_t)__float_as_int(b.w);
-            if ((tmask & rmask) == 0u) continue;
-            if (COUNT) cnt.tris++;
-            float t, u, v;
-            if (!tri_test(a, b, c, o, d, tmax_ray, t, u, v)) continue;
-            if (ANY) { hit.t = t; return true; }
-            const int prim = __float_as_int(a.w);
-            if (!found || t < best || (t == best && prim < hit.prim)) {
-                found = true; best = t;
-                hit.t = t; hit.prim = prim; hit.u = u; hit.v = v;
+        if (__ballot(busy) == 0ull) break;
+        if (busy) {
+            for (;;) {
+                while (tv.node >= 0) trav_node_step<COUNT, BLOCK>(sc, tv, stk, cnt);
+                if (tv.node == kNodeDone) break;
+                trav_leaf_step<COUNT, BLOCK>(sc, tv, any, stk, cnt);
+                if (tv.node == kNodeDone) break;
+                // enough lanes of this wavefront have run dry: let them refill (state stays in registers)
+                if (!exhausted && __popcll(__ballot(1)) <= 64 - kRefillMin) break;
+            }
+            if (tv.node == kNodeDone) {
+                if (any) {
+                    if (tv.found) { v4f sh = pv.SH[slot]; sh.w = -1.0f; pv.SH[slot] = sh; }
+                } else {
+                    v4f h;
+                    h.x = tv.found ? tv.hit.t : -1.0f; h.y = __int_as_float(tv.hit.prim); h.z = tv.hit.u; h.w = tv.hit.v;
+                    pv.H[slot] = h;
+                }
+                busy = false;
             }
         }
-        if (sp == 0) return found;
-        node = stk.pop(--sp);
+    }
+}
+
+// wave-compacted append of `val` to an LDS list: one atomic per wavefront, slots by ballot prefix
+TRG_DEV void list_append(bool pred, unsigned short val, unsigned short *list, uint32_t *counter) {
+    const uint64_t m = __ballot(pred);
+    if (m != 0ull) {
+        const uint32_t lane = threadIdx.x & 63u;
+        const int leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, leader, 64);
+        if (pred) list[base + mbcnt64(m)] = val;
     }
 }
 

@@ -14,6 +14,11 @@ constexpr int kTile = 16;          // a workgroup renders a 16x16 pixel tile, on
 constexpr int kCounterSlots = 64;  // ray counters are spread over 64 slots to avoid same-address atomics
 constexpr int kCounterWords = 8;   // primary, bounce, shadow, shaded, node_fetches, tri_tests, 2 spare
 constexpr uint32_t kMaxLdsScene = 40u * 1024u;  // scenes up to this size are staged in LDS per workgroup
+#ifndef TRG_POOL_S
+#define TRG_POOL_S 2
+#endif
+constexpr int kPoolS = TRG_POOL_S;           // frames (path slots per thread) a pool workgroup keeps in flight
+constexpr uint32_t kPoolSlotBytes = 64u;      // R0, R1, SH, H: four float4 per slot
 
 // The scene lives in ONE device allocation: [nodes | tris | normals | colors | mats], every section
 // 16-byte aligned, so a workgroup can stage it into LDS with a single stream of 16-byte copies.
@@ -32,6 +37,7 @@ struct RenderParams {
     uint32_t frame_begin, spp, bounces, row0, rows, tiles_x;
     uint32_t stack_off;            // byte offset of the traversal stacks in dynamic LDS
     uint32_t red_off;              // byte offset of the counter-reduction scratch in dynamic LDS
+    uint32_t pool_off;             // render_pool_kernel: byte offset of the path pool (slots, lists, counters)
 };
 
 struct TraceParams {
@@ -45,6 +51,8 @@ struct TraceParams {
 #define TRG_DECL_LAUNCHERS(SFX)                                                                                   \
     hipError_t launch_render_##SFX(const RenderParams &p, bool lds_scene, bool counters, uint32_t grid,          \
                                    size_t lds_bytes, hipStream_t s);                                             \
+    hipError_t launch_render_pool_##SFX(const RenderParams &p, bool lds_scene, bool counters, uint32_t grid,     \
+                                        size_t lds_bytes, hipStream_t s);                                        \
     hipError_t launch_trace_##SFX(const TraceParams &p, bool lds_scene, bool any_hit, size_t lds_bytes,          \
                                   hipStream_t s);                                                                \
     hipError_t launch_halton_##SFX(const uint32_t *i, const uint32_t *d, uint32_t n, float *out, hipStream_t s); \

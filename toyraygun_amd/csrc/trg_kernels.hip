@@ -51,8 +51,11 @@ TRG_DEV uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
+#ifndef TRG_EXP_WAVES
+#define TRG_EXP_WAVES 1
+#endif
 template <bool LDS_SCENE, bool COUNT>
-__global__ __launch_bounds__(trg::kBlock) void render_kernel(const trg::RenderParams p) {
+__global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES) void render_kernel(const trg::RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const SceneView sc = scene_view<LDS_SCENE>(p.sc, smem);
     LdsStack<trg::kBlock> stk;
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(trg::kBlock) void render_kernel(const trg::RenderPa
     const uint32_t pix = y * p.u.width + x;
 
     uint32_t n_primary = 0, n_bounce = 0, n_shadow = 0, n_shaded = 0;
-    Counters cnt; cnt.nodes = 0; cnt.tris = 0;
+    Counters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.wnodes = 0; cnt.wtris = 0;
 
     const uint32_t offset = valid ? p.offsets[pix] : 0u;
     v4f *accum = reinterpret_cast<v4f *>(p.accum);
@@ -150,16 +153,192 @@ __global__ __launch_bounds__(trg::kBlock) void render_kernel(const trg::RenderPa
 
     // ray counters: wavefront reduce -> workgroup reduce in LDS -> one atomic per counter per workgroup,
     // spread over kCounterSlots slots
-    uint32_t vals[6] = { n_primary, n_bounce, n_shadow, n_shaded, cnt.nodes, cnt.tris };
+    uint32_t vals[8] = { n_primary, n_bounce, n_shadow, n_shaded, cnt.nodes, cnt.tris, cnt.wnodes, cnt.wtris };
     uint32_t *red = reinterpret_cast<uint32_t *>(smem + p.red_off);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 0; k < 8; ++k) {
         if (!COUNT && k >= 4) break;
         const uint32_t s = wave_sum(vals[k]);
         if (lane == 0) red[wave * 8 + k] = s;
     }
     __syncthreads();
-    if (threadIdx.x < (COUNT ? 6 : 4)) {
+    if (threadIdx.x < (COUNT ? 8 : 4)) {
+        const uint32_t k = threadIdx.x;
+        const unsigned long long s = (unsigned long long)red[k] + red[8 + k] + red[16 + k] + red[24 + k];
+        if (s) atomicAdd(&p.counters[(blockIdx.x % trg::kCounterSlots) * trg::kCounterWords + k], s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// render_pool_kernel: the same path tracer, scheduled as a workgroup-local wavefront.
+//
+// A workgroup owns a 16x16 pixel tile and S consecutive frames at a time: a pool of P = 256*S path
+// slots in LDS.  Thread t owns the S paths of its pixel (throughput, radiance, running average stay in
+// ITS registers, so the per-pixel accumulation order is the reference's), but rays are traced by
+// whichever lane is free: each bounce is one TRACE phase (trace_queue drains the compacted list of
+// nearest-hit rays of this bounce + shadow rays of the previous bounce) and one SHADE phase (owners
+// consume hit records, emit the next rays and append them to the next list with ballot/prefix
+// compaction).  Dead paths simply stop appearing in the lists.  Arithmetic per path is identical to
+// render_kernel: only the schedule differs (the strict build of both is bit-exact against the oracle).
+// ---------------------------------------------------------------------------------------------
+template <bool LDS_SCENE, bool COUNT, int S>
+__global__ __launch_bounds__(trg::kBlock) void render_pool_kernel(const trg::RenderParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const SceneView sc = scene_view<LDS_SCENE>(p.sc, smem);
+    LdsStack<trg::kBlock> stk;
+    stk.base = reinterpret_cast<int *>(smem + p.stack_off) + threadIdx.x;
+    constexpr int P = trg::kBlock * S;
+    PoolView pv;
+    pv.R0 = reinterpret_cast<v4f *>(smem + p.pool_off);
+    pv.R1 = pv.R0 + P; pv.SH = pv.R1 + P; pv.H = pv.SH + P;
+    unsigned short *lists = reinterpret_cast<unsigned short *>(pv.H + P);  // two lists of 2*P entries
+    uint32_t *ctr = reinterpret_cast<uint32_t *>(lists + 4 * P);         // [0] head, [1] n(list 0), [2] n(list 1)
+
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t bx = blockIdx.x % p.tiles_x, by = blockIdx.x / p.tiles_x;
+    const uint32_t x = bx * trg::kTile + (wave & 1) * 8 + (lane & 7);
+    const uint32_t y = p.row0 + by * trg::kTile + (wave >> 1) * 8 + (lane >> 3);
+    const bool valid = (x < p.u.width) && (y < p.row0 + p.rows) && (y < p.u.height);
+    const uint32_t pix = y * p.u.width + x;
+
+    uint32_t n_primary = 0, n_bounce = 0, n_shadow = 0, n_shaded = 0;
+    Counters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.wnodes = 0; cnt.wtris = 0;
+    const uint32_t offset = valid ? p.offsets[pix] : 0u;
+    v4f *accum = reinterpret_cast<v4f *>(p.accum);
+    V3 acc = mk(0.0f, 0.0f, 0.0f);
+    if (valid && p.frame_begin > 0) { const v4f a = accum[pix]; acc = mk(a.x, a.y, a.z); }
+    const V3 light_color = mk(p.u.light_color[0], p.u.light_color[1], p.u.light_color[2]);
+    const uint32_t frame_end = p.frame_begin + p.spp;
+
+    V3 thr[S], rad[S], scol[S];
+    bool alive[S], shpend[S];
+
+    for (uint32_t f0 = p.frame_begin; f0 < frame_end; f0 += S) {
+        // ---------------- raygen: owners fill their slots, list 0 = every valid path ----------------
+        if (threadIdx.x == 0) { ctr[0] = 0u; ctr[1] = 0u; ctr[2] = 0u; }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            const uint32_t slot = threadIdx.x + trg::kBlock * j;
+            const bool pvalid = valid && (f0 + j < frame_end);
+            thr[j] = mk(1.0f, 1.0f, 1.0f); rad[j] = mk(0.0f, 0.0f, 0.0f); scol[j] = mk(0.0f, 0.0f, 0.0f);
+            alive[j] = pvalid; shpend[j] = false;
+            if (pvalid) {
+                V3 o, d;
+                raygen(p.u, x, y, offset + f0 + j, o, d);
+                v4f r0, r1;
+                r0.x = o.x; r0.y = o.y; r0.z = o.z; r0.w = INFINITY;
+                r1.x = d.x; r1.y = d.y; r1.z = d.z; r1.w = __int_as_float(3);  // RAY_MASK_PRIMARY
+                pv.R0[slot] = r0; pv.R1[slot] = r1;
+                n_primary++;
+            }
+            list_append(pvalid, (unsigned short)slot, lists, &ctr[1]);
+        }
+        __syncthreads();
+
+        uint32_t cur = 0;
+        for (uint32_t b = 0; b <= p.bounces; ++b) {
+            const uint32_t n_cur = ctr[1 + cur];
+            if (n_cur == 0u) break;  // workgroup-uniform: nothing left in flight
+            // ---------------- TRACE ----------------
+            trace_queue<COUNT, trg::kBlock>(sc, pv, lists + cur * 2 * P, n_cur, &ctr[0], stk, cnt);
+            __syncthreads();
+            if (threadIdx.x == 0) { ctr[0] = 0u; ctr[1 + cur] = 0u; }  // head, and this list becomes the next "next"
+            // ---------------- SHADE ----------------
+            unsigned short *next = lists + (cur ^ 1u) * 2 * P;
+            uint32_t *n_next = &ctr[1 + (cur ^ 1u)];
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                const uint32_t slot = threadIdx.x + trg::kBlock * j;
+                if (shpend[j]) {  // shadowHit (Raytracing.metal:219-246) of the previous bounce
+                    if (pv.SH[slot].w >= 0.0f) rad[j] = rad[j] + scol[j];
+                    shpend[j] = false;
+                }
+                bool trace_next = false, trace_shadow = false;
+                if (alive[j] && b < p.bounces) {
+                    const v4f h = pv.H[slot];
+                    if (!(h.x >= 0.0f)) {
+                        alive[j] = false;  // Raytracing.metal:139-144
+                    } else {
+                        const int prim = __float_as_int(h.y);
+                        const float hu = h.z, hv = h.w;
+                        const uint32_t mat = sc.mats[prim];
+                        if (mat == TRG_MATERIAL_DEFAULT) {
+                            n_shaded++;
+                            const v4f r0 = pv.R0[slot], r1 = pv.R1[slot];
+                            const V3 o = mk(r0.x, r0.y, r0.z), d = mk(r1.x, r1.y, r1.z);
+                            const V3 Pp = o + d * h.x;
+                            const float cx = 1.0f - hu - hv, cy = hu;
+                            const V3 vcol = interp_attr(sc.colors, prim, cx, cy);
+                            const V3 nrm = normalize(interp_attr(sc.normals, prim, cx, cy));
+                            float r[4];
+                            uint32_t hi = offset + f0 + j;
+                            asm volatile("" : "+v"(hi));
+                            halton4(hi, b, r);
+                            const LightSample ls = sample_area_light(p.u, r[0], r[1], Pp, nrm);
+                            thr[j] = thr[j] * vcol;
+                            const V3 so = Pp + nrm * 1e-3f;
+                            const float smax = ls.dist - 1e-3f;
+                            scol[j] = ls.color * thr[j];
+                            const V3 sd = sample_cosine_hemisphere(r[2], r[3]);
+                            const V3 nd = align_hemisphere(sd, nrm);
+                            v4f q0, q1, sh;
+                            q0.x = so.x; q0.y = so.y; q0.z = so.z; q0.w = INFINITY;
+                            q1.x = nd.x; q1.y = nd.y; q1.z = nd.z; q1.w = __int_as_float(1);  // RAY_MASK_SECONDARY
+                            sh.x = ls.dir.x; sh.y = ls.dir.y; sh.z = ls.dir.z; sh.w = smax;
+                            pv.R0[slot] = q0; pv.R1[slot] = q1; pv.SH[slot] = sh;
+                            trace_shadow = smax >= 0.0f;
+                            trace_next = (b + 1u < p.bounces);
+                            if (trace_shadow) { shpend[j] = true; n_shadow++; }
+                            if (trace_next) n_bounce++;
+                        } else if (mat == TRG_MATERIAL_EMISSIVE) {
+                            rad[j] = light_color;
+                            alive[j] = false;
+                        } else {
+                            rad[j] = mk(1.0f, 0.0f, 1.0f);  // ray left as is: traced again unchanged
+                            trace_next = (b + 1u < p.bounces);
+                            if (trace_next) n_bounce++;
+                        }
+                    }
+                }
+                list_append(trace_next, (unsigned short)slot, next, n_next);
+                list_append(trace_shadow, (unsigned short)(slot | 0x8000u), next, n_next);
+            }
+            __syncthreads();
+            cur ^= 1u;
+        }
+        // ---------------- accumulate (Accumulate.metal:19-39), frames in order ----------------
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            const uint32_t f = f0 + j;
+            if (f < frame_end) {
+                if (f == 0) {
+                    acc = rad[j];
+                } else {
+                    const V3 prev = acc * (float)f;
+                    const V3 c = rad[j] + prev;
+                    const float f1 = (float)(f + 1u);
+                    acc = mk(c.x / f1, c.y / f1, c.z / f1);
+                }
+            }
+        }
+    }
+    if (valid) {
+        v4f outv; outv.x = acc.x; outv.y = acc.y; outv.z = acc.z; outv.w = 1.0f;
+        accum[pix] = outv;
+    }
+
+    uint32_t vals[8] = { n_primary, n_bounce, n_shadow, n_shaded, cnt.nodes, cnt.tris, cnt.wnodes, cnt.wtris };
+    uint32_t *red = reinterpret_cast<uint32_t *>(smem + p.red_off);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (!COUNT && k >= 4) break;
+        const uint32_t s = wave_sum(vals[k]);
+        if (lane == 0) red[wave * 8 + k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < (COUNT ? 8 : 4)) {
         const uint32_t k = threadIdx.x;
         const unsigned long long s = (unsigned long long)red[k] + red[8 + k] + red[16 + k] + red[24 + k];
         if (s) atomicAdd(&p.counters[(blockIdx.x % trg::kCounterSlots) * trg::kCounterWords + k], s);
@@ -177,7 +356,7 @@ __global__ __launch_bounds__(trg::kBlock) void trace_kernel(const trg::TracePara
     if (i >= p.n) return;
     const trg_ray r = p.rays[i];
     const V3 o = mk(r.origin[0], r.origin[1], r.origin[2]), d = mk(r.direction[0], r.direction[1], r.direction[2]);
-    Counters cnt; cnt.nodes = 0; cnt.tris = 0;
+    Counters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.wnodes = 0; cnt.wtris = 0;
     Hit h; h.t = -1.0f; h.prim = -1; h.u = 0.0f; h.v = 0.0f;
     bool found = false;
     if (r.maxDistance >= 0.0f) found = traverse<ANY, false, trg::kBlock>(sc, o, d, r.maxDistance, r.mask, h, stk, cnt);
@@ -262,6 +441,27 @@ hipError_t SFX(launch_render)(const RenderParams &p, bool lds_scene, bool counte
         else hipLaunchKernelGGL((render_kernel<false, false>), dim3(grid), dim3(kBlock), lds_bytes, s, p);
     }
     return hipGetLastError();
+}
+
+template <typename K>
+static hipError_t launch_big_lds(K kernel, const RenderParams &p, uint32_t grid, size_t lds_bytes, hipStream_t s) {
+    // more than 64 KB of dynamic LDS has to be opted into per kernel (gfx950 has 160 KB per CU)
+    if (lds_bytes > 64u * 1024u) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds_bytes, s, p);
+    return hipGetLastError();
+}
+
+hipError_t SFX(launch_render_pool)(const RenderParams &p, bool lds_scene, bool counters, uint32_t grid, size_t lds_bytes, hipStream_t s) {
+    constexpr int S = kPoolS;
+    if (lds_scene) {
+        if (counters) return launch_big_lds(render_pool_kernel<true, true, S>, p, grid, lds_bytes, s);
+        return launch_big_lds(render_pool_kernel<true, false, S>, p, grid, lds_bytes, s);
+    }
+    if (counters) return launch_big_lds(render_pool_kernel<false, true, S>, p, grid, lds_bytes, s);
+    return launch_big_lds(render_pool_kernel<false, false, S>, p, grid, lds_bytes, s);
 }
 
 hipError_t SFX(launch_trace)(const TraceParams &p, bool lds_scene, bool any_hit, size_t lds_bytes, hipStream_t s) {
