@@ -1,1 +1,2 @@
-for ml in 1 2 4 8; do for tc in 0.3 1.2 3.0; do echo "maxleaf=$ml travcost=$tc"; TRG_BVH_MAXLEAF=$ml TRG_BVH_TRAVCOST=$tc timeout -k 10 120 python scripts/exp_bounces.py 2>&1 | grep "bounces 3"; done; done
+for ml in 1 2 4; do echo "maxleaf=$ml"; TRG_BVH_MAXLEAF=$ml timeout -k 10 120 python scripts/exp_time.py base 2>&1 | grep lds=; done
+timeout -k 10 300 python scripts/exp_time.py w6 w8 2>&1 | grep lds=

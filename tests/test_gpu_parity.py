@@ -184,6 +184,15 @@ def test_intersector_large_scene_in_hbm(capi, O):
         got = c.trace(rays)
         assert np.array_equal(got.view(np.uint8), ref.view(np.uint8))
         assert np.array_equal(c.trace(rays, any_hit=True) >= 0, O.intersect_any(scene, rays) >= 0)
+        # and the whole path on that scene, both megakernels, against the oracle (which uses its own BVH)
+        O.set_trig_mode(O.TRIG_PORTABLE)
+        ref_img, rst = O.render(scene, 64, 64, 2, 3)
+        O.set_trig_mode(O.TRIG_LIBM)
+        for k in KERNELS:
+            c.set_option(capi.OPT_KERNEL, k)
+            c.reset_stats()
+            c.render(0, 2, 3)
+            assert np.array_equal(_bits(c.read_accum()), _bits(ref_img)) and c.stats().rays == rst.rays
     finally:
         c.close()
 
@@ -214,14 +223,19 @@ def test_degenerate_scenes(capi, O):
 
 
 # ------------------------------------------------------------------ whole path
-@pytest.mark.parametrize("w,h,spp,bounces", [(256, 256, 1, 1), (96, 64, 4, 3), (48, 32, 2, 8), (33, 17, 3, 15)])
-def test_render_strict_is_bit_exact(capi, O, cornell, w, h, spp, bounces):
+KERNELS = [0, 1]   # TRG_KERNEL_DIRECT, TRG_KERNEL_POOL: two schedules of the same arithmetic
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("w,h,spp,bounces", [(256, 256, 1, 1), (96, 64, 4, 3), (48, 32, 2, 8), (33, 17, 3, 15), (40, 40, 5, 2)])
+def test_render_strict_is_bit_exact(capi, O, cornell, w, h, spp, bounces, kernel):
     off = O.pixel_offsets(w, h)
     c = make_ctx(O, cornell, w, h, offsets=off)
     try:
         O.set_trig_mode(O.TRIG_PORTABLE)
         ref, st = O.render(cornell, w, h, spp, bounces, offsets=off)
         c.set_option(capi.OPT_STRICT, 1)
+        c.set_option(capi.OPT_KERNEL, kernel)
         c.render(0, spp, bounces)
         img, gs = c.read_accum(), c.stats()
         assert np.array_equal(_bits(img), _bits(ref))
@@ -247,12 +261,14 @@ def test_render_c1_fast_within_tolerance_and_golden(capi, O, cornell, ctx256, go
     assert (img[..., 3] == 1.0).all()
 
 
+@pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("w,h,spp,bounces", [(128, 96, 16, 3), (64, 64, 8, 8)])
-def test_render_fast_within_tolerance(capi, O, cornell, w, h, spp, bounces):
+def test_render_fast_within_tolerance(capi, O, cornell, w, h, spp, bounces, kernel):
     off = O.pixel_offsets(w, h)
     c = make_ctx(O, cornell, w, h, offsets=off)
     try:
         ref, st = O.render(cornell, w, h, spp, bounces, offsets=off)
+        c.set_option(capi.OPT_KERNEL, kernel)
         c.render(0, spp, bounces)
         img, gs = c.read_accum(), c.stats()
         rmse, frac_ok, worst = image_metrics(img, ref)
@@ -274,12 +290,14 @@ def test_golden_frames_on_gpu(capi, O, cornell, golden):
         c.close()
 
 
-def test_continuation_bands_and_determinism(capi, O, cornell):
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_continuation_bands_and_determinism(capi, O, cornell, kernel):
     """Size-independent properties: frames [0,6) == [0,2)+[2,6); union of row bands == full frame;
     repeated launches are bitwise identical; LDS-resident and HBM-resident scenes agree bitwise."""
     w, h = 80, 48
     c = make_ctx(O, cornell, w, h)
     try:
+        c.set_option(capi.OPT_KERNEL, kernel)
         for strict in (0, 1):
             c.set_option(capi.OPT_STRICT, strict)
             c.render(0, 6, 3)
@@ -288,6 +306,9 @@ def test_continuation_bands_and_determinism(capi, O, cornell):
             assert np.array_equal(_bits(full), _bits(c.read_accum()))
             c.render(0, 2, 3)
             c.render(2, 4, 3)
+            assert np.array_equal(_bits(full), _bits(c.read_accum()))
+            c.render(0, 1, 3)
+            c.render(1, 5, 3)            # odd split: the pool kernel batches frames in pairs
             assert np.array_equal(_bits(full), _bits(c.read_accum()))
             c.render(0, 1, 3)            # clobber, then rebuild from uneven bands
             for row0, rows in ((0, 7), (7, 16), (23, 1), (24, 24)):
@@ -347,6 +368,30 @@ def test_full_size_c2_properties(capi, O, cornell):
         c.close()
 
 
+def test_kernels_agree(capi, O, cornell):
+    c = make_ctx(O, cornell, 200, 120)
+    try:
+        for strict in (1, 0):
+            c.set_option(capi.OPT_STRICT, strict)
+            imgs, rays = [], []
+            for k in KERNELS:
+                c.set_option(capi.OPT_KERNEL, k)
+                c.reset_stats()
+                c.render(0, 6, 5)
+                imgs.append(c.read_accum())
+                st = c.stats()
+                rays.append((st.primary_rays, st.bounce_rays, st.shadow_rays, st.shaded_hits))
+            if strict:
+                assert np.array_equal(_bits(imgs[0]), _bits(imgs[1])) and rays[0] == rays[1]
+            else:
+                rmse, frac_ok, _ = image_metrics(imgs[1], imgs[0])
+                assert rmse <= TOL_RMSE and frac_ok >= TOL_FRAC
+        with pytest.raises(capi.TrgError):
+            c.set_option(capi.OPT_KERNEL, 7)
+    finally:
+        c.close()
+
+
 def test_invalid_material_is_magenta(capi, O):
     s = O.OracleScene()
     m = np.eye(4, dtype=np.float32)
@@ -358,9 +403,11 @@ def test_invalid_material_is_magenta(capi, O):
             O.set_trig_mode(mode)
             ref, _ = O.render(s, 32, 32, 2, 3, offsets=O.pixel_offsets(32, 32))
             c.set_option(capi.OPT_STRICT, strict)
-            c.render(0, 2, 3)
-            img = c.read_accum()
-            assert np.array_equal(_bits(img), _bits(ref))
+            for k in KERNELS:
+                c.set_option(capi.OPT_KERNEL, k)
+                c.render(0, 2, 3)
+                img = c.read_accum()
+                assert np.array_equal(_bits(img), _bits(ref))
         assert (img[..., :3] == np.array([1, 0, 1], np.float32)).all()
     finally:
         O.set_trig_mode(O.TRIG_LIBM)

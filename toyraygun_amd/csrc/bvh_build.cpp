@@ -12,7 +12,7 @@ namespace trg {
 namespace {
 
 constexpr int kBins = 16;
-uint32_t kMaxLeaf = 4;               // leaf encoding allows 8 (tunable: TRG_BVH_MAXLEAF)
+uint32_t kMaxLeaf = 2;               // leaf encoding allows 8 (tunable: TRG_BVH_MAXLEAF)
 float kTravCost = 1.2f;               // SAH cost of one node visit relative to one triangle test (TRG_BVH_TRAVCOST)
 constexpr uint32_t kSahDepthCap = 24; // below this depth switch to balanced median splits
 constexpr float kInf = std::numeric_limits<float>::infinity();
