@@ -45,3 +45,51 @@ inline toyraygun::Scene *createCornellBoxScene() {
     }
     return scene;
 }
+
+// BASELINE config C4 (a synthetic this project defines): the Cornell box plus the reference's cube
+// mesh (Scene::addCube) replicated on an n x n x n lattice inside the room.  Lattice region x,z in
+// [-0.9, 0.9], y in [0.05, 1.85]; cube side 0.25 x cell; per-cube jitter, y-rotation and colour from
+// pcg_hash32(seed ^ ...).  n = 44 -> 36 + 12 * 44^3 = 1,022,244 triangles.
+namespace toyraygun_scenes {
+inline uint32_t pcgHash32(uint32_t v) {
+    const uint32_t state = v * 747796405u + 2891336453u;
+    const uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+}  // namespace toyraygun_scenes
+
+inline toyraygun::Scene *createCornellLatticeScene(int n, uint32_t seed = 0x5EED0002u) {
+    using toyraygun_scenes::pcgHash32;
+    toyraygun::Scene *scene = createCornellBoxScene();
+    const float lo[3] = { -0.9f, 0.05f, -0.9f }, hi[3] = { 0.9f, 1.85f, 0.9f };
+    float cell[3];
+    for (int a = 0; a < 3; ++a) cell[a] = (hi[a] - lo[a]) / (float)n;
+    float minCell = cell[0];
+    if (cell[1] < minCell) minCell = cell[1];
+    if (cell[2] < minCell) minCell = cell[2];
+    const float side = 0.25f * minCell;
+    const float unit = 1.0f / 16777216.0f;
+    scene->m_vertexBuffer.reserve(scene->m_vertexBuffer.size() + (size_t)36 * n * n * n);
+    scene->m_normalBuffer.reserve(scene->m_normalBuffer.size() + (size_t)36 * n * n * n);
+    scene->m_colorBuffer.reserve(scene->m_colorBuffer.size() + (size_t)36 * n * n * n);
+    scene->m_indexBuffer.reserve(scene->m_indexBuffer.size() + (size_t)36 * n * n * n);
+    uint32_t id = 0;
+    float m[16];
+    for (int iz = 0; iz < n; ++iz)
+        for (int iy = 0; iy < n; ++iy)
+            for (int ix = 0; ix < n; ++ix, ++id) {
+                const uint32_t h0 = pcgHash32(seed ^ (id * 4u + 0u)), h1 = pcgHash32(seed ^ (id * 4u + 1u));
+                const uint32_t h2 = pcgHash32(seed ^ (id * 4u + 2u)), h3 = pcgHash32(seed ^ (id * 4u + 3u));
+                const float j0 = (float)(h0 >> 8) * unit - 0.5f, j1 = (float)(h1 >> 8) * unit - 0.5f;
+                const float j2 = (float)(h2 >> 8) * unit - 0.5f;
+                const float rot = (float)(h3 >> 8) * unit * 1.5707964f;
+                const float cx = lo[0] + ((float)ix + 0.5f + 0.3f * j0) * cell[0];
+                const float cy = lo[1] + ((float)iy + 0.5f + 0.3f * j1) * cell[1];
+                const float cz = lo[2] + ((float)iz + 0.5f + 0.3f * j2) * cell[2];
+                const bx::Vec3 color(0.3f + 0.6f * (float)((h0 >> 3) & 31) / 31.0f, 0.3f + 0.6f * (float)((h1 >> 3) & 31) / 31.0f,
+                                     0.3f + 0.6f * (float)((h2 >> 3) & 31) / 31.0f);
+                bx::mtxSRT(m, side, side, side, 0.0f, rot, 0.0f, cx, cy, cz);
+                scene->addCube(color, m);
+            }
+    return scene;
+}

@@ -307,7 +307,7 @@ void orc_scene_cornell_box(orc_scene *s)
 }
 /* SURVEY 8d C4 (a synthetic this project defines, not in the reference): Cornell box + the
  * reference cube mesh replicated on an n x n x n lattice inside the room.  Lattice region
- * x,z in [-0.9,0.9], y in [0.05,1.85]; cube side = 0.45 * cell; per-cube jitter and y-rotation
+ * x,z in [-0.9,0.9], y in [0.05,1.85]; cube side = 0.25 * cell; per-cube jitter and y-rotation
  * from pcg(seed).  n = 44 -> 36 + 12*44^3 = 1,022,244 triangles. */
 void orc_scene_cornell_lattice(orc_scene *s, int n, uint32_t seed)
 {
@@ -330,7 +330,7 @@ void orc_scene_cornell_lattice(orc_scene *s, int n, uint32_t seed)
                 float cx = lo[0] + ((float)ix + 0.5f + 0.3f * j0) * cell[0];
                 float cy = lo[1] + ((float)iy + 0.5f + 0.3f * j1) * cell[1];
                 float cz = lo[2] + ((float)iz + 0.5f + 0.3f * j2) * cell[2];
-                float side = 0.45f * fminf(cell[0], fminf(cell[1], cell[2]));
+                float side = 0.25f * fminf(cell[0], fminf(cell[1], cell[2]));
                 float col[3] = { 0.3f + 0.6f * (float)((h0 >> 3) & 31) / 31.0f,
                                  0.3f + 0.6f * (float)((h1 >> 3) & 31) / 31.0f,
                                  0.3f + 0.6f * (float)((h2 >> 3) & 31) / 31.0f };

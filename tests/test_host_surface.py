@@ -62,6 +62,11 @@ def test_host_scene_equals_oracle_scene(built, O):
     for k in ha:
         assert np.array_equal(ha[k], hb[k]), k
     assert ha["material_ids"].tolist() == [1] * 14 + [2] * 2
+    # the C4 lattice scene (product builder == oracle builder)
+    la, lb = host.Scene.cornell_lattice(5).buffers(), O.OracleScene.cornell_lattice(5).buffers()
+    assert la["material_ids"].shape == (36 + 12 * 125,)
+    for k in la:
+        assert np.array_equal(la[k], lb[k]), k
 
 
 def test_host_matrices_uniforms_offsets_equal_oracle(built, O):

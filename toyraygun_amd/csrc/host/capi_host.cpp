@@ -17,6 +17,7 @@ extern "C" {
 // ---- scene (a1) ----
 void *trh_scene_new() { return new Scene(); }
 void *trh_scene_cornell() { return createCornellBoxScene(); }
+void *trh_scene_lattice(int n, uint32_t seed) { return createCornellLatticeScene(n, seed); }
 void trh_scene_free(void *s) { delete static_cast<Scene *>(s); }
 void trh_scene_add(void *s, int kind, const float *color3, const float *mtx16) {
     Scene *sc = static_cast<Scene *>(s);

@@ -408,9 +408,7 @@ TRG_DEV void trav_begin(Trav &tv, V3 o, V3 d, float tmax, uint32_t rmask) {
 // Written with selects and two predicated LDS stack accesses instead of a four-way branch: the branchy
 // form spent more scalar instructions on exec-mask bookkeeping than vector instructions on the boxes.
 template <bool COUNT, int BLOCK>
-TRG_DEV void trav_node_step(const SceneView &sc, Trav &tv, LdsStack<BLOCK> stk, Counters &cnt) {
-    const v4f *n = sc.nodes + tv.node * 4;
-    const v4f n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+TRG_DEV void trav_node_math(const v4f n0, const v4f n1, const v4f n2, const v4f n3, Trav &tv, LdsStack<BLOCK> stk, Counters &cnt) {
     if (COUNT) { cnt.nodes++; if (mbcnt64(__ballot(1)) == 0) cnt.wnodes++; }
     // slab tests; (b - o) * inv written as b*inv - o*inv so the fast build gets one fma each.
     // Boxes are padded by 2e-5 x scene extent on the host, far more than the rounding of these
@@ -439,6 +437,31 @@ TRG_DEV void trav_node_step(const SceneView &sc, Trav &tv, LdsStack<BLOCK> stk, 
     tv.node = next; tv.sp = sp;
 }
 
+template <bool COUNT, int BLOCK>
+TRG_DEV void trav_node_step(const SceneView &sc, Trav &tv, LdsStack<BLOCK> stk, Counters &cnt) {
+    const v4f *n = sc.nodes + tv.node * 4;
+    const v4f n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+    trav_node_math<COUNT, BLOCK>(n0, n1, n2, n3, tv, stk, cnt);
+}
+
+// One ray/triangle test folded into the traversal state; returns true when an any-hit query is satisfied.
+template <bool COUNT>
+TRG_DEV bool trav_tri_math(const v4f a, const v4f b, const v4f c, Trav &tv, bool any, Counters &cnt) {
+    const bool masked_in = (((uint32_t)__float_as_int(b.w)) & tv.rmask) != 0u;
+    if (COUNT) { if (masked_in) cnt.tris++; if (mbcnt64(__ballot(1)) == 0) cnt.wtris++; }
+    float t, u, v;
+    const bool ok = tri_test(a, b, c, tv.o, tv.d, tv.tmax, t, u, v) && masked_in;
+    const int prim = __float_as_int(a.w);
+    const bool take = ok && (any || !tv.found || t < tv.best || (t == tv.best && prim < tv.hit.prim));
+    tv.found = tv.found || ok;
+    tv.best = (take && !any) ? t : tv.best;
+    tv.hit.t = take ? t : tv.hit.t;
+    tv.hit.prim = take ? prim : tv.hit.prim;
+    tv.hit.u = take ? u : tv.hit.u;
+    tv.hit.v = take ? v : tv.hit.v;
+    return any && ok;
+}
+
 // One leaf: test its 1..8 triangles.  ~node = (first << 3) | (count - 1).  Returns with tv.node = next node or kNodeDone.
 template <bool COUNT, int BLOCK>
 TRG_DEV void trav_leaf_step(const SceneView &sc, Trav &tv, bool any, LdsStack<BLOCK> stk, Counters &cnt) {
@@ -448,19 +471,7 @@ TRG_DEV void trav_leaf_step(const SceneView &sc, Trav &tv, bool any, LdsStack<BL
     for (uint32_t k = 0; k < count; ++k) {
         const v4f *tr = sc.tris + (first + k) * 3;
         const v4f a = tr[0], b = tr[1], c = tr[2];
-        const bool masked_in = (((uint32_t)__float_as_int(b.w)) & tv.rmask) != 0u;
-        if (COUNT) { if (masked_in) cnt.tris++; if (mbcnt64(__ballot(1)) == 0) cnt.wtris++; }
-        float t, u, v;
-        const bool ok = tri_test(a, b, c, tv.o, tv.d, tv.tmax, t, u, v) && masked_in;
-        const int prim = __float_as_int(a.w);
-        const bool take = ok && (any || !tv.found || t < tv.best || (t == tv.best && prim < tv.hit.prim));
-        tv.found = tv.found || ok;
-        tv.best = (take && !any) ? t : tv.best;
-        tv.hit.t = take ? t : tv.hit.t;
-        tv.hit.prim = take ? prim : tv.hit.prim;
-        tv.hit.u = take ? u : tv.hit.u;
-        tv.hit.v = take ? v : tv.hit.v;
-        if (any && ok) { stop = true; break; }
+        if (trav_tri_math<COUNT>(a, b, c, tv, any, cnt)) { stop = true; break; }
     }
     const bool empty = tv.sp == 0;
     int sp = tv.sp - ((stop || empty) ? 0 : 1);
@@ -469,17 +480,49 @@ TRG_DEV void trav_leaf_step(const SceneView &sc, Trav &tv, bool any, LdsStack<BL
     tv.sp = sp;
 }
 
+// Unified step for scenes that live in HBM: every lane does ONE unit of work per iteration -- an inner node
+// (two boxes) or one triangle of its current leaf -- off a single group of four 16-byte loads, so there is
+// one memory round trip per iteration for the whole wavefront and no lane waits for lanes of the other
+// kind (the while-while form above serialises node and leaf phases; it is kept for LDS-resident scenes,
+// where instructions, not latency, are the cost).  A leaf is consumed by advancing its own code:
+// ~node = (first << 3) | (remaining - 1).
+template <bool COUNT, int BLOCK>
+TRG_DEV void trav_step_unified(const SceneView &sc, Trav &tv, bool any, LdsStack<BLOCK> stk, Counters &cnt) {
+    const bool inner = tv.node >= 0;
+    const uint32_t code = (uint32_t)~tv.node;
+    const uint32_t first = code >> 3, left = code & 7u;
+    const v4f *ptr = inner ? sc.nodes + tv.node * 4 : sc.tris + first * 3;
+    const v4f q0 = ptr[0], q1 = ptr[1], q2 = ptr[2], q3 = ptr[3];  // a triangle record reads 16 bytes into the next one: in bounds
+    if (inner) {
+        trav_node_math<COUNT, BLOCK>(q0, q1, q2, q3, tv, stk, cnt);
+    } else {
+        const bool stop = trav_tri_math<COUNT>(q0, q1, q2, tv, any, cnt);
+        const bool more = left != 0u;
+        const bool empty = tv.sp == 0;
+        const bool do_pop = !stop && !more && !empty;
+        const int sp = tv.sp - (do_pop ? 1 : 0);
+        const int popped = stk.pop(sp);
+        const int advanced = ~(int)(((first + 1u) << 3) | (left - 1u));
+        tv.node = stop ? kNodeDone : (more ? advanced : (empty ? kNodeDone : popped));
+        tv.sp = sp;
+    }
+}
+
 // Nearest-hit (ANY=false) or any-hit (ANY=true) query for one ray per lane.
-template <bool ANY, bool COUNT, int BLOCK>
+template <bool ANY, bool COUNT, int BLOCK, bool UNIFIED = false>
 TRG_DEV bool traverse(const SceneView &sc, V3 o, V3 d, float tmax_ray, uint32_t rmask, Hit &hit, LdsStack<BLOCK> stk,
                       Counters &cnt) {
     Trav tv;
     trav_begin(tv, o, d, tmax_ray, rmask);
-    for (;;) {
-        while (tv.node >= 0) trav_node_step<COUNT, BLOCK>(sc, tv, stk, cnt);
-        if (tv.node == kNodeDone) break;
-        trav_leaf_step<COUNT, BLOCK>(sc, tv, ANY, stk, cnt);
-        if (tv.node == kNodeDone) break;
+    if (UNIFIED) {
+        while (tv.node != kNodeDone) trav_step_unified<COUNT, BLOCK>(sc, tv, ANY, stk, cnt);
+    } else {
+        for (;;) {
+            while (tv.node >= 0) trav_node_step<COUNT, BLOCK>(sc, tv, stk, cnt);
+            if (tv.node == kNodeDone) break;
+            trav_leaf_step<COUNT, BLOCK>(sc, tv, ANY, stk, cnt);
+            if (tv.node == kNodeDone) break;
+        }
     }
     hit = tv.hit;
     return tv.found;
@@ -512,7 +555,7 @@ struct PoolView {
     v4f *R0, *R1, *SH, *H;
 };
 
-template <bool COUNT, int BLOCK>
+template <bool COUNT, int BLOCK, bool UNIFIED = false>
 TRG_DEV void trace_queue(const SceneView &sc, const PoolView pv, const unsigned short *list, uint32_t count,
                          uint32_t *head, LdsStack<BLOCK> stk, Counters &cnt) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -546,9 +589,13 @@ TRG_DEV void trace_queue(const SceneView &sc, const PoolView pv, const unsigned 
         if (__ballot(busy) == 0ull) break;
         if (busy) {
             for (;;) {
-                while (tv.node >= 0) trav_node_step<COUNT, BLOCK>(sc, tv, stk, cnt);
-                if (tv.node == kNodeDone) break;
-                trav_leaf_step<COUNT, BLOCK>(sc, tv, any, stk, cnt);
+                if (UNIFIED) {
+                    trav_step_unified<COUNT, BLOCK>(sc, tv, any, stk, cnt);
+                } else {
+                    while (tv.node >= 0) trav_node_step<COUNT, BLOCK>(sc, tv, stk, cnt);
+                    if (tv.node == kNodeDone) break;
+                    trav_leaf_step<COUNT, BLOCK>(sc, tv, any, stk, cnt);
+                }
                 if (tv.node == kNodeDone) break;
                 // enough lanes of this wavefront have run dry: let them refill (state stays in registers)
                 if (!exhausted && __popcll(__ballot(1)) <= 64 - kRefillMin) break;

@@ -51,8 +51,10 @@ TRG_DEV uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
+// minimum waves per SIMD the register allocator must leave room for (6 -> at most 80 VGPRs): +5 % on C2
+// over the unconstrained 91-VGPR / 5-wave build, a dozen cold values go to scratch
 #ifndef TRG_EXP_WAVES
-#define TRG_EXP_WAVES 1
+#define TRG_EXP_WAVES 6
 #endif
 template <bool LDS_SCENE, bool COUNT>
 __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES) void render_kernel(const trg::RenderParams p) {
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES) void render_kernel(cons
             if (active) {
                 if (b > 0) n_bounce++;
                 Hit h;
-                const bool found = traverse<false, COUNT, trg::kBlock>(sc, o, d, INFINITY, rmask, h, stk, cnt);
+                const bool found = traverse<false, COUNT, trg::kBlock, !LDS_SCENE>(sc, o, d, INFINITY, rmask, h, stk, cnt);
                 if (!found) {
                     active = false;  // Raytracing.metal:139-144
                 } else {
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES) void render_kernel(cons
                         if (smax >= 0.0f) {  // inactive shadow rays are not traced (MPS skips maxDistance < 0)
                             n_shadow++;
                             Hit sh;
-                            const bool occluded = traverse<true, COUNT, trg::kBlock>(sc, so, ls.dir, smax, 1u, sh, stk, cnt);
+                            const bool occluded = traverse<true, COUNT, trg::kBlock, !LDS_SCENE>(sc, so, ls.dir, smax, 1u, sh, stk, cnt);
                             if (!occluded) rad = rad + scol;  // Raytracing.metal:240-241
                         }
                         const V3 sd = sample_cosine_hemisphere(r[2], r[3]);
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(trg::kBlock) void render_pool_kernel(const trg::Ren
             const uint32_t n_cur = ctr[1 + cur];
             if (n_cur == 0u) break;  // workgroup-uniform: nothing left in flight
             // ---------------- TRACE ----------------
-            trace_queue<COUNT, trg::kBlock>(sc, pv, lists + cur * 2 * P, n_cur, &ctr[0], stk, cnt);
+            trace_queue<COUNT, trg::kBlock, !LDS_SCENE>(sc, pv, lists + cur * 2 * P, n_cur, &ctr[0], stk, cnt);
             __syncthreads();
             if (threadIdx.x == 0) { ctr[0] = 0u; ctr[1 + cur] = 0u; }  // head, and this list becomes the next "next"
             // ---------------- SHADE ----------------
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(trg::kBlock) void trace_kernel(const trg::TracePara
     Counters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.wnodes = 0; cnt.wtris = 0;
     Hit h; h.t = -1.0f; h.prim = -1; h.u = 0.0f; h.v = 0.0f;
     bool found = false;
-    if (r.maxDistance >= 0.0f) found = traverse<ANY, false, trg::kBlock>(sc, o, d, r.maxDistance, r.mask, h, stk, cnt);
+    if (r.maxDistance >= 0.0f) found = traverse<ANY, false, trg::kBlock, !LDS_SCENE>(sc, o, d, r.maxDistance, r.mask, h, stk, cnt);
     if (ANY) {
         reinterpret_cast<float *>(p.out)[i] = found ? h.t : -1.0f;
     } else {

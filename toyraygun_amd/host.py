@@ -13,7 +13,7 @@ from . import capi
 HOST_SO = os.path.join(capi.LIB_DIR, "libtoyraygun.so")
 _lib = None
 
-SYMBOL_NAMES = ["trh_scene_new", "trh_scene_cornell", "trh_scene_free", "trh_scene_add", "trh_scene_add_mesh",
+SYMBOL_NAMES = ["trh_scene_new", "trh_scene_cornell", "trh_scene_lattice", "trh_scene_free", "trh_scene_add", "trh_scene_add_mesh",
                 "trh_scene_counts", "trh_scene_copy", "trh_mtx_srt", "trh_mtx_inverse", "trh_uniforms",
                 "trh_random_texture", "trh_run_app"]
 
@@ -28,6 +28,8 @@ def load():
         P, F = C.c_void_p, C.c_void_p
         L.trh_scene_new.restype = P
         L.trh_scene_cornell.restype = P
+        L.trh_scene_lattice.restype = P
+        L.trh_scene_lattice.argtypes = [C.c_int, C.c_uint32]
         L.trh_scene_free.argtypes = [P]
         L.trh_scene_add.argtypes = [P, C.c_int, F, F]
         L.trh_scene_add_mesh.argtypes = [P, F, F, F, C.c_int, F, F, C.c_uint]
@@ -60,6 +62,11 @@ class Scene:
     @classmethod
     def cornell_box(cls):
         return cls(load().trh_scene_cornell())
+
+    @classmethod
+    def cornell_lattice(cls, n, seed=0x5EED0002):
+        """BASELINE config C4: Cornell box + n^3 replicated cubes (n = 44 -> 1,022,244 triangles)."""
+        return cls(load().trh_scene_lattice(int(n), seed))
 
     def __del__(self):
         try:
