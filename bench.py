@@ -74,9 +74,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
-    if distributed:
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ  # under torch.distributed.run (also with N = 1)
+    if distributed or launched:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
@@ -85,13 +87,14 @@ def main():
     from toyraygun_amd.dist import DistributedRenderer
 
     buffers, uniforms = cornell_buffers()
-    r = DistributedRenderer(W, H, local_rank)
+    r = DistributedRenderer(W, H, local_rank, pipelined=distributed or bool(os.environ.get("TRG_FORCE_GATHER")))
     r.load_scene(buffers)
     r.ctx.set_uniforms(uniforms)
     r.ctx.set_pixel_offsets_seed()
     dev = r.device
 
     def sync_all():
+        r.synchronize()
         torch.cuda.synchronize(dev)
         if distributed:
             dist.barrier()
@@ -106,19 +109,33 @@ def main():
     rays_per_launch = cst.rays
     r.ctx.set_option(capi.OPT_COUNTERS, 0)
 
+    gather = distributed or bool(os.environ.get("TRG_FORCE_GATHER"))
     for _ in range(args.warmup):
-        r.render(0, SPP, BOUNCES, gather=distributed)
+        r.render(0, SPP, BOUNCES, gather=gather)
     sync_all()
+    # average launch duration of the megakernel: HIP events on the stream it runs on (trg_render brackets the
+    # launch with hipEventRecord on the context's stream).  Single GPU: measured on every timed step.  Multi GPU:
+    # measured here on 3 extra launches, because the event wait is a host sync that would serialise the
+    # render/gather pipeline inside the timed region.
+    kernel_ms_pre = None
+    if gather:
+        r.ctx.reset_stats()
+        for _ in range(3):
+            r.ctx.render(0, SPP, BOUNCES, r.row0, r.rows)
+        pst = r.ctx.stats()
+        kernel_ms_pre = pst.total_render_ms / max(pst.renders, 1)
+        r.ctx.set_option(capi.OPT_TIMING, 0)
+        sync_all()
     r.ctx.reset_stats()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        r.render(0, SPP, BOUNCES, gather=distributed)
+        r.render(0, SPP, BOUNCES, gather=gather)
     sync_all()
     dt = time.perf_counter() - t0
     st = r.ctx.stats()
 
     rays_local = float(st.rays)
-    kernel_ms = st.total_render_ms / max(st.renders, 1)
+    kernel_ms = kernel_ms_pre if kernel_ms_pre is not None else st.total_render_ms / max(st.renders, 1)
     if distributed:
         t = torch.tensor([dt, rays_local, kernel_ms], dtype=torch.float64, device=dev)
         tmax = t.clone()
@@ -145,7 +162,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Cornell box (36 triangles) 1920x1080, 16 spp, 3 bounces (BASELINE configs[1])",
-                       "rays_per_step": rays_total / args.steps, "sharding": "row bands + RCCL all-gather" if distributed else "none",
+                       "rays_per_step": rays_total / args.steps, "sharding": "row bands + RCCL all-gather (double-buffered, gather k overlaps render k+1)" if distributed else "none",
                        "kernel": "render_kernel<LDS scene> (fast build)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel_ms": kernel_ms, "algorithmic_bytes_per_ray": bytes_per_ray,
@@ -156,7 +173,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(buffers)
         print(json.dumps(out), flush=True)
     r.close()
-    if distributed:
+    if distributed or launched:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -508,13 +508,23 @@ TRG_DEV void trav_step_unified(const SceneView &sc, Trav &tv, bool any, LdsStack
     }
 }
 
+// traversal schedules: 0 = while-while, 1 = unified (node + triangle every iteration).  (A third schedule,
+// one block kind per iteration chosen by a lane-count vote, measured no better on C4 and 9 % worse on C2.)
+#ifndef TRG_TRAV_LDS
+#define TRG_TRAV_LDS 0
+#endif
+#ifndef TRG_TRAV_HBM
+#define TRG_TRAV_HBM 1
+#endif
+
 // Nearest-hit (ANY=false) or any-hit (ANY=true) query for one ray per lane.
 template <bool ANY, bool COUNT, int BLOCK, bool UNIFIED = false>
 TRG_DEV bool traverse(const SceneView &sc, V3 o, V3 d, float tmax_ray, uint32_t rmask, Hit &hit, LdsStack<BLOCK> stk,
                       Counters &cnt) {
     Trav tv;
     trav_begin(tv, o, d, tmax_ray, rmask);
-    if (UNIFIED) {
+    constexpr int mode = UNIFIED ? TRG_TRAV_HBM : TRG_TRAV_LDS;
+    if (mode == 1) {
         while (tv.node != kNodeDone) trav_step_unified<COUNT, BLOCK>(sc, tv, ANY, stk, cnt);
     } else {
         for (;;) {
@@ -588,8 +598,9 @@ TRG_DEV void trace_queue(const SceneView &sc, const PoolView pv, const unsigned 
         }
         if (__ballot(busy) == 0ull) break;
         if (busy) {
+            constexpr int mode = UNIFIED ? TRG_TRAV_HBM : TRG_TRAV_LDS;
             for (;;) {
-                if (UNIFIED) {
+                if (mode == 1) {
                     trav_step_unified<COUNT, BLOCK>(sc, tv, any, stk, cnt);
                 } else {
                     while (tv.node >= 0) trav_node_step<COUNT, BLOCK>(sc, tv, stk, cnt);

@@ -5,7 +5,13 @@ Pixels are independent, so the frame is split into contiguous ROW BA
 full-frame device tensor; ONE all-gather at the end lands every band in place on every rank (disjoint
 pixels: no reduction, no change of floating-point summation order).  The reference has no multi-GPU
 code at all; this is new.
+
+Streams: the megakernel runs on a render stream, the collective on a communication stream, ordered by
+events.  With two frame buffers (`pipelined=True`) the gather of frame k overlaps the render of frame
+k+1 -- at 8 GPUs a band of C2 renders in ~0.45 ms, about as long as the 33 MB gather takes.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -19,7 +25,7 @@ def band_rows(height, world, rank):
 
 def gather_bands(full, world, rank, group=None):
     """All-gather the row bands of `full` ([h, w, 4] float32, this rank's band already filled) in place."""
-    if world == 1:
+    if world == 1 and not os.environ.get("TRG_FORCE_GATHER"):
         return full
     h = full.shape[0]
     bands = [band_rows(h, world, r) for r in range(world)]
@@ -43,7 +49,7 @@ def gather_bands(full, world, rank, group=None):
 class DistributedRenderer:
     """Row-band sharded renderer over an initialised process group (one rank per GPU)."""
 
-    def __init__(self, width, height, device_index, group=None):
+    def __init__(self, width, height, device_index, group=None, pipelined=False):
         from . import capi
         self.capi = capi
         self.group = group
@@ -53,27 +59,51 @@ class DistributedRenderer:
         self.device = torch.device("cuda", device_index)
         torch.cuda.set_device(self.device)
         self.ctx = capi.Context(width, height, device=device_index)
-        # torch owns the frame (so RCCL can see it); the kernel writes into it through trg_bind_accum
-        self.frame = torch.zeros((height, width, 4), dtype=torch.float32, device=self.device)
-        self.ctx.bind_accum(self.frame.data_ptr())
-        # one torch stream carries both the megakernel and the collective, so they are ordered
-        self.stream = torch.cuda.Stream(self.device)
-        self.ctx.set_stream(self.stream.cuda_stream)
+        # torch owns the frames (so RCCL can see them); the kernel writes into them through trg_bind_accum
+        self.frames = [torch.zeros((height, width, 4), dtype=torch.float32, device=self.device)
+                       for _ in range(2 if pipelined else 1)]
+        self.render_stream = torch.cuda.Stream(self.device)
+        self.comm_stream = torch.cuda.Stream(self.device) if pipelined else self.render_stream
+        self.ctx.set_stream(self.render_stream.cuda_stream)
+        self.ctx.bind_accum(self.frames[0].data_ptr())
         self.row0, self.rows = band_rows(height, self.world, self.rank)
+        self._step = 0
+        self._gathered = [None] * len(self.frames)  # event: last gather into frames[i] has finished
+        self.frame = self.frames[0]
+        self._needs_gather = self.world > 1 or bool(os.environ.get("TRG_FORCE_GATHER"))
 
     def load_scene(self, buffers):
         self.ctx.load_scene(buffers["positions"], buffers["normals"], buffers["colors"], buffers["indices"], buffers["material_ids"])
 
     def render(self, frame_begin, spp, bounces, gather=True):
-        """Render this rank's band; with gather=True every rank ends up with the whole frame."""
+        """Render this rank's band; with gather=True every rank ends up with the whole frame.
+        Returns the frame tensor the result lands in (valid after synchronize())."""
+        i = self._step % len(self.frames)
+        self._step += 1
+        frame = self.frames[i]
+        if len(self.frames) > 1:
+            self.ctx.bind_accum(frame.data_ptr())
+            if self._gathered[i] is not None:  # the previous gather into this buffer must be done
+                self.render_stream.wait_event(self._gathered[i])
         self.ctx.render(frame_begin, spp, bounces, self.row0, self.rows)
-        if gather and self.world > 1:
-            with torch.cuda.stream(self.stream):
-                gather_bands(self.frame, self.world, self.rank, self.group)
-        return self.frame
+        if gather and self._needs_gather:
+            if self.comm_stream is not self.render_stream:
+                done = torch.cuda.Event()
+                done.record(self.render_stream)
+                self.comm_stream.wait_event(done)
+            with torch.cuda.stream(self.comm_stream):
+                gather_bands(frame, self.world, self.rank, self.group)
+                if len(self.frames) > 1:
+                    ev = torch.cuda.Event()
+                    ev.record(self.comm_stream)
+                    self._gathered[i] = ev
+        self.frame = frame
+        return frame
 
     def synchronize(self):
-        self.stream.synchronize()
+        self.render_stream.synchronize()
+        self.comm_stream.synchronize()
 
     def close(self):
+        self.synchronize()
         self.ctx.close()
