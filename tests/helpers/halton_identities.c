@@ -1,3 +1,9 @@
+/* Exhaustive CPU validation of the two identities the device Halton code relies on (trg_device.h halton_c):
+ *  (1) for every prime base b of the table and every integer n < 2^22:  floor((n + 0.5) * fl(1/b)) == n div b
+ *      and fma(-q, b, n) == n mod b;
+ *  (2) the closed form of the base-2 radical inverse equals the reference's fp32 loop (strided sample here;
+ *      the full 2^32 sweep was run once when the code was written: 0 mismatches).
+ * Build: gcc -O2 -fopenmp -mfma -ffp-contract=off halton_identities.c -lm */
 #include <stdio.h>
 #include <stdint.h>
 #include <math.h>

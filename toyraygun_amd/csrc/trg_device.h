@@ -86,7 +86,9 @@ struct HaltonTab {
 //  * odd primes: ONE integer division splits i = hi * b^k1 + lo with lo, hi < 2^22; below 2^22 the digits
 //    come out of pure fp32 arithmetic -- q = floor((n + 0.5) * fl(1/b)) is exactly n div b there, and
 //    d = fma(q, -b, n) is exact -- six full-rate VALU instructions per digit, every constant a literal or
-//    an inline operand (no registers), instead of two quarter-rate integer multiplies.  The products
+//    an inline operand (no registers), instead of two quarter-rate integer multiplies.  (A fused
+//    fma(n, 1/b, 0.5/b) would save one instruction but needs two non-inline constants, which gfx950's
+//    one-slot constant bus only allows with a VGPR per base: that cost 60 registers.)  The products
 //    f_k * d and the sums r + t are never contracted.
 __host__ __device__ constexpr int halton_lo_digits(uint32_t b) {
     int k = 0;
@@ -157,6 +159,32 @@ TRG_DEV void halton4_c(uint32_t i, float r[4]) {
     r[1] = halton_c<2 + 4 * BNC + 1>(i);
     r[2] = halton_c<2 + 4 * BNC + 2>(i);
     r[3] = halton_c<2 + 4 * BNC + 3>(i);
+}
+// only the two light-sample dimensions 2 + 4*bounce + {0,1}: on the last bounce the continuation ray is never
+// traced, so its two dimensions (and the hemisphere sample built from them) are not evaluated at all
+template <int BNC>
+TRG_DEV void halton2_c(uint32_t i, float r[4]) {
+    r[0] = halton_c<2 + 4 * BNC + 0>(i);
+    r[1] = halton_c<2 + 4 * BNC + 1>(i);
+}
+TRG_DEV void halton2(uint32_t i, uint32_t bounce, float r[4]) {
+    switch (bounce) {
+    case 0: halton2_c<0>(i, r); break;
+    case 1: halton2_c<1>(i, r); break;
+    case 2: halton2_c<2>(i, r); break;
+    case 3: halton2_c<3>(i, r); break;
+    case 4: halton2_c<4>(i, r); break;
+    case 5: halton2_c<5>(i, r); break;
+    case 6: halton2_c<6>(i, r); break;
+    case 7: halton2_c<7>(i, r); break;
+    case 8: halton2_c<8>(i, r); break;
+    case 9: halton2_c<9>(i, r); break;
+    case 10: halton2_c<10>(i, r); break;
+    case 11: halton2_c<11>(i, r); break;
+    case 12: halton2_c<12>(i, r); break;
+    case 13: halton2_c<13>(i, r); break;
+    default: halton2_c<14>(i, r); break;
+    }
 }
 TRG_DEV void halton4(uint32_t i, uint32_t bounce, float r[4]) {
     switch (bounce) {

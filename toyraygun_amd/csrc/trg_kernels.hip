@@ -113,7 +113,9 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES) void render_kernel(cons
                         // dimensions) out of the bounce loop and keeping them live in VGPRs
                         uint32_t hi = hidx;
                         asm volatile("" : "+v"(hi));
-                        halton4(hi, b, r);
+                        const bool last = (b + 1u == p.bounces);  // wave-uniform
+                        r[2] = 0.0f; r[3] = 0.0f;
+                        if (last) halton2(hi, b, r); else halton4(hi, b, r);
                         const LightSample ls = sample_area_light(p.u, r[0], r[1], P, nrm);
                         thr = thr * vcol;
                         const V3 so = P + nrm * 1e-3f;
@@ -125,8 +127,10 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES) void render_kernel(cons
                             const bool occluded = traverse<true, COUNT, trg::kBlock, !LDS_SCENE>(sc, so, ls.dir, smax, 1u, sh, stk, cnt);
                             if (!occluded) rad = rad + scol;  // Raytracing.metal:240-241
                         }
-                        const V3 sd = sample_cosine_hemisphere(r[2], r[3]);
-                        d = align_hemisphere(sd, nrm);
+                        if (!last) {  // the reference also writes a continuation ray on the last bounce; nothing reads it
+                            const V3 sd = sample_cosine_hemisphere(r[2], r[3]);
+                            d = align_hemisphere(sd, nrm);
+                        }
                         o = so;
                         rmask = 1u;  // RAY_MASK_SECONDARY
                     } else if (mat == TRG_MATERIAL_EMISSIVE) {
@@ -276,14 +280,16 @@ __global__ __launch_bounds__(trg::kBlock) void render_pool_kernel(const trg::Ren
                             float r[4];
                             uint32_t hi = offset + f0 + j;
                             asm volatile("" : "+v"(hi));
-                            halton4(hi, b, r);
+                            const bool last = (b + 1u == p.bounces);  // workgroup-uniform
+                            r[2] = 0.0f; r[3] = 0.0f;
+                            if (last) halton2(hi, b, r); else halton4(hi, b, r);
                             const LightSample ls = sample_area_light(p.u, r[0], r[1], Pp, nrm);
                             thr[j] = thr[j] * vcol;
                             const V3 so = Pp + nrm * 1e-3f;
                             const float smax = ls.dist - 1e-3f;
                             scol[j] = ls.color * thr[j];
-                            const V3 sd = sample_cosine_hemisphere(r[2], r[3]);
-                            const V3 nd = align_hemisphere(sd, nrm);
+                            V3 nd = nrm;
+                            if (!last) nd = align_hemisphere(sample_cosine_hemisphere(r[2], r[3]), nrm);
                             v4f q0, q1, sh;
                             q0.x = so.x; q0.y = so.y; q0.z = so.z; q0.w = INFINITY;
                             q1.x = nd.x; q1.y = nd.y; q1.z = nd.z; q1.w = __int_as_float(1);  // RAY_MASK_SECONDARY
