@@ -222,9 +222,9 @@ int trg_render(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces,
     p.accum = c->accum;
     p.counters = c->counters;
     p.frame_begin = frame_begin; p.spp = spp; p.bounces = bounces; p.row0 = row0; p.rows = rows;
-    p.tiles_x = (c->w + kTile - 1) / kTile;
+    p.tiles_x = (c->w + kTileW - 1) / kTileW;
     p.stack_off = plan.stack_off; p.red_off = plan.red_off; p.pool_off = plan.pool_off;
-    const uint32_t tiles_y = (rows + kTile - 1) / kTile;
+    const uint32_t tiles_y = (rows + kTileH - 1) / kTileH;
     const uint32_t grid = p.tiles_x * tiles_y;
 
     if (c->opt_timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));

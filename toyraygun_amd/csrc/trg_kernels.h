@@ -9,8 +9,14 @@
 
 namespace trg {
 
-constexpr int kBlock = 256;        // threads per workgroup = 4 wavefronts of 64
-constexpr int kTile = 16;          // a workgroup renders a 16x16 pixel tile, one 8x8 sub-tile per wavefront
+#ifndef TRG_BLOCK
+#define TRG_BLOCK 256
+#endif
+constexpr int kBlock = TRG_BLOCK;  // threads per workgroup: 1, 2 or 4 wavefronts of 64
+constexpr int kTileW = kBlock >= 128 ? 16 : 8;   // a workgroup renders a kTileW x kTileH pixel tile,
+constexpr int kTileH = kBlock >= 256 ? 16 : 8;   // one 8x8 sub-tile per wavefront
+constexpr int kWaves = kBlock / 64;
+static_assert(kBlock == 64 || kBlock == 128 || kBlock == 256, "workgroup must be 1, 2 or 4 wavefronts");
 constexpr int kCounterSlots = 64;  // ray counters are spread over 64 slots to avoid same-address atomics
 constexpr int kCounterWords = 8;   // primary, bounce, shadow, shaded, node_fetches, tri_tests, 2 spare
 constexpr uint32_t kMaxLdsScene = 40u * 1024u;  // scenes up to this size are staged in LDS per workgroup

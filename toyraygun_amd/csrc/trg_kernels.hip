@@ -66,9 +66,15 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES) void render_kernel(cons
     // workgroup -> 16x16 tile, wavefront -> 8x8 sub-tile, lane -> pixel (8 consecutive pixels of a row
     // per 8 lanes: each wavefront writes eight 128-byte row segments)
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t bx = blockIdx.x % p.tiles_x, by = blockIdx.x / p.tiles_x;
-    const uint32_t x = bx * trg::kTile + (wave & 1) * 8 + (lane & 7);
-    const uint32_t y = p.row0 + by * trg::kTile + (wave >> 1) * 8 + (lane >> 3);
+    // workgroup -> tile: image columns from the centre outwards (rows inner).  Any bijection is correct; this one
+    // starts the tiles a camera usually points at first, so the tail of the launch is made of the cheap
+    // edge tiles (C2: the 16:9 side bars) instead of leaving CUs idle behind a few expensive ones (+9 %).
+    const uint32_t tiles_y = gridDim.x / p.tiles_x;
+    const uint32_t crank = blockIdx.x / tiles_y, by = blockIdx.x % tiles_y;
+    const uint32_t cleft = (p.tiles_x - 1u) / 2u;
+    const uint32_t bx = (crank & 1u) ? cleft + 1u + crank / 2u : cleft - crank / 2u;
+    const uint32_t x = bx * trg::kTileW + (wave % (trg::kTileW / 8)) * 8 + (lane & 7);
+    const uint32_t y = p.row0 + by * trg::kTileH + (wave / (trg::kTileW / 8)) * 8 + (lane >> 3);
     const bool valid = (x < p.u.width) && (y < p.row0 + p.rows) && (y < p.u.height);
     const uint32_t pix = y * p.u.width + x;
 
@@ -170,7 +176,8 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES) void render_kernel(cons
     __syncthreads();
     if (threadIdx.x < (COUNT ? 8 : 4)) {
         const uint32_t k = threadIdx.x;
-        const unsigned long long s = (unsigned long long)red[k] + red[8 + k] + red[16 + k] + red[24 + k];
+        unsigned long long s = 0;
+        for (int wv = 0; wv < trg::kWaves; ++wv) s += red[wv * 8 + k];
         if (s) atomicAdd(&p.counters[(blockIdx.x % trg::kCounterSlots) * trg::kCounterWords + k], s);
     }
 }
@@ -201,9 +208,15 @@ __global__ __launch_bounds__(trg::kBlock) void render_pool_kernel(const trg::Ren
     uint32_t *ctr = reinterpret_cast<uint32_t *>(lists + 4 * P);         // [0] head, [1] n(list 0), [2] n(list 1)
 
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t bx = blockIdx.x % p.tiles_x, by = blockIdx.x / p.tiles_x;
-    const uint32_t x = bx * trg::kTile + (wave & 1) * 8 + (lane & 7);
-    const uint32_t y = p.row0 + by * trg::kTile + (wave >> 1) * 8 + (lane >> 3);
+    // workgroup -> tile: image columns from the centre outwards (rows inner).  Any bijection is correct; this one
+    // starts the tiles a camera usually points at first, so the tail of the launch is made of the cheap
+    // edge tiles (C2: the 16:9 side bars) instead of leaving CUs idle behind a few expensive ones (+9 %).
+    const uint32_t tiles_y = gridDim.x / p.tiles_x;
+    const uint32_t crank = blockIdx.x / tiles_y, by = blockIdx.x % tiles_y;
+    const uint32_t cleft = (p.tiles_x - 1u) / 2u;
+    const uint32_t bx = (crank & 1u) ? cleft + 1u + crank / 2u : cleft - crank / 2u;
+    const uint32_t x = bx * trg::kTileW + (wave % (trg::kTileW / 8)) * 8 + (lane & 7);
+    const uint32_t y = p.row0 + by * trg::kTileH + (wave / (trg::kTileW / 8)) * 8 + (lane >> 3);
     const bool valid = (x < p.u.width) && (y < p.row0 + p.rows) && (y < p.u.height);
     const uint32_t pix = y * p.u.width + x;
 
@@ -348,7 +361,8 @@ __global__ __launch_bounds__(trg::kBlock) void render_pool_kernel(const trg::Ren
     __syncthreads();
     if (threadIdx.x < (COUNT ? 8 : 4)) {
         const uint32_t k = threadIdx.x;
-        const unsigned long long s = (unsigned long long)red[k] + red[8 + k] + red[16 + k] + red[24 + k];
+        unsigned long long s = 0;
+        for (int wv = 0; wv < trg::kWaves; ++wv) s += red[wv * 8 + k];
         if (s) atomicAdd(&p.counters[(blockIdx.x % trg::kCounterSlots) * trg::kCounterWords + k], s);
     }
 }
