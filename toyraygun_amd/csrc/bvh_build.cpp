@@ -210,6 +210,77 @@ void build_bvh(const float *pos, const uint32_t *idx, const uint32_t *masks, uin
         }
     }
 
+    // ---- 4-wide collapse (used for scenes that stay in HBM): each BVH2 inner node pulls up grandchildren,
+    //      largest surface area first, until it has four children.  Same leaves, same triangle records. ----
+    constexpr int32_t kEmpty = (int32_t)0x80000000;
+    struct Wide { int32_t child[4]; Box box[4]; };
+    std::vector<Wide> wide;
+    uint32_t wdepth = 0;
+    if (synth_root) {
+        Wide w;
+        for (int k = 0; k < 4; ++k) { w.child[k] = kEmpty; w.box[k] = Box(); }
+        // reuse the two leaf references the BVH2 root got
+        const F4 *n = &out.nodes[0];
+        for (int k = 0; k < 2; ++k) {
+            uint32_t bits; std::memcpy(&bits, k == 0 ? &n[3].x : &n[3].y, 4);
+            w.child[k] = (int32_t)bits;
+        }
+        w.box[0].lo[0] = n[0].x; w.box[0].hi[0] = n[0].y; w.box[0].lo[1] = n[0].z; w.box[0].hi[1] = n[0].w; w.box[0].lo[2] = n[2].x; w.box[0].hi[2] = n[2].y;
+        w.box[1].lo[0] = n[1].x; w.box[1].hi[0] = n[1].y; w.box[1].lo[1] = n[1].z; w.box[1].hi[1] = n[1].w; w.box[1].lo[2] = n[2].z; w.box[1].hi[2] = n[2].w;
+        wide.push_back(w);
+        wdepth = 1;
+    } else {
+        // iterative DFS; a work item = (build node, wide index it was assigned, depth)
+        struct Item { int32_t bn; uint32_t wi; uint32_t d; };
+        std::vector<Item> st;
+        wide.emplace_back();
+        st.push_back({ root, 0u, 1u });
+        while (!st.empty()) {
+            const Item it = st.back(); st.pop_back();
+            wdepth = std::max(wdepth, it.d);
+            int32_t ch[4]; int nch = 2;
+            ch[0] = B.nodes[it.bn].child[0]; ch[1] = B.nodes[it.bn].child[1];
+            while (nch < 4) {
+                int best = -1; float best_area = -1.f;
+                for (int k = 0; k < nch; ++k)
+                    if (!B.nodes[ch[k]].leaf) { const float a = B.nodes[ch[k]].box.half_area(); if (a > best_area) { best_area = a; best = k; } }
+                if (best < 0) break;
+                const int32_t open = ch[best];
+                ch[best] = B.nodes[open].child[0];
+                ch[nch++] = B.nodes[open].child[1];
+            }
+            Wide w;
+            for (int k = 0; k < 4; ++k) { w.child[k] = kEmpty; w.box[k] = Box(); }
+            for (int k = 0; k < nch; ++k) {
+                const BuildNode &c = B.nodes[ch[k]];
+                w.box[k] = padded(c.box);
+                if (c.leaf) {
+                    w.child[k] = leaf_ref(c.first, c.count);
+                } else {
+                    w.child[k] = (int32_t)wide.size();
+                    wide.emplace_back();
+                    st.push_back({ ch[k], (uint32_t)w.child[k], it.d + 1 });
+                }
+            }
+            wide[it.wi] = w;
+        }
+    }
+    out.n_nodes4 = (uint32_t)wide.size();
+    out.depth4 = wdepth;
+    out.nodes4.assign((size_t)out.n_nodes4 * 8, F4{ 0, 0, 0, 0 });
+    for (size_t i = 0; i < wide.size(); ++i) {
+        const Wide &w = wide[i];
+        F4 *n = &out.nodes4[i * 8];
+        float v[6][4];
+        for (int k = 0; k < 4; ++k) {
+            const bool e = w.child[k] == kEmpty;
+            for (int a = 0; a < 3; ++a) { v[a * 2][k] = e ? 0.f : w.box[k].lo[a]; v[a * 2 + 1][k] = e ? 0.f : w.box[k].hi[a]; }
+        }
+        for (int r = 0; r < 6; ++r) n[r] = F4{ v[r][0], v[r][1], v[r][2], v[r][3] };
+        n[6] = F4{ bits_f((uint32_t)w.child[0]), bits_f((uint32_t)w.child[1]), bits_f((uint32_t)w.child[2]), bits_f((uint32_t)w.child[3]) };
+        n[7] = F4{ 0.f, 0.f, 0.f, 0.f };
+    }
+
     // SAH cost (reporting only)
     double cost = 0.0;
     if (!synth_root) {

@@ -21,10 +21,15 @@ struct F4 { float x, y, z, w; };
 //  every node has two children; the root is always an inner node (bvh_build.cpp synthesises one).
 //  triangle record k (leaf order) = 3 x float4 (48 B):
 //    t[0] = (v0.xyz, bits primitiveIndex)  t[1] = (e1.xyz, bits mask)  t[2] = (e2.xyz, 0)
+//  wide node i (scenes kept in HBM) = 8 x float4 (128 B, one cache line), four children, SoA:
+//    w[0..5] = lo.x[4], hi.x[4], lo.y[4], hi.y[4], lo.z[4], hi.z[4]   w[6] = (bits child0..3)   w[7] = padding
+//    child encoding as above; an unused slot holds 0x80000000 and is never entered.
 struct Bvh {
-    std::vector<F4> nodes;  // 4 per node
-    std::vector<F4> tris;   // 3 per triangle
+    std::vector<F4> nodes;   // 4 per node (BVH2)
+    std::vector<F4> nodes4;  // 8 per node (BVH4 collapse of the same tree)
+    std::vector<F4> tris;    // 3 per triangle
     uint32_t n_nodes = 0, n_leaves = 0, depth = 0, max_leaf = 0;
+    uint32_t n_nodes4 = 0, depth4 = 0;
     double sah_cost = 0.0;
 };
 

@@ -25,6 +25,9 @@ struct trg_ctx {
     uint32_t *offsets = nullptr;
     unsigned long long *counters = nullptr;
     unsigned char *blob = nullptr;
+    int *stack_scratch = nullptr;      // global overflow levels of the traversal stacks (grow-only)
+    size_t stack_scratch_bytes = 0;
+    uint32_t bvh_depth4 = 0, bvh_nodes4 = 0;
     SceneDesc sc{};
     bool scene_loaded = false, have_uniforms = false, have_offsets = false;
     trg_uniforms u{};
@@ -55,12 +58,22 @@ static int fail(trg_ctx *c, int code, const char *fmt, ...) {
 
 static inline uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
 
-struct LdsPlan { bool lds_scene; uint32_t stack_off, red_off, pool_off, total; };
+constexpr uint32_t kStackLdsLevels = 16;  // HBM scenes: stack levels kept in LDS (deeper ones spill to global scratch)
+
+struct LdsPlan { bool lds_scene; uint32_t stack_off, red_off, pool_off, total, klds, overflow_levels; };
 static int plan_lds(trg_ctx *c, LdsPlan &p, bool pool = false) {
-    const uint32_t levels = c->bvh_depth + 2;
-    p.lds_scene = !c->opt_force_global && c->sc.blob_bytes <= kMaxLdsScene;
-    p.stack_off = p.lds_scene ? align16(c->sc.blob_bytes) : 0u;
-    p.red_off = p.stack_off + levels * kBlock * 4u;
+    p.lds_scene = !c->opt_force_global && c->sc.lds_stage_bytes != 0 && c->sc.lds_stage_bytes <= kMaxLdsScene;
+    uint32_t levels;
+    if (p.lds_scene) {
+        levels = c->bvh_depth + 2;      // BVH2, near child first: at most one pending entry per level
+        p.klds = levels;
+    } else {
+        levels = kWideHbm ? 3 * c->bvh_depth4 + 2 : c->bvh_depth + 2;  // 4-wide: up to three pending entries per level
+        p.klds = std::min(levels, kStackLdsLevels);
+    }
+    p.overflow_levels = levels - p.klds;
+    p.stack_off = p.lds_scene ? align16(c->sc.lds_stage_bytes) : 0u;
+    p.red_off = p.stack_off + p.klds * kBlock * 4u;
     p.pool_off = align16(p.red_off + 4u * 8u * 4u);
     p.total = p.pool_off;
     if (pool) {
@@ -70,6 +83,22 @@ static int plan_lds(trg_ctx *c, LdsPlan &p, bool pool = false) {
     const uint32_t limit = pool ? 160u * 1024u : 64u * 1024u;
     if (p.total > limit)
         return fail(c, TRG_ERR_RANGE, "BVH depth %u needs %u B of LDS per workgroup (limit %u)", c->bvh_depth, p.total, limit);
+    return TRG_OK;
+}
+
+// global scratch for the stack levels that do not fit in LDS: overflow_levels x grid_threads ints
+static int ensure_stack_scratch(trg_ctx *c, const LdsPlan &plan, uint64_t grid_threads, StackDesc &out) {
+    out.klds = plan.klds;
+    out.overflow = nullptr;
+    if (plan.overflow_levels == 0) return TRG_OK;
+    const size_t need = (size_t)plan.overflow_levels * grid_threads * sizeof(int);
+    if (need > c->stack_scratch_bytes) {
+        if (c->stack_scratch) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->stack_scratch); c->stack_scratch = nullptr; c->stack_scratch_bytes = 0; }
+        hipError_t e = hipMalloc((void **)&c->stack_scratch, need);
+        if (e != hipSuccess) return fail(c, TRG_ERR_NOMEM, "stack scratch hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+        c->stack_scratch_bytes = need;
+    }
+    out.overflow = c->stack_scratch;
     return TRG_OK;
 }
 
@@ -118,6 +147,7 @@ void trg_destroy(trg_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     if (c->blob) (void)hipFree(c->blob);
+    if (c->stack_scratch) (void)hipFree(c->stack_scratch);
     if (c->counters) (void)hipFree(c->counters);
     if (c->offsets) (void)hipFree(c->offsets);
     if (c->accum_own) (void)hipFree(c->accum_own);
@@ -143,24 +173,38 @@ int trg_load_scene(trg_ctx *c, const float *pos, const float *nrm, const float *
     // normals and colours are read as attributes[triangle*3 + j], NOT through the index buffer
     // (Raytracing.metal:104-108), so they are copied as they are.
     const uint32_t nt_rec = (uint32_t)(bvh.tris.size() / 3);
+    const uint32_t attr_tris = std::max(n_tris, 1u);
+    // [ BVH2 nodes | triangle records | normals | colours | material ids ] [ 4-wide nodes | 128 B pad ]
+    // The first bracket is what a workgroup stages into LDS when it is small enough; scenes that can only be
+    // traversed from HBM skip the BVH2 nodes when the HBM kernels use the 4-wide tree.
+    const uint64_t small_bytes = (uint64_t)bvh.n_nodes * 64u + (uint64_t)nt_rec * 48u + (uint64_t)attr_tris * 76u + 64u;
+    const bool lds_candidate = small_bytes <= kMaxLdsScene;
+    const bool keep_bvh2 = lds_candidate || !kWideHbm;
     SceneDesc sc{};
-    sc.n_nodes = bvh.n_nodes; sc.n_tris = n_tris;
+    sc.n_nodes = keep_bvh2 ? bvh.n_nodes : 0u; sc.n_tris = n_tris;
     sc.off_nodes = 0;
-    sc.off_tris = align16(sc.off_nodes + bvh.n_nodes * 64u);
+    sc.off_tris = align16(sc.off_nodes + sc.n_nodes * 64u);
     sc.off_normals = align16(sc.off_tris + nt_rec * 48u);
-    sc.off_colors = align16(sc.off_normals + std::max(n_tris, 1u) * 36u);
-    sc.off_mats = align16(sc.off_colors + std::max(n_tris, 1u) * 36u);
-    sc.blob_bytes = align16(sc.off_mats + std::max(n_tris, 1u) * 4u);
+    sc.off_colors = align16(sc.off_normals + attr_tris * 36u);
+    sc.off_mats = align16(sc.off_colors + attr_tris * 36u);
+    sc.off_nodes4 = align16(sc.off_mats + attr_tris * 4u);
+    sc.off_nodes4 = (sc.off_nodes4 + 127u) & ~127u;  // 128-byte nodes on 128-byte lines
+    sc.n_nodes4 = kWideHbm ? bvh.n_nodes4 : 0u;
+    sc.lds_stage_bytes = lds_candidate ? align16(sc.off_mats + attr_tris * 4u) : 0u;
+    const uint64_t total = (uint64_t)sc.off_nodes4 + (uint64_t)sc.n_nodes4 * 128u + 128u;
+    if (total > 0xFFFFFFF0ull) return fail(c, TRG_ERR_RANGE, "trg_load_scene: scene needs %llu B on the device (limit 4 GiB)", (unsigned long long)total);
+    sc.blob_bytes = (uint32_t)total;
     std::vector<unsigned char> host(sc.blob_bytes, 0);
-    memcpy(&host[sc.off_nodes], bvh.nodes.data(), bvh.nodes.size() * sizeof(F4));
+    if (sc.n_nodes) memcpy(&host[sc.off_nodes], bvh.nodes.data(), (size_t)sc.n_nodes * 64u);
     memcpy(&host[sc.off_tris], bvh.tris.data(), bvh.tris.size() * sizeof(F4));
     float *hn = reinterpret_cast<float *>(&host[sc.off_normals]);
     float *hc = reinterpret_cast<float *>(&host[sc.off_colors]);
     if (n_tris) {
         memcpy(hn, nrm, (size_t)n_tris * 36);
         memcpy(hc, col, (size_t)n_tris * 36);
+        memcpy(&host[sc.off_mats], mat, (size_t)n_tris * 4);
     }
-    if (n_tris) memcpy(&host[sc.off_mats], mat, (size_t)n_tris * 4);
+    if (sc.n_nodes4) memcpy(&host[sc.off_nodes4], bvh.nodes4.data(), (size_t)sc.n_nodes4 * 128u);
 
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->blob) { (void)hipFree(c->blob); c->blob = nullptr; c->scene_loaded = false; }
@@ -170,6 +214,7 @@ int trg_load_scene(trg_ctx *c, const float *pos, const float *nrm, const float *
     sc.blob = c->blob;
     c->sc = sc;
     c->bvh_nodes = bvh.n_nodes; c->bvh_depth = bvh.depth; c->bvh_leaves = bvh.n_leaves;
+    c->bvh_nodes4 = bvh.n_nodes4; c->bvh_depth4 = bvh.depth4;
     c->scene_loaded = true;
     LdsPlan plan;
     return plan_lds(c, plan, c->opt_kernel == TRG_KERNEL_POOL);
@@ -226,6 +271,7 @@ int trg_render(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces,
     p.stack_off = plan.stack_off; p.red_off = plan.red_off; p.pool_off = plan.pool_off;
     const uint32_t tiles_y = (rows + kTileH - 1) / kTileH;
     const uint32_t grid = p.tiles_x * tiles_y;
+    if (int rc = ensure_stack_scratch(c, plan, (uint64_t)grid * kBlock, p.stack)) return rc;
 
     if (c->opt_timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     hipError_t e;
@@ -380,6 +426,7 @@ int trg_trace(trg_ctx *c, const trg_ray *rays, size_t n, int any_hit, void *out)
     HIPCHK(c, hipMemcpyAsync(dr.p, rays, n * sizeof(trg_ray), hipMemcpyHostToDevice, c->stream));
     TraceParams p{};
     p.sc = c->sc; p.rays = static_cast<const trg_ray *>(dr.p); p.out = dout.p; p.n = (uint32_t)n; p.stack_off = plan.stack_off;
+    if (int rc = ensure_stack_scratch(c, plan, (uint64_t)((n + kBlock - 1) / kBlock) * kBlock, p.stack)) return rc;
     hipError_t e = c->opt_strict ? launch_trace_strict(p, plan.lds_scene, any_hit != 0, plan.total, c->stream)
                                  : launch_trace_fast(p, plan.lds_scene, any_hit != 0, plan.total, c->stream);
     if (e != hipSuccess) return fail(c, TRG_ERR_DEVICE, "trg_trace: launch failed: %s", hipGetErrorString(e));

@@ -391,12 +391,25 @@ TRG_DEV bool tri_test(const v4f a, const v4f b, const v4f c, V3 o, V3 d, float t
     return (u >= 0.0f) && (v >= 0.0f) && ((u + v) <= 1.0f) && (t >= 0.0f) && (t <= tmax_ray);
 }
 
-// Per-lane stack in LDS, laid out [level][thread] so lane i always hits bank i%32 (no conflicts).
-template <int BLOCK>
-struct LdsStack {
-    int *base;  // already offset by the thread index
-    TRG_DEV void push(int sp, int v) { base[sp * BLOCK] = v; }
-    TRG_DEV int pop(int sp) { return base[sp * BLOCK]; }
+// Per-lane traversal stack, laid out [level][thread] so lane i always hits LDS bank i%32 (no conflicts).
+// Scenes staged in LDS have shallow trees and keep the whole stack in LDS (klds = all levels).  Scenes in
+// HBM keep the first klds levels in LDS and spill deeper levels to a per-thread column of a global scratch
+// buffer: the 4-wide tree can need 3 x depth entries in the worst case, typical rays need about a dozen,
+// and LDS spent on never-used levels is occupancy lost.
+template <int BLOCK, bool OVERFLOW = false>
+struct LdsStackT {
+    int *base;         // LDS, already offset by the thread index
+    int *gbase;        // global overflow column of this thread (nullptr when unused)
+    uint32_t gstride;  // elements between consecutive overflow levels
+    int klds;          // levels held in LDS
+    TRG_DEV void push(int sp, int v) {
+        if (!OVERFLOW || sp < klds) base[sp * BLOCK] = v;
+        else gbase[(size_t)(sp - klds) * gstride] = v;
+    }
+    TRG_DEV int pop(int sp) {
+        if (!OVERFLOW || sp < klds) return base[sp * BLOCK];
+        return gbase[(size_t)(sp - klds) * gstride];
+    }
 };
 
 constexpr int kNodeDone = (int)0x80000000;  // "traversal finished" marker in the node register (never a valid leaf code)
@@ -435,8 +448,8 @@ TRG_DEV void trav_begin(Trav &tv, V3 o, V3 d, float tmax, uint32_t rmask) {
 // One inner-node step: test both child boxes, descend into the nearer hit child, push the other, or pop.
 // Written with selects and two predicated LDS stack accesses instead of a four-way branch: the branchy
 // form spent more scalar instructions on exec-mask bookkeeping than vector instructions on the boxes.
-template <bool COUNT, int BLOCK>
-TRG_DEV void trav_node_math(const v4f n0, const v4f n1, const v4f n2, const v4f n3, Trav &tv, LdsStack<BLOCK> stk, Counters &cnt) {
+template <bool COUNT, int BLOCK, typename STK>
+TRG_DEV void trav_node_math(const v4f n0, const v4f n1, const v4f n2, const v4f n3, Trav &tv, STK stk, Counters &cnt) {
     if (COUNT) { cnt.nodes++; if (mbcnt64(__ballot(1)) == 0) cnt.wnodes++; }
     // slab tests; (b - o) * inv written as b*inv - o*inv so the fast build gets one fma each.
     // Boxes are padded by 2e-5 x scene extent on the host, far more than the rounding of these
@@ -465,8 +478,8 @@ TRG_DEV void trav_node_math(const v4f n0, const v4f n1, const v4f n2, const v4f 
     tv.node = next; tv.sp = sp;
 }
 
-template <bool COUNT, int BLOCK>
-TRG_DEV void trav_node_step(const SceneView &sc, Trav &tv, LdsStack<BLOCK> stk, Counters &cnt) {
+template <bool COUNT, int BLOCK, typename STK>
+TRG_DEV void trav_node_step(const SceneView &sc, Trav &tv, STK stk, Counters &cnt) {
     const v4f *n = sc.nodes + tv.node * 4;
     const v4f n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
     trav_node_math<COUNT, BLOCK>(n0, n1, n2, n3, tv, stk, cnt);
@@ -491,8 +504,8 @@ TRG_DEV bool trav_tri_math(const v4f a, const v4f b, const v4f c, Trav &tv, bool
 }
 
 // One leaf: test its 1..8 triangles.  ~node = (first << 3) | (count - 1).  Returns with tv.node = next node or kNodeDone.
-template <bool COUNT, int BLOCK>
-TRG_DEV void trav_leaf_step(const SceneView &sc, Trav &tv, bool any, LdsStack<BLOCK> stk, Counters &cnt) {
+template <bool COUNT, int BLOCK, typename STK>
+TRG_DEV void trav_leaf_step(const SceneView &sc, Trav &tv, bool any, STK stk, Counters &cnt) {
     const uint32_t code = (uint32_t)~tv.node;
     const uint32_t first = code >> 3, count = (code & 7u) + 1u;
     bool stop = false;
@@ -508,14 +521,89 @@ TRG_DEV void trav_leaf_step(const SceneView &sc, Trav &tv, bool any, LdsStack<BL
     tv.sp = sp;
 }
 
+// ---- 4-wide nodes (scenes in HBM): 128-byte node, four child boxes in SoA form (bvh_build.h) ----
+#define TRG_CSWAP(ta, ca, tb, cb)                         \
+    {                                                     \
+        const bool sw_ = (tb) < (ta);                     \
+        const float tt_ = sw_ ? (tb) : (ta);              \
+        (tb) = sw_ ? (ta) : (tb);                         \
+        (ta) = tt_;                                       \
+        const int cc_ = sw_ ? (cb) : (ca);                \
+        (cb) = sw_ ? (ca) : (cb);                         \
+        (ca) = cc_;                                       \
+    }
+
+TRG_DEV float box_entry(float lx, float hx, float ly, float hy, float lz, float hz, const Trav &tv, int child) {
+    const float x0 = lx * tv.idx - tv.oix, x1 = hx * tv.idx - tv.oix;
+    const float y0 = ly * tv.idy - tv.oiy, y1 = hy * tv.idy - tv.oiy;
+    const float z0 = lz * tv.idz - tv.oiz, z1 = hz * tv.idz - tv.oiz;
+    const float tmin = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
+    const float tmax = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tv.best));
+    return (tmin <= tmax && child != kNodeDone) ? tmin : INFINITY;  // +inf = not entered (miss or unused slot)
+}
+
+template <bool COUNT, int BLOCK, typename STK>
+TRG_DEV void trav_node4_math(const v4f lox, const v4f hix, const v4f loy, const v4f hiy, const v4f loz, const v4f hiz,
+                             const v4f ch, Trav &tv, STK stk, Counters &cnt) {
+    if (COUNT) { cnt.nodes += 2; if (mbcnt64(__ballot(1)) == 0) cnt.wnodes++; }  // 4 boxes = 2 BVH2-equivalent fetches
+    int c0 = __float_as_int(ch.x), c1 = __float_as_int(ch.y), c2 = __float_as_int(ch.z), c3 = __float_as_int(ch.w);
+    float t0 = box_entry(lox.x, hix.x, loy.x, hiy.x, loz.x, hiz.x, tv, c0);
+    float t1 = box_entry(lox.y, hix.y, loy.y, hiy.y, loz.y, hiz.y, tv, c1);
+    float t2 = box_entry(lox.z, hix.z, loy.z, hiy.z, loz.z, hiz.z, tv, c2);
+    float t3 = box_entry(lox.w, hix.w, loy.w, hiy.w, loz.w, hiz.w, tv, c3);
+    const int n_hit = (t0 < INFINITY ? 1 : 0) + (t1 < INFINITY ? 1 : 0) + (t2 < INFINITY ? 1 : 0) + (t3 < INFINITY ? 1 : 0);
+    // sort the four (entry distance, child) pairs, nearest first (5-comparator network); misses sink to the end
+    TRG_CSWAP(t0, c0, t1, c1) TRG_CSWAP(t2, c2, t3, c3) TRG_CSWAP(t0, c0, t2, c2) TRG_CSWAP(t1, c1, t3, c3) TRG_CSWAP(t1, c1, t2, c2)
+    int sp = tv.sp;
+    if (n_hit >= 4) stk.push(sp, c3);
+    sp += n_hit >= 4 ? 1 : 0;
+    if (n_hit >= 3) stk.push(sp, c2);
+    sp += n_hit >= 3 ? 1 : 0;
+    if (n_hit >= 2) stk.push(sp, c1);
+    sp += n_hit >= 2 ? 1 : 0;
+    int next = c0;
+    if (n_hit == 0) {
+        const bool empty = sp == 0;
+        sp -= empty ? 0 : 1;
+        const int popped = stk.pop(sp);
+        next = empty ? kNodeDone : popped;
+    }
+    tv.node = next; tv.sp = sp;
+}
+
+// one unit of work per lane per iteration on the 4-wide tree: a node (eight 16-byte loads = one 128-byte line)
+// or one triangle of the current leaf (the same eight loads, three of them used)
+template <bool COUNT, int BLOCK, typename STK>
+TRG_DEV void trav_step_wide(const SceneView &sc, Trav &tv, bool any, STK stk, Counters &cnt) {
+    const bool inner = tv.node >= 0;
+    const uint32_t code = (uint32_t)~tv.node;
+    const uint32_t first = code >> 3, left = code & 7u;
+    const v4f *ptr = inner ? sc.nodes + (size_t)tv.node * 8 : sc.tris + (size_t)first * 3;
+    const v4f q0 = ptr[0], q1 = ptr[1], q2 = ptr[2];
+    if (inner) {
+        const v4f q3 = ptr[3], q4 = ptr[4], q5 = ptr[5], q6 = ptr[6];
+        trav_node4_math<COUNT, BLOCK>(q0, q1, q2, q3, q4, q5, q6, tv, stk, cnt);
+    } else {
+        const bool stop = trav_tri_math<COUNT>(q0, q1, q2, tv, any, cnt);
+        const bool more = left != 0u;
+        const bool empty = tv.sp == 0;
+        const bool do_pop = !stop && !more && !empty;
+        const int sp = tv.sp - (do_pop ? 1 : 0);
+        const int popped = stk.pop(sp);
+        const int advanced = ~(int)(((first + 1u) << 3) | (left - 1u));
+        tv.node = stop ? kNodeDone : (more ? advanced : (empty ? kNodeDone : popped));
+        tv.sp = sp;
+    }
+}
+
 // Unified step for scenes that live in HBM: every lane does ONE unit of work per iteration -- an inner node
 // (two boxes) or one triangle of its current leaf -- off a single group of four 16-byte loads, so there is
 // one memory round trip per iteration for the whole wavefront and no lane waits for lanes of the other
 // kind (the while-while form above serialises node and leaf phases; it is kept for LDS-resident scenes,
 // where instructions, not latency, are the cost).  A leaf is consumed by advancing its own code:
 // ~node = (first << 3) | (remaining - 1).
-template <bool COUNT, int BLOCK>
-TRG_DEV void trav_step_unified(const SceneView &sc, Trav &tv, bool any, LdsStack<BLOCK> stk, Counters &cnt) {
+template <bool COUNT, int BLOCK, typename STK>
+TRG_DEV void trav_step_unified(const SceneView &sc, Trav &tv, bool any, STK stk, Counters &cnt) {
     const bool inner = tv.node >= 0;
     const uint32_t code = (uint32_t)~tv.node;
     const uint32_t first = code >> 3, left = code & 7u;
@@ -536,23 +624,26 @@ TRG_DEV void trav_step_unified(const SceneView &sc, Trav &tv, bool any, LdsStack
     }
 }
 
-// traversal schedules: 0 = while-while, 1 = unified (node + triangle every iteration).  (A third schedule,
+// traversal schedules: 0 = while-while on BVH2, 1 = unified step on BVH2 (node + triangle every iteration),
+// 3 = unified step on the 4-wide tree (the host uploads 4-wide nodes for HBM scenes when TRG_TRAV_HBM == 3).  (A third schedule,
 // one block kind per iteration chosen by a lane-count vote, measured no better on C4 and 9 % worse on C2.)
 #ifndef TRG_TRAV_LDS
 #define TRG_TRAV_LDS 0
 #endif
 #ifndef TRG_TRAV_HBM
-#define TRG_TRAV_HBM 1
+#define TRG_TRAV_HBM 3
 #endif
 
 // Nearest-hit (ANY=false) or any-hit (ANY=true) query for one ray per lane.
-template <bool ANY, bool COUNT, int BLOCK, bool UNIFIED = false>
-TRG_DEV bool traverse(const SceneView &sc, V3 o, V3 d, float tmax_ray, uint32_t rmask, Hit &hit, LdsStack<BLOCK> stk,
+template <bool ANY, bool COUNT, int BLOCK, bool UNIFIED = false, typename STK>
+TRG_DEV bool traverse(const SceneView &sc, V3 o, V3 d, float tmax_ray, uint32_t rmask, Hit &hit, STK stk,
                       Counters &cnt) {
     Trav tv;
     trav_begin(tv, o, d, tmax_ray, rmask);
     constexpr int mode = UNIFIED ? TRG_TRAV_HBM : TRG_TRAV_LDS;
-    if (mode == 1) {
+    if (mode == 3) {
+        while (tv.node != kNodeDone) trav_step_wide<COUNT, BLOCK>(sc, tv, ANY, stk, cnt);
+    } else if (mode == 1) {
         while (tv.node != kNodeDone) trav_step_unified<COUNT, BLOCK>(sc, tv, ANY, stk, cnt);
     } else {
         for (;;) {
@@ -593,9 +684,9 @@ struct PoolView {
     v4f *R0, *R1, *SH, *H;
 };
 
-template <bool COUNT, int BLOCK, bool UNIFIED = false>
+template <bool COUNT, int BLOCK, bool UNIFIED = false, typename STK>
 TRG_DEV void trace_queue(const SceneView &sc, const PoolView pv, const unsigned short *list, uint32_t count,
-                         uint32_t *head, LdsStack<BLOCK> stk, Counters &cnt) {
+                         uint32_t *head, STK stk, Counters &cnt) {
     const uint32_t lane = threadIdx.x & 63u;
     bool busy = false, exhausted = false, any = false;
     uint32_t slot = 0;
@@ -628,7 +719,9 @@ TRG_DEV void trace_queue(const SceneView &sc, const PoolView pv, const unsigned 
         if (busy) {
             constexpr int mode = UNIFIED ? TRG_TRAV_HBM : TRG_TRAV_LDS;
             for (;;) {
-                if (mode == 1) {
+                if (mode == 3) {
+                    trav_step_wide<COUNT, BLOCK>(sc, tv, any, stk, cnt);
+                } else if (mode == 1) {
                     trav_step_unified<COUNT, BLOCK>(sc, tv, any, stk, cnt);
                 } else {
                     while (tv.node >= 0) trav_node_step<COUNT, BLOCK>(sc, tv, stk, cnt);

@@ -32,6 +32,14 @@ struct SceneDesc {
     const unsigned char *blob;
     uint32_t off_nodes, off_tris, off_normals, off_colors, off_mats, blob_bytes;
     uint32_t n_nodes, n_tris;
+    uint32_t off_nodes4, n_nodes4;  // 4-wide nodes (HBM traversal); they sit after the LDS-staged part of the blob
+    uint32_t lds_stage_bytes;       // bytes a workgroup stages into LDS (everything before the 4-wide nodes)
+};
+
+// traversal stack: the first `klds` levels live in LDS, deeper ones in a global scratch column per thread
+struct StackDesc {
+    int *overflow;      // (levels - klds) x grid_threads ints, or nullptr
+    uint32_t klds;
 };
 
 struct RenderParams {
@@ -44,6 +52,7 @@ struct RenderParams {
     uint32_t stack_off;            // byte offset of the traversal stacks in dynamic LDS
     uint32_t red_off;              // byte offset of the counter-reduction scratch in dynamic LDS
     uint32_t pool_off;             // render_pool_kernel: byte offset of the path pool (slots, lists, counters)
+    StackDesc stack;
 };
 
 struct TraceParams {
@@ -52,7 +61,14 @@ struct TraceParams {
     void *out;  // trg_isect[n] or float[n]
     uint32_t n;
     uint32_t stack_off;
+    StackDesc stack;
 };
+
+// which BVH flavour the HBM (non-LDS) kernels traverse; must match TRG_TRAV_HBM in trg_device.h
+#ifndef TRG_TRAV_HBM
+#define TRG_TRAV_HBM 3
+#endif
+constexpr bool kWideHbm = (TRG_TRAV_HBM == 3);
 
 #define TRG_DECL_LAUNCHERS(SFX)                                                                                   \
     hipError_t launch_render_##SFX(const RenderParams &p, bool lds_scene, bool counters, uint32_t grid,          \

@@ -27,7 +27,7 @@ TRG_DEV SceneView scene_view(const trg::SceneDesc &sc, unsigned char *smem) {
     if (LDS_SCENE) {
         const uint4 *src = reinterpret_cast<const uint4 *>(sc.blob);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
-        const uint32_t n16 = sc.blob_bytes >> 4;
+        const uint32_t n16 = sc.lds_stage_bytes >> 4;
         for (uint32_t i = threadIdx.x; i < n16; i += trg::kBlock) dst[i] = src[i];
         __syncthreads();
         v.nodes = reinterpret_cast<const v4f *>(smem + sc.off_nodes);
@@ -36,7 +36,7 @@ TRG_DEV SceneView scene_view(const trg::SceneDesc &sc, unsigned char *smem) {
         v.colors = reinterpret_cast<const float *>(smem + sc.off_colors);
         v.mats = reinterpret_cast<const uint32_t *>(smem + sc.off_mats);
     } else {
-        v.nodes = reinterpret_cast<const v4f *>(sc.blob + sc.off_nodes);
+        v.nodes = reinterpret_cast<const v4f *>(sc.blob + (trg::kWideHbm ? sc.off_nodes4 : sc.off_nodes));
         v.tris = reinterpret_cast<const v4f *>(sc.blob + sc.off_tris);
         v.normals = reinterpret_cast<const float *>(sc.blob + sc.off_normals);
         v.colors = reinterpret_cast<const float *>(sc.blob + sc.off_colors);
@@ -60,8 +60,11 @@ template <bool LDS_SCENE, bool COUNT>
 __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES) void render_kernel(const trg::RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const SceneView sc = scene_view<LDS_SCENE>(p.sc, smem);
-    LdsStack<trg::kBlock> stk;
+    LdsStackT<trg::kBlock, !LDS_SCENE> stk;  // HBM scenes may spill deep stack levels to global scratch
     stk.base = reinterpret_cast<int *>(smem + p.stack_off) + threadIdx.x;
+    stk.klds = (int)p.stack.klds;
+    stk.gstride = gridDim.x * trg::kBlock;
+    stk.gbase = p.stack.overflow ? p.stack.overflow + (size_t)blockIdx.x * trg::kBlock + threadIdx.x : nullptr;
 
     // workgroup -> 16x16 tile, wavefront -> 8x8 sub-tile, lane -> pixel (8 consecutive pixels of a row
     // per 8 lanes: each wavefront writes eight 128-byte row segments)
@@ -198,8 +201,11 @@ template <bool LDS_SCENE, bool COUNT, int S>
 __global__ __launch_bounds__(trg::kBlock) void render_pool_kernel(const trg::RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const SceneView sc = scene_view<LDS_SCENE>(p.sc, smem);
-    LdsStack<trg::kBlock> stk;
+    LdsStackT<trg::kBlock, !LDS_SCENE> stk;  // HBM scenes may spill deep stack levels to global scratch
     stk.base = reinterpret_cast<int *>(smem + p.stack_off) + threadIdx.x;
+    stk.klds = (int)p.stack.klds;
+    stk.gstride = gridDim.x * trg::kBlock;
+    stk.gbase = p.stack.overflow ? p.stack.overflow + (size_t)blockIdx.x * trg::kBlock + threadIdx.x : nullptr;
     constexpr int P = trg::kBlock * S;
     PoolView pv;
     pv.R0 = reinterpret_cast<v4f *>(smem + p.pool_off);
@@ -372,8 +378,11 @@ template <bool LDS_SCENE, bool ANY>
 __global__ __launch_bounds__(trg::kBlock) void trace_kernel(const trg::TraceParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const SceneView sc = scene_view<LDS_SCENE>(p.sc, smem);
-    LdsStack<trg::kBlock> stk;
+    LdsStackT<trg::kBlock, !LDS_SCENE> stk;  // HBM scenes may spill deep stack levels to global scratch
     stk.base = reinterpret_cast<int *>(smem + p.stack_off) + threadIdx.x;
+    stk.klds = (int)p.stack.klds;
+    stk.gstride = gridDim.x * trg::kBlock;
+    stk.gbase = p.stack.overflow ? p.stack.overflow + (size_t)blockIdx.x * trg::kBlock + threadIdx.x : nullptr;
     const uint32_t i = blockIdx.x * trg::kBlock + threadIdx.x;
     if (i >= p.n) return;
     const trg_ray r = p.rays[i];
