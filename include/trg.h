@@ -155,6 +155,11 @@ TRG_API int trg_debug_build_bvh(const float *positions3, const uint32_t *indices
                         uint32_t n_tris, float *nodes_out, uint32_t nodes_cap, float *tris_out, uint32_t tris_cap,
                         uint32_t *n_nodes, uint32_t *n_tri_records, uint32_t *depth);
 
+/* host-only: the 4-wide collapse of the same tree that HBM-resident scenes are traversed with (32 floats per node:
+ * lo.x[4] hi.x[4] lo.y[4] hi.y[4] lo.z[4] hi.z[4] child[4] pad[4]; unused child slot = 0x80000000). */
+TRG_API int trg_debug_build_bvh4(const float *positions3, const uint32_t *indices, const uint32_t *material_ids, uint32_t n_verts,
+                                 uint32_t n_tris, float *nodes4_out, uint32_t nodes4_cap, uint32_t *n_nodes4, uint32_t *depth4);
+
 /* --- N1: ACES tonemap + sRGB of the accumulation buffer to RGBA8 (PostProcessing.metal:44-57;
  *     common.h:36-43,163-171).  flip_y != 0 writes the top image row first (PNG order). */
 TRG_API int trg_postprocess(trg_ctx *ctx, uint8_t *rgba8, int flip_y);

@@ -169,6 +169,9 @@ class OracleScene:
     def buffers(self):
         s = self.p.contents
         nv, nt = s.nverts, s.ntris
+        if nv == 0:
+            return dict(positions=np.zeros((0, 3), np.float32), normals=np.zeros((0, 3), np.float32),
+                        colors=np.zeros((0, 3), np.float32), indices=np.zeros(0, np.uint32), material_ids=np.zeros(0, np.uint32))
         return dict(
             positions=np.ctypeslib.as_array(s.positions, (nv, 3)).copy(),
             normals=np.ctypeslib.as_array(s.normals, (nv, 3)).copy(),

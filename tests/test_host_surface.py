@@ -152,6 +152,62 @@ def test_bvh_builder_is_sound(built, O):
     assert (seen == 1).all() and d2 <= 12
 
 
+def test_wide_bvh_is_sound(built, O):
+    """The 4-wide collapse reaches every triangle exactly once, boxes enclose their subtrees, and the stack
+    bound the kernel sizes its scratch from (3 * depth + 2) holds."""
+    from toyraygun_amd import capi
+    for scene in (O.OracleScene.cornell_box(), O.OracleScene.cornell_lattice(5), O.OracleScene()):
+        b = scene.buffers()
+        _, tris, _ = capi.debug_build_bvh(b["positions"], b["indices"], b["material_ids"])
+        nodes4, depth4 = capi.debug_build_bvh4(b["positions"], b["indices"], b["material_ids"])
+        nt = scene.ntris
+        seen = np.zeros(max(nt, 1), np.int32)
+        child = nodes4[:, 24:28].copy().view(np.int32)
+        dmax = 0
+        stack = [(0, 1, np.full(3, -np.inf), np.full(3, np.inf))]
+        visited = 0
+        while stack:
+            ni, d, plo, phi = stack.pop()
+            visited += 1
+            dmax = max(dmax, d)
+            n = nodes4[ni]
+            for k in range(4):
+                ref = int(child[ni, k])
+                if ref == -2 ** 31:
+                    continue
+                lo, hi = np.array([n[0 + k], n[8 + k], n[16 + k]]), np.array([n[4 + k], n[12 + k], n[20 + k]])
+                assert (lo >= plo - 1e-4).all() and (hi <= phi + 1e-4).all()      # nested (up to the padding)
+                if ref >= 0:
+                    stack.append((ref, d + 1, lo - 1e-4, hi + 1e-4))
+                else:
+                    code = ~ref
+                    first, count = code >> 3, (code & 7) + 1
+                    for r in range(first, first + count):
+                        rec = tris[r]
+                        v0, e1, e2 = rec[0:3], rec[4:7], rec[8:11]
+                        if nt:
+                            for pnt in (v0, v0 + e1, v0 + e2):
+                                assert (pnt >= lo - 1e-6).all() and (pnt <= hi + 1e-6).all()
+                            seen[int(rec[3:4].view(np.int32)[0])] += 1
+        assert visited == nodes4.shape[0] and dmax == depth4
+        if nt:
+            assert (seen == 1).all()
+        assert depth4 <= 20
+
+
+def test_halton_device_identities():
+    """The two arithmetic identities behind the device Halton code, checked exhaustively in C
+    (tests/helpers/halton_identities.c): fp32 digit extraction for every n < 2^22 and every prime of the table,
+    and the closed form of the base-2 radical inverse on a strided sweep of all 32-bit indices."""
+    import tempfile
+    src = os.path.join(ROOT, "tests", "helpers", "halton_identities.c")
+    with tempfile.TemporaryDirectory() as td:
+        exe = os.path.join(td, "hi")
+        subprocess.check_call(["gcc", "-O2", "-fopenmp", "-mfma", "-ffp-contract=off", src, "-o", exe, "-lm"])
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=600).stdout
+    assert "bad=0" in out and "bad2=0" in out, out
+
+
 def test_bvh_is_deterministic_and_shallow_enough(built, O):
     from toyraygun_amd import capi
     b = O.OracleScene.cornell_lattice(12).buffers()   # 20,772 triangles

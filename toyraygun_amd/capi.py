@@ -82,6 +82,7 @@ _SYMBOLS = [
     ("trg_postprocess", C.c_int, [_P, _P, C.c_int]),
     ("trg_debug_build_bvh", C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32,
                                       C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("trg_debug_build_bvh4", C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
 ]
 SYMBOL_NAMES = [s[0] for s in _SYMBOLS]
 
@@ -255,3 +256,20 @@ def debug_build_bvh(positions, indices, material_ids):
     if rc != OK:
         raise TrgError(rc, "trg_debug_build_bvh")
     return nodes, tris, dp.value
+
+
+def debug_build_bvh4(positions, indices, material_ids):
+    """Host-only 4-wide BVH (no GPU): returns (nodes4[n,32] float32, depth)."""
+    L = load()
+    pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+    idx = np.ascontiguousarray(indices, np.uint32).reshape(-1)
+    mat = np.ascontiguousarray(material_ids, np.uint32).reshape(-1)
+    nn, dp = C.c_uint32(), C.c_uint32()
+    rc = L.trg_debug_build_bvh4(_ptr(pos), _ptr(idx), _ptr(mat), pos.shape[0], mat.shape[0], None, 0, C.byref(nn), C.byref(dp))
+    if rc != OK:
+        raise TrgError(rc, "trg_debug_build_bvh4")
+    nodes = np.zeros((nn.value, 32), np.float32)
+    rc = L.trg_debug_build_bvh4(_ptr(pos), _ptr(idx), _ptr(mat), pos.shape[0], mat.shape[0], _ptr(nodes), nn.value, C.byref(nn), C.byref(dp))
+    if rc != OK:
+        raise TrgError(rc, "trg_debug_build_bvh4")
+    return nodes, dp.value

@@ -402,6 +402,22 @@ int trg_debug_build_bvh(const float *positions3, const uint32_t *indices, const 
     return TRG_OK;
 }
 
+int trg_debug_build_bvh4(const float *positions3, const uint32_t *indices, const uint32_t *material_ids, uint32_t n_verts,
+                         uint32_t n_tris, float *nodes4_out, uint32_t nodes4_cap, uint32_t *n_nodes4, uint32_t *depth4) {
+    if (n_tris && (!positions3 || !indices || !material_ids)) return TRG_ERR_INVALID;
+    for (size_t i = 0; i < (size_t)n_tris * 3; ++i)
+        if (indices[i] >= n_verts) return TRG_ERR_INVALID;
+    Bvh bvh;
+    build_bvh(positions3, indices, material_ids, n_tris, bvh);
+    if (n_nodes4) *n_nodes4 = bvh.n_nodes4;
+    if (depth4) *depth4 = bvh.depth4;
+    if (nodes4_out) {
+        if (nodes4_cap < bvh.n_nodes4) return TRG_ERR_RANGE;
+        memcpy(nodes4_out, bvh.nodes4.data(), (size_t)bvh.n_nodes4 * 128);
+    }
+    return TRG_OK;
+}
+
 // ---- stage-level entry points (host buffers in, host buffers out) ----
 namespace {
 struct DevBuf {

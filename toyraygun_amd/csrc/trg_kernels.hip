@@ -56,8 +56,11 @@ TRG_DEV uint32_t wave_sum(uint32_t v) {
 #ifndef TRG_EXP_WAVES
 #define TRG_EXP_WAVES 6
 #endif
+#ifndef TRG_EXP_WAVES_HBM
+#define TRG_EXP_WAVES_HBM 6
+#endif
 template <bool LDS_SCENE, bool COUNT>
-__global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES) void render_kernel(const trg::RenderParams p) {
+__global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES : TRG_EXP_WAVES_HBM) void render_kernel(const trg::RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const SceneView sc = scene_view<LDS_SCENE>(p.sc, smem);
     LdsStackT<trg::kBlock, !LDS_SCENE> stk;  // HBM scenes may spill deep stack levels to global scratch
