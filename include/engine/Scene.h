@@ -25,6 +25,11 @@ public:
     void addMesh(const bx::Vec3 *vertices, const bx::Vec3 *normals, const uint32_t *indices, int triangleCount,
                  float *transformMtx, bx::Vec3 color, unsigned int materialID);
 
+    // Wavefront OBJ (v / vn / f with v, v/vt, v//vn or v/vt/vn corners, negative indices, polygons as fans).
+    // Faces without normals get the flat face normal addGeometry would give them.  Returns the number of
+    // triangles added, or -1 if the file cannot be read.  ("To Be Completed" upstream, README.md:18-22.)
+    int addObj(const char *path, float *transformMtx, bx::Vec3 color, unsigned int materialID);
+
 protected:
     void addGeometry(bx::Vec3 *vertices, uint32_t *indices, int triangleCount, float *transformMtx, bx::Vec3 color,
                      unsigned int materialID);

@@ -96,6 +96,37 @@ def test_add_mesh_smooth_normals(built):
     assert b["positions"].shape == (3, 3) and np.allclose(b["normals"], n) and b["material_ids"].tolist() == [1]
 
 
+def test_obj_loader(built, O, tmp_path):
+    """Scene::addObj (SURVEY 8f N4): a cube written as OBJ quads gives the same triangle soup as addCube up to
+    the fan triangulation; smooth normals survive; negative indices and v/vt/vn corners parse."""
+    from toyraygun_amd import host
+    p = tmp_path / "cube.obj"
+    v = [(-.5, -.5, -.5), (.5, -.5, -.5), (-.5, .5, -.5), (.5, .5, -.5), (-.5, -.5, .5), (.5, -.5, .5), (-.5, .5, .5), (.5, .5, .5)]
+    quads = [(0, 4, 6, 2), (1, 3, 7, 5), (0, 1, 5, 4), (2, 6, 7, 3), (0, 2, 3, 1), (4, 5, 7, 6)]   # the faces of Scene::addCube
+    with open(p, "w") as f:
+        f.write("# cube\n")
+        for x in v:
+            f.write("v %g %g %g\n" % x)
+        for q in quads:
+            f.write("f " + " ".join(str(i + 1) for i in q) + "\n")
+    m = host.mtx_srt((0.6, 1.2, 0.6), (0, -0.3, 0), (-0.335, 0.6, -0.29))
+    a, b = host.Scene(), host.Scene()
+    assert a.add_obj(p, m, (0.7, 0.7, 0.7)) == 12
+    b.add("cube", (0.7, 0.7, 0.7), m)
+    A, B = a.buffers(), b.buffers()
+    assert np.array_equal(A["positions"], B["positions"]) and np.array_equal(A["normals"], B["normals"])
+    assert np.array_equal(A["indices"], np.arange(36, dtype=np.uint32)) and A["material_ids"].tolist() == [1] * 12
+    # normals, texture coordinates and negative (relative) indices
+    p2 = tmp_path / "tri.obj"
+    p2.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvn 0 0 1\nvn 0.6 0 0.8\nf 1/1/1 2/1/2 3/1/1\nf -3//1 -2//1 -1//1\n")
+    c = host.Scene()
+    assert c.add_obj(p2, np.eye(4, dtype=np.float32), (1, 1, 1), 2) == 2
+    Cb = c.buffers()
+    assert np.allclose(Cb["normals"][:3], [[0, 0, 1], [0.6, 0, 0.8], [0, 0, 1]]) and Cb["material_ids"].tolist() == [2, 2]
+    assert np.array_equal(Cb["positions"][3:], Cb["positions"][:3])
+    assert host.Scene().add_obj(tmp_path / "missing.obj", np.eye(4, dtype=np.float32), (1, 1, 1)) == -1
+
+
 def _walk(nodes, tris, ntris):
     """Check the flattened BVH: every triangle is in exactly one leaf and inside every box above it."""
     seen = np.zeros(ntris, np.int32)

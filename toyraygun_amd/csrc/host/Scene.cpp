@@ -3,6 +3,10 @@
 
 #include "engine/Renderer.h"
 
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
 namespace toyraygun {
 namespace {
 
@@ -79,6 +83,66 @@ void Scene::addMesh(const bx::Vec3 *vertices, const bx::Vec3 *normals, const uin
         }
         m_materialIDBuffer.push_back(materialID);
     }
+}
+
+int Scene::addObj(const char *path, float *transformMtx, bx::Vec3 color, unsigned int materialID) {
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    std::vector<bx::Vec3> pos, nrm;
+    int added = 0;
+    char line[1024];
+    while (fgets(line, sizeof(line), f)) {
+        const char *p = line;
+        while (*p == ' ' || *p == '\t') ++p;
+        if (p[0] == 'v' && (p[1] == ' ' || p[1] == '\t')) {
+            float x = 0, y = 0, z = 0;
+            if (sscanf(p + 1, "%f %f %f", &x, &y, &z) == 3) pos.push_back(bx::Vec3(x, y, z));
+        } else if (p[0] == 'v' && p[1] == 'n') {
+            float x = 0, y = 0, z = 0;
+            if (sscanf(p + 2, "%f %f %f", &x, &y, &z) == 3) nrm.push_back(bx::Vec3(x, y, z));
+        } else if (p[0] == 'f' && (p[1] == ' ' || p[1] == '\t')) {
+            // corners: v, v/vt, v//vn, v/vt/vn
+            int vi[64], ni[64], n = 0;
+            char *q = const_cast<char *>(p + 1);
+            while (n < 64) {
+                while (*q == ' ' || *q == '\t') ++q;
+                if (*q == 0 || *q == '\n' || *q == '\r' || *q == '#') break;
+                char *end;
+                long v = strtol(q, &end, 10), t = 0, nn = 0;
+                if (end == q) break;
+                q = end;
+                if (*q == '/') {
+                    ++q;
+                    if (*q != '/') { t = strtol(q, &end, 10); q = end; }
+                    if (*q == '/') { ++q; nn = strtol(q, &end, 10); q = end; }
+                }
+                (void)t;
+                vi[n] = (int)(v < 0 ? (long)pos.size() + v : v - 1);
+                ni[n] = nn == 0 ? -1 : (int)(nn < 0 ? (long)nrm.size() + nn : nn - 1);
+                ++n;
+            }
+            for (int k = 1; k + 1 < n; ++k) {  // triangle fan
+                const int c3[3] = { 0, k, k + 1 };
+                bool ok = true, have_n = true;
+                for (int j = 0; j < 3; ++j) {
+                    if (vi[c3[j]] < 0 || vi[c3[j]] >= (int)pos.size()) ok = false;
+                    if (ni[c3[j]] < 0 || ni[c3[j]] >= (int)nrm.size()) have_n = false;
+                }
+                if (!ok) continue;
+                bx::Vec3 v3[3] = { pos[vi[c3[0]]], pos[vi[c3[1]]], pos[vi[c3[2]]] };
+                uint32_t idx[3] = { 0, 1, 2 };
+                if (have_n) {
+                    bx::Vec3 n3[3] = { nrm[ni[c3[0]]], nrm[ni[c3[1]]], nrm[ni[c3[2]]] };
+                    addMesh(v3, n3, idx, 1, transformMtx, color, materialID);
+                } else {
+                    addGeometry(v3, idx, 1, transformMtx, color, materialID);
+                }
+                ++added;
+            }
+        }
+    }
+    fclose(f);
+    return added;
 }
 
 }  // namespace toyraygun

@@ -13,7 +13,7 @@ from . import capi
 HOST_SO = os.path.join(capi.LIB_DIR, "libtoyraygun.so")
 _lib = None
 
-SYMBOL_NAMES = ["trh_scene_new", "trh_scene_cornell", "trh_scene_lattice", "trh_scene_free", "trh_scene_add", "trh_scene_add_mesh",
+SYMBOL_NAMES = ["trh_scene_new", "trh_scene_cornell", "trh_scene_lattice", "trh_scene_free", "trh_scene_add", "trh_scene_add_mesh", "trh_scene_add_obj",
                 "trh_scene_counts", "trh_scene_copy", "trh_mtx_srt", "trh_mtx_inverse", "trh_uniforms",
                 "trh_random_texture", "trh_run_app"]
 
@@ -33,6 +33,8 @@ def load():
         L.trh_scene_free.argtypes = [P]
         L.trh_scene_add.argtypes = [P, C.c_int, F, F]
         L.trh_scene_add_mesh.argtypes = [P, F, F, F, C.c_int, F, F, C.c_uint]
+        L.trh_scene_add_obj.argtypes = [P, C.c_char_p, F, F, C.c_uint]
+        L.trh_scene_add_obj.restype = C.c_int
         L.trh_scene_counts.argtypes = [P, C.POINTER(C.c_uint)]
         L.trh_scene_counts.restype = C.c_uint
         L.trh_scene_copy.argtypes = [P, F, F, F, F, F]
@@ -83,6 +85,11 @@ class Scene:
         t = np.ascontiguousarray(tri_idx, np.uint32)
         self.L.trh_scene_add_mesh(self.h, v.ctypes.data, n.ctypes.data, t.ctypes.data, t.size // 3, m.ctypes.data,
                                   c.ctypes.data, material_id)
+
+    def add_obj(self, path, mtx, color, material_id=1):
+        """Scene::addObj: returns the number of triangles added (-1: unreadable file)."""
+        m, c = _f32(mtx).reshape(16), _f32(color)
+        return int(self.L.trh_scene_add_obj(self.h, str(path).encode(), m.ctypes.data, c.ctypes.data, material_id))
 
     def buffers(self):
         nt = C.c_uint()
