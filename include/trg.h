@@ -75,6 +75,8 @@ typedef struct trg_stats {
     uint32_t renders;       /* trg_render calls since reset */
     uint32_t bvh_nodes, bvh_depth, bvh_leaves, scene_in_lds, lds_bytes;
     uint64_t scene_bytes;   /* bytes of nodes + triangle records + attributes on the device */
+    double last_build_ms;   /* acceleration-structure build of the last trg_load_scene: host wall time, or HIP-event time when built on the GPU */
+    uint32_t gpu_built, bvh_nodes4, bvh_depth4, _pad;
 } trg_stats;
 
 enum trg_option {
@@ -82,6 +84,7 @@ enum trg_option {
     TRG_OPT_COUNTERS = 2,     /* 1: count node fetches / triangle tests (slower) */
     TRG_OPT_FORCE_GLOBAL = 3, /* 1: keep the scene in HBM even if it would fit in LDS */
     TRG_OPT_TIMING = 4,       /* 1 (default): bracket trg_render with HIP events (forces a stream sync) */
+    TRG_OPT_GPU_BUILD = 6,    /* 1: the next trg_load_scene builds the BVH on the GPU (LBVH, 4-wide, HBM traversal only); 0 (default): host SAH build */
     TRG_OPT_KERNEL = 5        /* which megakernel trg_render launches: TRG_KERNEL_DIRECT (default) or TRG_KERNEL_POOL */
 };
 enum trg_kernel {

@@ -235,6 +235,45 @@ def test_c4_million_triangle_scene_parity(capi, O):
         c.close()
 
 
+@pytest.mark.parametrize("n", [0, 3, 7])
+def test_gpu_built_bvh_gives_identical_images(capi, O, n):
+    """with TRG_OPT_GPU_BUILD the acceleration structure is an LBVH built on the device (Morton sort +
+    Karras hierarchy + atomic refit, emitted 4-wide).  Traversal results do not depend on the tree, so the strict
+    image must still equal the oracle's bit for bit, for both megakernels; so must the intersector's records."""
+    scene = O.OracleScene.cornell_lattice(n) if n else O.OracleScene.cornell_box()
+    b = scene.buffers()
+    w, h = 72, 56
+    off = O.pixel_offsets(w, h)
+    O.set_trig_mode(O.TRIG_PORTABLE)
+    ref, rst = O.render(scene, w, h, 3, 4, offsets=off)
+    O.set_trig_mode(O.TRIG_LIBM)
+    c = capi.Context(w, h)
+    try:
+        c.set_option(capi.OPT_GPU_BUILD, 1)
+        c.load_scene(b["positions"], b["normals"], b["colors"], b["indices"], b["material_ids"])
+        st = c.stats()
+        assert st.gpu_built == 1 and st.scene_in_lds == 0 and st.bvh_nodes4 >= 1 and st.last_build_ms > 0
+        c.set_uniforms(O.uniforms_bytes(O.make_uniforms(w, h)))
+        c.set_pixel_offsets(off)
+        c.set_option(capi.OPT_STRICT, 1)
+        for k in KERNELS:
+            c.set_option(capi.OPT_KERNEL, k)
+            c.reset_stats()
+            c.render(0, 3, 4)
+            assert np.array_equal(_bits(c.read_accum()), _bits(ref)) and c.stats().rays == rst.rays
+        rays = np.concatenate([_rays(O, 20000, 31, hi=(0.95, 1.9, 0.95)), _adversarial_rays(O, O.OracleScene.cornell_box())])
+        assert np.array_equal(c.trace(rays).view(np.uint8), O.intersect_nearest(scene, rays).view(np.uint8))
+        # rebuilding with the host builder on the same context switches back
+        c.set_option(capi.OPT_GPU_BUILD, 0)
+        c.load_scene(b["positions"], b["normals"], b["colors"], b["indices"], b["material_ids"])
+        assert c.stats().gpu_built == 0
+        c.set_option(capi.OPT_KERNEL, 0)
+        c.render(0, 3, 4)
+        assert np.array_equal(_bits(c.read_accum()), _bits(ref))
+    finally:
+        c.close()
+
+
 def test_degenerate_scenes(capi, O):
     """Empty scene and a single triangle (the BVH builder synthesises the root)."""
     u = O.make_uniforms(32, 32)

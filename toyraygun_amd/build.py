@@ -59,6 +59,7 @@ def build(force=False, verbose=False):
     units = [
         ("trg_kernels_fast.o", os.path.join(CSRC, "trg_kernels.hip"), dev + ["-DTRG_STRICT=0"]),
         ("trg_kernels_strict.o", os.path.join(CSRC, "trg_kernels.hip"), dev + ["-DTRG_STRICT=1", "-ffp-contract=off"]),
+        ("trg_build.o", os.path.join(CSRC, "trg_build.hip"), dev),
         ("trg_capi.o", os.path.join(CSRC, "trg_capi.cpp"), ["-x", "hip", "--offload-arch=" + ARCH]),
         ("bvh_build.o", os.path.join(CSRC, "bvh_build.cpp"), ["-x", "hip", "--offload-arch=" + ARCH]),
     ]

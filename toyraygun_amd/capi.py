@@ -15,7 +15,7 @@ HIP_SO = os.path.join(LIB_DIR, "libtoyraygun_hip.so")
 
 OK = 0
 ERR_INVALID, ERR_NOMEM, ERR_DEVICE, ERR_NODEV, ERR_RANGE = -22, -12, -5, -19, -34
-OPT_STRICT, OPT_COUNTERS, OPT_FORCE_GLOBAL, OPT_TIMING, OPT_KERNEL = 1, 2, 3, 4, 5
+OPT_STRICT, OPT_COUNTERS, OPT_FORCE_GLOBAL, OPT_TIMING, OPT_KERNEL, OPT_GPU_BUILD = 1, 2, 3, 4, 5, 6
 KERNEL_DIRECT, KERNEL_POOL = 0, 1
 MATERIAL_DEFAULT, MATERIAL_EMISSIVE = 1, 2
 MAX_BOUNCES = 15
@@ -41,6 +41,8 @@ class Stats(C.Structure):
         ("renders", C.c_uint32), ("bvh_nodes", C.c_uint32), ("bvh_depth", C.c_uint32), ("bvh_leaves", C.c_uint32),
         ("scene_in_lds", C.c_uint32), ("lds_bytes", C.c_uint32),
         ("scene_bytes", C.c_uint64),
+        ("last_build_ms", C.c_double),
+        ("gpu_built", C.c_uint32), ("bvh_nodes4", C.c_uint32), ("bvh_depth4", C.c_uint32), ("_pad", C.c_uint32),
     ]
 
     @property

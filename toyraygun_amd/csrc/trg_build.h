@@ -1,0 +1,12 @@
+// trg_build.h -- device-side acceleration-structure build (trg_build.hip), internal to libtoyraygun_hip.so.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+namespace trg {
+
+hipError_t gpu_build_lbvh(const float *d_pos, const uint32_t *d_idx, const uint32_t *d_masks, uint32_t ntris,
+                          const float scene_lo[3], const float scene_hi[3], float pad, float4 *d_nodes4, float4 *d_tris,
+                          uint32_t *n_nodes4, uint32_t *depth4, hipStream_t s);
+
+}  // namespace trg

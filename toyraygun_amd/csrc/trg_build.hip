@@ -1,0 +1,228 @@
+// trg_build.hip -- acceleration-structure build ON the GPU: LBVH (Morton codes + radix sort +
+// Karras 2012 hierarchy + atomic bottom-up refit), emitted directly in the 4-wide node format the HBM
+// traversal reads.  The device counterpart of what the reference delegates to MPSTriangleAccelerationStructure
+// rebuild (src/engine/Metal/MetalRenderer.mm:272-279) / DXR BuildRaytracingAccelerationStructure
+// (src/engine/D3D12/D3D12Renderer.cpp:285-391).  Trees are lower quality than the host SAH build (no surface-area
+// heuristic) but take milliseconds for a million triangles; results of traversal are tree-independent
+// (intersection contract: minimum t, ties to the lower primitive index), so images stay bit-identical.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "trg_build.h"
+
+namespace trg {
+namespace {
+
+constexpr int kEmptyChild = (int)0x80000000;
+
+struct Box3 { float lo[3], hi[3]; };
+
+__device__ __forceinline__ uint32_t expand_bits10(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+// per triangle: padded box and the sort key (30-bit Morton code of the box centre << 32 | triangle index: unique)
+__global__ void prim_kernel(const float *pos, const uint32_t *idx, uint32_t ntris, float3 slo, float3 sinv, float pad,
+                            Box3 *boxes, unsigned long long *keys) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ntris) return;
+    Box3 b;
+    for (int a = 0; a < 3; ++a) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; }
+    for (int j = 0; j < 3; ++j) {
+        const float *p = pos + (size_t)idx[k * 3 + j] * 3;
+        for (int a = 0; a < 3; ++a) { b.lo[a] = fminf(b.lo[a], p[a]); b.hi[a] = fmaxf(b.hi[a], p[a]); }
+    }
+    const float cx = (0.5f * (b.lo[0] + b.hi[0]) - slo.x) * sinv.x;
+    const float cy = (0.5f * (b.lo[1] + b.hi[1]) - slo.y) * sinv.y;
+    const float cz = (0.5f * (b.lo[2] + b.hi[2]) - slo.z) * sinv.z;
+    const uint32_t ix = (uint32_t)fminf(fmaxf(cx * 1024.0f, 0.0f), 1023.0f);
+    const uint32_t iy = (uint32_t)fminf(fmaxf(cy * 1024.0f, 0.0f), 1023.0f);
+    const uint32_t iz = (uint32_t)fminf(fmaxf(cz * 1024.0f, 0.0f), 1023.0f);
+    const uint32_t morton = (expand_bits10(ix) << 2) | (expand_bits10(iy) << 1) | expand_bits10(iz);
+    for (int a = 0; a < 3; ++a) { b.lo[a] -= pad; b.hi[a] += pad; }
+    boxes[k] = b;
+    keys[k] = ((unsigned long long)morton << 32) | k;
+}
+
+// triangle records in sorted (leaf) order: (v0, prim) (e1, mask) (e2, -), same arithmetic as the host builder
+__global__ void record_kernel(const float *pos, const uint32_t *idx, const uint32_t *masks, const unsigned long long *keys,
+                              uint32_t ntris, float4 *tris) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= ntris) return;
+    const uint32_t k = (uint32_t)(keys[r] & 0xFFFFFFFFull);
+    const float *a = pos + (size_t)idx[k * 3 + 0] * 3, *b = pos + (size_t)idx[k * 3 + 1] * 3, *c = pos + (size_t)idx[k * 3 + 2] * 3;
+    tris[(size_t)r * 3 + 0] = make_float4(a[0], a[1], a[2], __uint_as_float(k));
+    tris[(size_t)r * 3 + 1] = make_float4(b[0] - a[0], b[1] - a[1], b[2] - a[2], __uint_as_float(masks[k]));
+    tris[(size_t)r * 3 + 2] = make_float4(c[0] - a[0], c[1] - a[1], c[2] - a[2], 0.0f);
+}
+
+__device__ __forceinline__ int delta(const unsigned long long *keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    return __clzll((long long)(keys[i] ^ keys[j]));  // keys are unique, so the xor is never 0
+}
+
+// Karras 2012: internal node i of n-1; children encoded: >= 0 internal node, < 0 leaf ~r (r = sorted position)
+__global__ void hierarchy_kernel(const unsigned long long *keys, int n, int *left, int *right, int *parent_int, int *parent_leaf) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    const int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = delta(keys, n, i, j);
+    int s = 0;
+    for (int t = (l + 1) / 2;; t = (t + 1) / 2) {
+        if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+        if (t == 1) break;
+    }
+    const int gamma = i + s * d + min(d, 0);
+    const int lo = min(i, j), hi = max(i, j);
+    const int lc = (lo == gamma) ? ~gamma : gamma;
+    const int rc = (hi == gamma + 1) ? ~(gamma + 1) : gamma + 1;
+    left[i] = lc; right[i] = rc;
+    if (lc >= 0) parent_int[lc] = i; else parent_leaf[~lc] = i;
+    if (rc >= 0) parent_int[rc] = i; else parent_leaf[~rc] = i;
+    if (i == 0) parent_int[0] = -1;
+}
+
+// bottom-up refit: the second thread to reach a node owns it
+__global__ void refit_kernel(const Box3 *prim_boxes, const unsigned long long *keys, int n, const int *left, const int *right,
+                             const int *parent_int, const int *parent_leaf, Box3 *node_boxes, int *arrive) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    int node = parent_leaf[r];
+    while (node >= 0) {
+        __threadfence();  // release: our child boxes are written back before the arrival is published
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // hipcc may drop the fence's own wait (cdna guide, G16 pitfall 12)
+        if (atomicAdd(&arrive[node], 1) == 0) return;  // first arrival: the sibling subtree is not finished yet
+        __threadfence();  // acquire: second arrival, make the sibling's writes visible before reading them
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        Box3 b;
+        const int c[2] = { left[node], right[node] };
+        for (int a = 0; a < 3; ++a) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; }
+        for (int k = 0; k < 2; ++k) {
+            const Box3 *cb = c[k] >= 0 ? &node_boxes[c[k]] : &prim_boxes[(uint32_t)(keys[~c[k]] & 0xFFFFFFFFull)];
+            for (int a = 0; a < 3; ++a) {
+                // L1-bypassing loads on top of the acquire fence
+                b.lo[a] = fminf(b.lo[a], __builtin_nontemporal_load(&cb->lo[a]));
+                b.hi[a] = fmaxf(b.hi[a], __builtin_nontemporal_load(&cb->hi[a]));
+            }
+        }
+        node_boxes[node] = b;
+        node = parent_int[node];
+    }
+}
+
+// depth of every internal node (root = 0) by walking up; kept[i] = depth even = becomes a 4-wide node
+__global__ void depth_kernel(const int *parent_int, int n_int, uint32_t *kept, int *max_depth) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_int) return;
+    int d = 0;
+    for (int p = parent_int[i]; p >= 0; p = parent_int[p]) ++d;
+    kept[i] = (d & 1) == 0 ? 1u : 0u;
+    atomicMax(max_depth, d);
+}
+
+// one 4-wide node per kept BVH2 node: its children's children (or the children themselves when they are leaves)
+__global__ void emit_wide_kernel(const Box3 *prim_boxes, const unsigned long long *keys, const Box3 *node_boxes, const int *left,
+                                 const int *right, const uint32_t *kept, const uint32_t *wide_index, int n_int, float4 *nodes4) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_int || !kept[i]) return;
+    int child[4]; int n = 0;
+    const int c2[2] = { left[i], right[i] };
+    for (int k = 0; k < 2; ++k) {
+        if (c2[k] >= 0) { child[n++] = left[c2[k]]; child[n++] = right[c2[k]]; }
+        else child[n++] = c2[k];
+    }
+    float v[6][4]; int ref[4];
+    for (int k = 0; k < 4; ++k) {
+        ref[k] = kEmptyChild;
+        for (int a = 0; a < 6; ++a) v[a][k] = 0.0f;
+        if (k >= n) continue;
+        const int c = child[k];
+        const Box3 *b;
+        if (c >= 0) { b = &node_boxes[c]; ref[k] = (int)wide_index[c]; }          // grandchild: kept (depth + 2)
+        else { const uint32_t r = (uint32_t)~c; b = &prim_boxes[(uint32_t)(keys[r] & 0xFFFFFFFFull)]; ref[k] = ~(int)(r << 3); }  // leaf of one triangle
+        for (int a = 0; a < 3; ++a) { v[a * 2][k] = b->lo[a]; v[a * 2 + 1][k] = b->hi[a]; }
+    }
+    float4 *o = nodes4 + (size_t)wide_index[i] * 8;
+    for (int a = 0; a < 6; ++a) o[a] = make_float4(v[a][0], v[a][1], v[a][2], v[a][3]);
+    o[6] = make_float4(__int_as_float(ref[0]), __int_as_float(ref[1]), __int_as_float(ref[2]), __int_as_float(ref[3]));
+    o[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+struct Tmp {
+    void *p = nullptr;
+    ~Tmp() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 16); }
+    template <typename T> T *as() { return static_cast<T *>(p); }
+};
+
+#define BCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
+
+}  // namespace
+
+// Builds the 4-wide tree and the leaf-ordered triangle records for `ntris` >= 2 triangles.
+// d_pos/d_idx/d_masks: device copies of the scene arrays.  d_nodes4 must hold (ntris - 1) * 8 float4 (upper
+// bound on wide nodes), d_tris ntris * 3 float4.  Returns the number of wide nodes and the wide depth.
+hipError_t gpu_build_lbvh(const float *d_pos, const uint32_t *d_idx, const uint32_t *d_masks, uint32_t ntris,
+                          const float scene_lo[3], const float scene_hi[3], float pad, float4 *d_nodes4, float4 *d_tris,
+                          uint32_t *n_nodes4, uint32_t *depth4, hipStream_t s) {
+    const int n = (int)ntris, n_int = n - 1;
+    const int T = 256;
+    Tmp boxes, keys_a, keys_b, left, right, par_i, par_l, nboxes, arrive, kept, widx, maxd, sort_tmp, scan_tmp;
+    BCHK(boxes.alloc(sizeof(Box3) * n)); BCHK(keys_a.alloc(8 * (size_t)n)); BCHK(keys_b.alloc(8 * (size_t)n));
+    BCHK(left.alloc(4 * (size_t)n)); BCHK(right.alloc(4 * (size_t)n)); BCHK(par_i.alloc(4 * (size_t)n)); BCHK(par_l.alloc(4 * (size_t)n));
+    BCHK(nboxes.alloc(sizeof(Box3) * n)); BCHK(arrive.alloc(4 * (size_t)n)); BCHK(kept.alloc(4 * (size_t)n)); BCHK(widx.alloc(4 * (size_t)n));
+    BCHK(maxd.alloc(16));
+    BCHK(hipMemsetAsync(arrive.p, 0, 4 * (size_t)n, s));
+    BCHK(hipMemsetAsync(maxd.p, 0, 16, s));
+
+    float3 slo = make_float3(scene_lo[0], scene_lo[1], scene_lo[2]);
+    float3 sinv;
+    sinv.x = scene_hi[0] > scene_lo[0] ? 1.0f / (scene_hi[0] - scene_lo[0]) : 0.0f;
+    sinv.y = scene_hi[1] > scene_lo[1] ? 1.0f / (scene_hi[1] - scene_lo[1]) : 0.0f;
+    sinv.z = scene_hi[2] > scene_lo[2] ? 1.0f / (scene_hi[2] - scene_lo[2]) : 0.0f;
+    hipLaunchKernelGGL(prim_kernel, dim3((n + T - 1) / T), dim3(T), 0, s, d_pos, d_idx, ntris, slo, sinv, pad, boxes.as<Box3>(),
+                       keys_a.as<unsigned long long>());
+    size_t tmp_bytes = 0;
+    BCHK(rocprim::radix_sort_keys(nullptr, tmp_bytes, keys_a.as<unsigned long long>(), keys_b.as<unsigned long long>(), (size_t)n, 0, 62, s));
+    BCHK(sort_tmp.alloc(tmp_bytes));
+    BCHK(rocprim::radix_sort_keys(sort_tmp.p, tmp_bytes, keys_a.as<unsigned long long>(), keys_b.as<unsigned long long>(), (size_t)n, 0, 62, s));
+    const unsigned long long *keys = keys_b.as<unsigned long long>();
+    hipLaunchKernelGGL(record_kernel, dim3((n + T - 1) / T), dim3(T), 0, s, d_pos, d_idx, d_masks, keys, ntris, d_tris);
+    hipLaunchKernelGGL(hierarchy_kernel, dim3((n_int + T - 1) / T), dim3(T), 0, s, keys, n, left.as<int>(), right.as<int>(), par_i.as<int>(),
+                       par_l.as<int>());
+    hipLaunchKernelGGL(refit_kernel, dim3((n + T - 1) / T), dim3(T), 0, s, boxes.as<Box3>(), keys, n, left.as<int>(), right.as<int>(),
+                       par_i.as<int>(), par_l.as<int>(), nboxes.as<Box3>(), arrive.as<int>());
+    hipLaunchKernelGGL(depth_kernel, dim3((n_int + T - 1) / T), dim3(T), 0, s, par_i.as<int>(), n_int, kept.as<uint32_t>(), maxd.as<int>());
+    tmp_bytes = 0;
+    BCHK(rocprim::exclusive_scan(nullptr, tmp_bytes, kept.as<uint32_t>(), widx.as<uint32_t>(), 0u, (size_t)n_int, rocprim::plus<uint32_t>(), s));
+    BCHK(scan_tmp.alloc(tmp_bytes));
+    BCHK(rocprim::exclusive_scan(scan_tmp.p, tmp_bytes, kept.as<uint32_t>(), widx.as<uint32_t>(), 0u, (size_t)n_int, rocprim::plus<uint32_t>(), s));
+    hipLaunchKernelGGL(emit_wide_kernel, dim3((n_int + T - 1) / T), dim3(T), 0, s, boxes.as<Box3>(), keys, nboxes.as<Box3>(), left.as<int>(),
+                       right.as<int>(), kept.as<uint32_t>(), widx.as<uint32_t>(), n_int, d_nodes4);
+    BCHK(hipGetLastError());
+    uint32_t last_kept = 0, last_idx = 0; int md = 0;
+    BCHK(hipMemcpyAsync(&last_kept, kept.as<uint32_t>() + (n_int - 1), 4, hipMemcpyDeviceToHost, s));
+    BCHK(hipMemcpyAsync(&last_idx, widx.as<uint32_t>() + (n_int - 1), 4, hipMemcpyDeviceToHost, s));
+    BCHK(hipMemcpyAsync(&md, maxd.p, 4, hipMemcpyDeviceToHost, s));
+    BCHK(hipStreamSynchronize(s));
+    *n_nodes4 = last_idx + last_kept;
+    *depth4 = (uint32_t)(md / 2 + 1);
+    return hipSuccess;
+}
+
+}  // namespace trg

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -12,6 +13,7 @@
 
 #include "../../include/trg.h"
 #include "bvh_build.h"
+#include "trg_build.h"
 #include "trg_kernels.h"
 
 using namespace trg;
@@ -33,6 +35,9 @@ struct trg_ctx {
     trg_uniforms u{};
     bool opt_strict = false, opt_counters = false, opt_force_global = false, opt_timing = true;
     int opt_kernel = TRG_KERNEL_DIRECT;
+    bool opt_gpu_build = false;
+    double last_build_ms = 0.0;
+    bool gpu_built = false;
     uint32_t bvh_nodes = 0, bvh_depth = 0, bvh_leaves = 0;
     double last_ms = 0.0, total_ms = 0.0;
     uint32_t renders = 0;
@@ -102,6 +107,68 @@ static int ensure_stack_scratch(trg_ctx *c, const LdsPlan &plan, uint64_t grid_t
     return TRG_OK;
 }
 
+// trg_load_scene with TRG_OPT_GPU_BUILD: LBVH on the device (trg_build.hip), 4-wide nodes only (never LDS-staged).
+static int load_scene_gpu_build(trg_ctx *c, const float *pos, const float *nrm, const float *col, const uint32_t *idx,
+                                const uint32_t *mat, uint32_t n_verts, uint32_t n_tris) {
+    if (!kWideHbm) return fail(c, TRG_ERR_INVALID, "GPU build needs the 4-wide HBM traversal");
+    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (size_t i = 0; i < (size_t)n_tris * 3; ++i) {
+        const float *p = pos + (size_t)idx[i] * 3;
+        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); }
+    }
+    const float diag = std::max({ hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2] });
+    const float pad = 2e-5f * std::max(diag, 1e-3f);  // same conservative padding as bvh_build.cpp
+    struct Dev { void *p = nullptr; ~Dev() { if (p) (void)hipFree(p); } } d_pos, d_idx, d_mat, d_nodes4, d_tris;
+    HIPCHK(c, hipMalloc(&d_pos.p, (size_t)n_verts * 12)); HIPCHK(c, hipMalloc(&d_idx.p, (size_t)n_tris * 12));
+    HIPCHK(c, hipMalloc(&d_mat.p, (size_t)n_tris * 4)); HIPCHK(c, hipMalloc(&d_nodes4.p, (size_t)(n_tris - 1) * 128));
+    HIPCHK(c, hipMalloc(&d_tris.p, (size_t)n_tris * 48));
+    HIPCHK(c, hipMemcpyAsync(d_pos.p, pos, (size_t)n_verts * 12, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_idx.p, idx, (size_t)n_tris * 12, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_mat.p, mat, (size_t)n_tris * 4, hipMemcpyHostToDevice, c->stream));
+    uint32_t n4 = 0, depth4 = 0;
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    hipError_t e = gpu_build_lbvh((const float *)d_pos.p, (const uint32_t *)d_idx.p, (const uint32_t *)d_mat.p, n_tris, lo, hi, pad,
+                                  (float4 *)d_nodes4.p, (float4 *)d_tris.p, &n4, &depth4, c->stream);
+    if (e != hipSuccess) return fail(c, TRG_ERR_DEVICE, "GPU BVH build failed: %s", hipGetErrorString(e));
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->last_build_ms = ms;
+    c->gpu_built = true;
+
+    SceneDesc sc{};
+    sc.n_nodes = 0; sc.n_tris = n_tris;
+    sc.off_nodes = 0; sc.off_tris = 0;
+    sc.off_normals = align16(n_tris * 48u);
+    sc.off_colors = align16(sc.off_normals + n_tris * 36u);
+    sc.off_mats = align16(sc.off_colors + n_tris * 36u);
+    sc.off_nodes4 = (align16(sc.off_mats + n_tris * 4u) + 127u) & ~127u;
+    sc.n_nodes4 = n4;
+    sc.lds_stage_bytes = 0;
+    const uint64_t total = (uint64_t)sc.off_nodes4 + (uint64_t)n4 * 128u + 128u;
+    if (total > 0xFFFFFFF0ull) return fail(c, TRG_ERR_RANGE, "trg_load_scene: scene needs %llu B on the device (limit 4 GiB)", (unsigned long long)total);
+    sc.blob_bytes = (uint32_t)total;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->blob) { (void)hipFree(c->blob); c->blob = nullptr; c->scene_loaded = false; }
+    e = hipMalloc((void **)&c->blob, sc.blob_bytes);
+    if (e != hipSuccess) return fail(c, TRG_ERR_NOMEM, "trg_load_scene: hipMalloc(%u) failed: %s", sc.blob_bytes, hipGetErrorString(e));
+    HIPCHK(c, hipMemsetAsync(c->blob, 0, sc.blob_bytes, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->blob + sc.off_tris, d_tris.p, (size_t)n_tris * 48, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->blob + sc.off_normals, nrm, (size_t)n_tris * 36, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->blob + sc.off_colors, col, (size_t)n_tris * 36, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->blob + sc.off_mats, mat, (size_t)n_tris * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->blob + sc.off_nodes4, d_nodes4.p, (size_t)n4 * 128, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    sc.blob = c->blob;
+    c->sc = sc;
+    c->bvh_nodes = 0; c->bvh_depth = 2 * depth4; c->bvh_leaves = n_tris;
+    c->bvh_nodes4 = n4; c->bvh_depth4 = depth4;
+    c->scene_loaded = true;
+    LdsPlan plan;
+    return plan_lds(c, plan, c->opt_kernel == TRG_KERNEL_POOL);
+}
+
 extern "C" {
 
 const char *trg_last_error(trg_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
@@ -165,9 +232,13 @@ int trg_load_scene(trg_ctx *c, const float *pos, const float *nrm, const float *
     for (size_t i = 0; i < (size_t)n_tris * 3; ++i)
         if (idx[i] >= n_verts) return fail(c, TRG_ERR_INVALID, "trg_load_scene: index %u out of range (%u vertices) at %zu", idx[i], n_verts, i);
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->opt_gpu_build && n_tris >= 2) return load_scene_gpu_build(c, pos, nrm, col, idx, mat, n_verts, n_tris);
 
+    const auto host_t0 = std::chrono::steady_clock::now();
     Bvh bvh;
     build_bvh(pos, idx, mat, n_tris, bvh);
+    c->last_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
+    c->gpu_built = false;
 
     // Positions go through the index buffer (MPS vertexBuffer + indexBuffer, MetalRenderer.mm:274-275);
     // normals and colours are read as attributes[triangle*3 + j], NOT through the index buffer
@@ -318,6 +389,8 @@ int trg_get_stats(trg_ctx *c, trg_stats *out) {
     out->last_render_ms = c->last_ms; out->total_render_ms = c->total_ms; out->renders = c->renders;
     out->bvh_nodes = c->bvh_nodes; out->bvh_depth = c->bvh_depth; out->bvh_leaves = c->bvh_leaves;
     out->scene_bytes = c->sc.blob_bytes;
+    out->last_build_ms = c->last_build_ms; out->gpu_built = c->gpu_built ? 1u : 0u;
+    out->bvh_nodes4 = c->bvh_nodes4; out->bvh_depth4 = c->bvh_depth4;
     if (c->scene_loaded) {
         LdsPlan plan;
         if (plan_lds(c, plan, c->opt_kernel == TRG_KERNEL_POOL) == TRG_OK) { out->scene_in_lds = plan.lds_scene ? 1u : 0u; out->lds_bytes = plan.total; }
@@ -341,6 +414,7 @@ int trg_set_option(trg_ctx *c, int option, int64_t value) {
     case TRG_OPT_COUNTERS: c->opt_counters = value != 0; break;
     case TRG_OPT_FORCE_GLOBAL: c->opt_force_global = value != 0; break;
     case TRG_OPT_TIMING: c->opt_timing = value != 0; break;
+    case TRG_OPT_GPU_BUILD: c->opt_gpu_build = value != 0; break;
     case TRG_OPT_KERNEL:
         if (value != TRG_KERNEL_DIRECT && value != TRG_KERNEL_POOL) return fail(c, TRG_ERR_INVALID, "trg_set_option: unknown kernel %lld", (long long)value);
         c->opt_kernel = (int)value;
