@@ -4,11 +4,11 @@ set -e
 cd /root/repo
 name=$1; shift
 out=exp_build/$name; mkdir -p $out
-C=toyraygun_amd/csrc
-F="-O3 -std=c++17 -fPIC -fvisibility=hidden -Iinclude --offload-arch=gfx950"
+C=${SRC:-toyraygun_amd/csrc}
+F="-O3 -std=c++17 -fPIC -fvisibility=hidden -Iinclude -I/root/repo/toyraygun_amd/csrc --offload-arch=gfx950"
 hipcc $F -DTRG_STRICT=0 "$@" -c $C/trg_kernels.hip -o $out/kf.o &
 hipcc $F -DTRG_STRICT=1 -ffp-contract=off "$@" -c $C/trg_kernels.hip -o $out/ks.o &
 hipcc $F -x hip "$@" -c $C/trg_capi.cpp -o $out/capi.o &
 wait
-hipcc -shared -fPIC --offload-arch=gfx950 -o $out/libtoyraygun_hip.so $out/kf.o $out/ks.o $out/capi.o toyraygun_amd/build/bvh_build.o
+hipcc -shared -fPIC --offload-arch=gfx950 -o $out/libtoyraygun_hip.so $out/kf.o $out/ks.o $out/capi.o toyraygun_amd/build/bvh_build.o toyraygun_amd/build/trg_build.o
 echo built $out

@@ -262,6 +262,9 @@ int trg_load_scene(trg_ctx *c, const float *pos, const float *nrm, const float *
     sc.off_nodes4 = (sc.off_nodes4 + 127u) & ~127u;  // 128-byte nodes on 128-byte lines
     sc.n_nodes4 = kWideHbm ? bvh.n_nodes4 : 0u;
     sc.lds_stage_bytes = lds_candidate ? align16(sc.off_mats + attr_tris * 4u) : 0u;
+#if defined(TRG_TRAV_LDS) && TRG_TRAV_LDS == 3  // experiment: LDS-resident scenes traverse the 4-wide tree too
+    if (lds_candidate) sc.lds_stage_bytes = align16(sc.off_nodes4 + sc.n_nodes4 * 128u);
+#endif
     const uint64_t total = (uint64_t)sc.off_nodes4 + (uint64_t)sc.n_nodes4 * 128u + 128u;
     if (total > 0xFFFFFFF0ull) return fail(c, TRG_ERR_RANGE, "trg_load_scene: scene needs %llu B on the device (limit 4 GiB)", (unsigned long long)total);
     sc.blob_bytes = (uint32_t)total;

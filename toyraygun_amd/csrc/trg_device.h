@@ -638,6 +638,10 @@ TRG_DEV void trav_step_unified(const SceneView &sc, Trav &tv, bool any, STK stk,
 template <bool ANY, bool COUNT, int BLOCK, bool UNIFIED = false, typename STK>
 TRG_DEV bool traverse(const SceneView &sc, V3 o, V3 d, float tmax_ray, uint32_t rmask, Hit &hit, STK stk,
                       Counters &cnt) {
+#ifdef TRG_EXP_NOTRAVERSE  // timing-only ablation: a made-up hit, no traversal
+    hit.t = 0.5f + 0.001f * (float)(threadIdx.x & 15); hit.prim = ANY ? -1 : (int)((threadIdx.x * 7u + (uint32_t)(o.x * 64.0f)) % 34u); hit.u = 0.3f; hit.v = 0.3f;
+    return !ANY;
+#endif
     Trav tv;
     trav_begin(tv, o, d, tmax_ray, rmask);
     constexpr int mode = UNIFIED ? TRG_TRAV_HBM : TRG_TRAV_LDS;
@@ -655,6 +659,44 @@ TRG_DEV bool traverse(const SceneView &sc, V3 o, V3 d, float tmax_ray, uint32_t 
     }
     hit = tv.hit;
     return tv.found;
+}
+
+// Two rays per lane in ONE traversal loop: the shadow ray of bounce b (any-hit) and the continuation ray of
+// bounce b+1 (nearest-hit) both come out of the same shading event and are independent, so a lane walks
+// them back to back without waiting for the other lanes in between.  The wavefront then pays
+// max over lanes of (len_shadow + len_next) instead of max(len_shadow) + max(len_next) -- the cheapest form of
+// decoupling lanes from one another: no queue, no LDS traffic, identical arithmetic per ray.
+template <bool COUNT, int BLOCK, bool UNIFIED, typename STK>
+TRG_DEV void traverse_pair(const SceneView &sc, V3 org, bool has_shadow, V3 sdir, float smax, bool has_next, V3 ndir,
+                           uint32_t nmask, bool &occluded, Hit &nhit, bool &nfound, STK stk, Counters &cnt) {
+    occluded = false; nfound = false;
+    nhit.t = -1.0f; nhit.prim = -1; nhit.u = 0.0f; nhit.v = 0.0f;
+    int phase = has_shadow ? 0 : (has_next ? 1 : 2);
+    Trav tv;
+    trav_begin(tv, org, phase == 0 ? sdir : ndir, phase == 0 ? smax : INFINITY, phase == 0 ? 1u : nmask);
+    if (phase == 2) tv.node = kNodeDone;
+    constexpr int mode = UNIFIED ? TRG_TRAV_HBM : TRG_TRAV_LDS;
+    while (phase < 2) {
+        const bool any = phase == 0;
+        if (mode == 3) {
+            trav_step_wide<COUNT, BLOCK>(sc, tv, any, stk, cnt);
+        } else if (mode == 1) {
+            trav_step_unified<COUNT, BLOCK>(sc, tv, any, stk, cnt);
+        } else {
+            while (tv.node >= 0) trav_node_step<COUNT, BLOCK>(sc, tv, stk, cnt);
+            if (tv.node != kNodeDone) trav_leaf_step<COUNT, BLOCK>(sc, tv, any, stk, cnt);
+        }
+        if (tv.node == kNodeDone) {
+            if (phase == 0) {
+                occluded = tv.found;
+                phase = has_next ? 1 : 2;
+                if (phase == 1) trav_begin(tv, org, ndir, INFINITY, nmask);
+            } else {
+                nhit = tv.hit; nfound = tv.found;
+                phase = 2;
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

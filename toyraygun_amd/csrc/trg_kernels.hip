@@ -30,7 +30,7 @@ TRG_DEV SceneView scene_view(const trg::SceneDesc &sc, unsigned char *smem) {
         const uint32_t n16 = sc.lds_stage_bytes >> 4;
         for (uint32_t i = threadIdx.x; i < n16; i += trg::kBlock) dst[i] = src[i];
         __syncthreads();
-        v.nodes = reinterpret_cast<const v4f *>(smem + sc.off_nodes);
+        v.nodes = reinterpret_cast<const v4f *>(smem + (TRG_TRAV_LDS == 3 ? sc.off_nodes4 : sc.off_nodes));
         v.tris = reinterpret_cast<const v4f *>(smem + sc.off_tris);
         v.normals = reinterpret_cast<const float *>(smem + sc.off_normals);
         v.colors = reinterpret_cast<const float *>(smem + sc.off_colors);
@@ -53,6 +53,55 @@ TRG_DEV uint32_t wave_sum(uint32_t v) {
 
 // minimum waves per SIMD the register allocator must leave room for (6 -> at most 80 VGPRs): +5 % on C2
 // over the unconstrained 91-VGPR / 5-wave build, a dozen cold values go to scratch
+// The shading event of one bounce (primaryHit, Raytracing.metal:115-215) for the lane's current ray and its
+// nearest-hit record: updates throughput / radiance / path state, moves the ray to the continuation ray and
+// returns the shadow ray to trace.  Shared by both loop shapes of render_kernel.
+struct ShadeOut { bool want_shadow, want_next; V3 sdir, scol; float smax; };
+TRG_DEV ShadeOut shade_event(const trg_uniforms &u, const SceneView &sc, const Hit &h, bool found, uint32_t b, bool last, uint32_t hidx,
+                             V3 &o, V3 &d, V3 &thr, V3 &rad, uint32_t &rmask, bool &active, V3 light_color, uint32_t &n_shaded) {
+    ShadeOut out;
+    out.want_shadow = false; out.want_next = false; out.sdir = mk(0.0f, 0.0f, 1.0f); out.scol = mk(0.0f, 0.0f, 0.0f); out.smax = -1.0f;
+    if (!found) {
+        active = false;  // Raytracing.metal:139-144
+        return out;
+    }
+    const uint32_t mat = sc.mats[h.prim];
+    if (mat == TRG_MATERIAL_DEFAULT) {
+        n_shaded++;
+        // Raytracing.metal:150-199
+        const V3 P = o + d * h.t;
+        const float cx = 1.0f - h.u - h.v, cy = h.u;  // weights of vertex 0, 1
+        const V3 vcol = interp_attr(sc.colors, h.prim, cx, cy);
+        const V3 nrm = normalize(interp_attr(sc.normals, h.prim, cx, cy));
+        float r[4];
+        // opaque copy: stops LICM from hoisting every bounce's Halton digits (all 60 dimensions) out of the
+        // bounce loop and keeping them live in VGPRs
+        uint32_t hi = hidx;
+        asm volatile("" : "+v"(hi));
+        r[2] = 0.0f; r[3] = 0.0f;
+        if (last) halton2(hi, b, r); else halton4(hi, b, r);
+        const LightSample ls = sample_area_light(u, r[0], r[1], P, nrm);
+        thr = thr * vcol;
+        o = P + nrm * 1e-3f;  // origin of both the shadow ray and the continuation ray
+        out.smax = ls.dist - 1e-3f;
+        out.sdir = ls.dir;
+        out.scol = ls.color * thr;
+        out.want_shadow = out.smax >= 0.0f;  // inactive shadow rays are not traced (MPS skips maxDistance < 0)
+        if (!last) {  // the reference also writes a continuation ray on the last bounce; nothing reads it
+            d = align_hemisphere(sample_cosine_hemisphere(r[2], r[3]), nrm);
+            out.want_next = true;
+        }
+        rmask = 1u;  // RAY_MASK_SECONDARY
+    } else if (mat == TRG_MATERIAL_EMISSIVE) {
+        rad = light_color;  // Raytracing.metal:200-209: overwrites the texel, ends the path
+        active = false;
+    } else {
+        rad = mk(1.0f, 0.0f, 1.0f);  // Raytracing.metal:210-214: magenta, ray left as is (traced again)
+        out.want_next = !last;
+    }
+    return out;
+}
+
 #ifndef TRG_EXP_WAVES
 #define TRG_EXP_WAVES 6
 #endif
@@ -103,54 +152,46 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES : TRG_EXP_WA
         bool active = valid;
         if (active) n_primary++;
 
-        for (uint32_t b = 0; b < p.bounces; ++b) {
-            if (__ballot(active) == 0ull) break;  // whole wavefront terminated
-            if (active) {
-                if (b > 0) n_bounce++;
-                Hit h;
-                const bool found = traverse<false, COUNT, trg::kBlock, !LDS_SCENE>(sc, o, d, INFINITY, rmask, h, stk, cnt);
-                if (!found) {
-                    active = false;  // Raytracing.metal:139-144
-                } else {
-                    const uint32_t mat = sc.mats[h.prim];
-                    if (mat == TRG_MATERIAL_DEFAULT) {
-                        n_shaded++;
-                        // Raytracing.metal:150-199
-                        const V3 P = o + d * h.t;
-                        const float cx = 1.0f - h.u - h.v, cy = h.u;  // weights of vertex 0, 1
-                        const V3 vcol = interp_attr(sc.colors, h.prim, cx, cy);
-                        const V3 nrm = normalize(interp_attr(sc.normals, h.prim, cx, cy));
-                        float r[4];
-                        // opaque copy: stops LICM from hoisting every bounce's Halton digits (all 60
-                        // dimensions) out of the bounce loop and keeping them live in VGPRs
-                        uint32_t hi = hidx;
-                        asm volatile("" : "+v"(hi));
-                        const bool last = (b + 1u == p.bounces);  // wave-uniform
-                        r[2] = 0.0f; r[3] = 0.0f;
-                        if (last) halton2(hi, b, r); else halton4(hi, b, r);
-                        const LightSample ls = sample_area_light(p.u, r[0], r[1], P, nrm);
-                        thr = thr * vcol;
-                        const V3 so = P + nrm * 1e-3f;
-                        const float smax = ls.dist - 1e-3f;
-                        const V3 scol = ls.color * thr;
-                        if (smax >= 0.0f) {  // inactive shadow rays are not traced (MPS skips maxDistance < 0)
-                            n_shadow++;
-                            Hit sh;
-                            const bool occluded = traverse<true, COUNT, trg::kBlock, !LDS_SCENE>(sc, so, ls.dir, smax, 1u, sh, stk, cnt);
-                            if (!occluded) rad = rad + scol;  // Raytracing.metal:240-241
-                        }
-                        if (!last) {  // the reference also writes a continuation ray on the last bounce; nothing reads it
-                            const V3 sd = sample_cosine_hemisphere(r[2], r[3]);
-                            d = align_hemisphere(sd, nrm);
-                        }
-                        o = so;
-                        rmask = 1u;  // RAY_MASK_SECONDARY
-                    } else if (mat == TRG_MATERIAL_EMISSIVE) {
-                        rad = light_color;  // Raytracing.metal:200-209: overwrites the texel, ends the path
-                        active = false;
-                    } else {
-                        rad = mk(1.0f, 0.0f, 1.0f);  // Raytracing.metal:210-214: magenta, ray left as is
+        if (LDS_SCENE) {
+            // LDS-resident scene: per bounce, a wave-synchronous nearest-hit trace, the shading event, a
+            // wave-synchronous any-hit trace.
+            for (uint32_t b = 0; b < p.bounces; ++b) {
+                if (__ballot(active) == 0ull) break;  // whole wavefront terminated
+                const bool last = (b + 1u == p.bounces);  // wave-uniform
+                if (active) {
+                    if (b > 0) n_bounce++;
+                    Hit h;
+                    const bool found = traverse<false, COUNT, trg::kBlock, false>(sc, o, d, INFINITY, rmask, h, stk, cnt);
+                    const ShadeOut so = shade_event(p.u, sc, h, found, b, last, hidx, o, d, thr, rad, rmask, active, light_color, n_shaded);
+                    if (so.want_shadow) {
+                        n_shadow++;
+                        Hit sh;
+                        const bool occluded = traverse<true, COUNT, trg::kBlock, false>(sc, o, so.sdir, so.smax, 1u, sh, stk, cnt);
+                        if (!occluded) rad = rad + so.scol;  // Raytracing.metal:240-241
                     }
+                }
+            }
+        } else {
+            // HBM-resident scene: the primary ray alone; afterwards every shading event yields a (shadow ray,
+            // continuation ray) pair that the lane traces back to back in one loop (traverse_pair): +5 % on C4.
+            // (On the LDS-resident Cornell box pairing costs 7 %: the bounce-0 shadow rays are coherent and cheap,
+            // and the incoherent continuation rays give the wavefront nothing to overlap them with.)
+            Hit h; h.t = -1.0f; h.prim = -1; h.u = 0.0f; h.v = 0.0f;
+            bool found = false;
+            if (p.bounces > 0u && active) found = traverse<false, COUNT, trg::kBlock, true>(sc, o, d, INFINITY, rmask, h, stk, cnt);
+            for (uint32_t b = 0; b < p.bounces; ++b) {
+                if (__ballot(active) == 0ull) break;
+                const bool last = (b + 1u == p.bounces);
+                ShadeOut so; so.want_shadow = false; so.want_next = false; so.sdir = mk(0.0f, 0.0f, 1.0f); so.scol = mk(0.0f, 0.0f, 0.0f); so.smax = -1.0f;
+                if (active) so = shade_event(p.u, sc, h, found, b, last, hidx, o, d, thr, rad, rmask, active, light_color, n_shaded);
+                if (__ballot(so.want_shadow || so.want_next) != 0ull) {
+                    bool occluded = false;
+                    traverse_pair<COUNT, trg::kBlock, true>(sc, o, so.want_shadow, so.sdir, so.smax, so.want_next, d, rmask, occluded, h, found, stk, cnt);
+                    if (so.want_shadow) {
+                        n_shadow++;
+                        if (!occluded) rad = rad + so.scol;
+                    }
+                    if (so.want_next) n_bounce++;
                 }
             }
         }
