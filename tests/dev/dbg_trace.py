@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0, ".")
+import sys; sys.path.insert(0, ".")  # run from the repo root: python tests/dev/<script>.py
 import numpy as np
 from oracle import pyoracle as O
 from toyraygun_amd import capi

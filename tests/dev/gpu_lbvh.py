@@ -1,5 +1,5 @@
 """GPU LBVH build (TRG_OPT_GPU_BUILD) vs host SAH build: bit-exact images (strict), build time, traversal speed."""
-import sys, time; sys.path.insert(0, ".")
+import sys, time; sys.path.insert(0, ".")  # run from the repo root: python tests/dev/<script>.py
 import numpy as np
 from oracle import pyoracle as O
 from toyraygun_amd import capi, host

@@ -1,7 +1,7 @@
 """Quick on-GPU sanity run (developer script): HIP path vs the CPU oracle on C1, timing on C2."""
 import sys, time, json
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, ".")  # run from the repo root: python tests/dev/<script>.py
 from oracle import pyoracle as O
 from toyraygun_amd import capi
 

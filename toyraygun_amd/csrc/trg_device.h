@@ -47,6 +47,22 @@ TRG_DEV float rcp_fast(float x) {
     return __builtin_amdgcn_rcpf(x);
 #endif
 }
+// sqrt / divide of the shading code: IEEE in the strict build (the oracle's arithmetic), the 1-ulp hardware
+// instructions in the shipped build (a correctly rounded sqrt or divide is ~10 instructions each on gfx950)
+TRG_DEV float sqrt_fast(float x) {
+#if TRG_STRICT
+    return sqrtf(x);
+#else
+    return __builtin_amdgcn_sqrtf(x);
+#endif
+}
+TRG_DEV float div_fast(float a, float b) {
+#if TRG_STRICT
+    return a / b;
+#else
+    return a * __builtin_amdgcn_rcpf(b);
+#endif
+}
 
 // ---------------------------------------------------------------------------------------------
 // Halton (a5): runtime/shaders/common.h:51-75, prime table extended per SURVEY F5.
@@ -312,8 +328,8 @@ TRG_DEV V3 sample_cosine_hemisphere(float ux, float uy) {
     const float phi = 2.0f * PI_F * ux;
     float sin_phi, cos_phi;
     trg_sincos(phi, sin_phi, cos_phi);
-    const float cos_theta = sqrtf(uy);
-    const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+    const float cos_theta = sqrt_fast(uy);
+    const float sin_theta = sqrt_fast(1.0f - cos_theta * cos_theta);
     return mk(sin_theta * cos_phi, cos_theta, sin_theta * sin_phi);
 }
 // common.h:95-110
@@ -334,8 +350,8 @@ TRG_DEV LightSample sample_area_light(const trg_uniforms &u, float r0, float r1,
     const V3 lf = mk(u.light_forward[0], u.light_forward[1], u.light_forward[2]);
     const V3 sp = lp + lr * ux + lu * uy;
     V3 d = sp - p;
-    const float dist = sqrtf(dot(d, d));
-    const float inv = 1.0f / fmaxf(dist, 1e-3f);
+    const float dist = sqrt_fast(dot(d, d));
+    const float inv = div_fast(1.0f, fmaxf(dist, 1e-3f));
     d = d * inv;
     V3 c = mk(u.light_color[0], u.light_color[1], u.light_color[2]);
     c = c * (inv * inv);
@@ -350,7 +366,7 @@ TRG_DEV void raygen(const trg_uniforms &u, uint32_t x, uint32_t y, uint32_t hidx
     float r0, r1;
     halton_pixel(hidx, r0, r1);
     const float px = (float)x + r0, py = (float)y + r1;
-    float uvx = px / (float)u.width, uvy = py / (float)u.height;
+    float uvx = div_fast(px, (float)u.width), uvy = div_fast(py, (float)u.height);
     uvx = uvx * 2.0f - 1.0f;
     uvy = uvy * 2.0f - 1.0f;
     const float *m = u.inv_view_proj;
@@ -358,7 +374,7 @@ TRG_DEV void raygen(const trg_uniforms &u, uint32_t x, uint32_t y, uint32_t hidx
 #pragma unroll
     for (int j = 0; j < 4; ++j) w[j] = uvx * m[j * 4 + 0] + uvy * m[j * 4 + 1] + 0.0f * m[j * 4 + 2] + 1.0f * m[j * 4 + 3];
     const V3 cam = mk(u.cam_pos[0], u.cam_pos[1], u.cam_pos[2]);
-    const V3 world = mk(w[0] / w[3], w[1] / w[3], w[2] / w[3]);
+    const V3 world = mk(div_fast(w[0], w[3]), div_fast(w[1], w[3]), div_fast(w[2], w[3]));
     org = cam;
     dir = normalize(world - cam);
 }
