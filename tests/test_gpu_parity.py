@@ -274,6 +274,57 @@ def test_gpu_built_bvh_gives_identical_images(capi, O, n):
         c.close()
 
 
+def _random_soup(O, n, seed):
+    """A hostile triangle soup inside the Cornell room: random triangles plus exact duplicates (tie-break by
+    primitive index), coplanar overlapping pairs, zero-area and needle triangles, a few emissive / masked ones."""
+    rng = np.random.default_rng(seed)
+    s = O.OracleScene.cornell_box()
+    eye = np.eye(4, dtype=np.float32)
+    ctr = rng.uniform([-0.8, 0.2, -0.8], [0.8, 1.8, 0.8], (n, 3)).astype(np.float32)
+    tri = ctr[:, None, :] + rng.normal(0, 0.12, (n, 3, 3)).astype(np.float32)
+    tri[n // 2: n // 2 + n // 10] = tri[: n // 10]                       # exact duplicates
+    tri[n // 2 + n // 10: n // 2 + n // 5, :, 1] = np.float32(1.0)        # coplanar, overlapping (y = 1 plane)
+    tri[-8:-4, 2] = tri[-8:-4, 1]                                          # zero-area (two equal vertices)
+    tri[-4:, 2] = tri[-4:, 0] + (tri[-4:, 1] - tri[-4:, 0]) * np.float32(0.5)   # zero-area (collinear)
+    mats = rng.choice([1, 1, 1, 1, 2, 3], n).astype(np.uint32)
+    for k in range(n):
+        s.add_geometry(tri[k], [0, 1, 2], eye, rng.uniform(0.2, 0.9, 3), int(mats[k]))
+    return s
+
+
+@pytest.mark.parametrize("n,seed,gpu_build", [(300, 1, 0), (300, 2, 1), (3000, 3, 0), (3000, 4, 1)])
+def test_random_triangle_soup_parity(capi, O, n, seed, gpu_build):
+    """Fuzz: the intersector and the whole path on random, partly degenerate geometry -- strict build bit-exact against
+    the oracle's brute force / BVH, host-built and GPU-built trees, both megakernels."""
+    scene = _random_soup(O, n, seed)
+    b = scene.buffers()
+    w, h = 64, 48
+    off = O.pixel_offsets(w, h)
+    c = capi.Context(w, h)
+    try:
+        c.set_option(capi.OPT_GPU_BUILD, gpu_build)
+        c.load_scene(b["positions"], b["normals"], b["colors"], b["indices"], b["material_ids"])
+        c.set_uniforms(O.uniforms_bytes(O.make_uniforms(w, h)))
+        c.set_pixel_offsets(off)
+        c.set_option(capi.OPT_STRICT, 1)
+        rays = _rays(O, 30000, 100 + seed, hi=(0.95, 1.9, 0.95))
+        ref = O.intersect_nearest(scene, rays, brute=(n <= 300))
+        got = c.trace(rays)
+        assert np.array_equal(got.view(np.uint8), ref.view(np.uint8))
+        assert np.array_equal(c.trace(rays, any_hit=True) >= 0, O.intersect_any(scene, rays) >= 0)
+        O.set_trig_mode(O.TRIG_PORTABLE)
+        img_ref, rst = O.render(scene, w, h, 2, 4, offsets=off)
+        O.set_trig_mode(O.TRIG_LIBM)
+        for k in KERNELS:
+            c.set_option(capi.OPT_KERNEL, k)
+            c.reset_stats()
+            c.render(0, 2, 4)
+            assert np.array_equal(_bits(c.read_accum()), _bits(img_ref)) and c.stats().rays == rst.rays
+    finally:
+        O.set_trig_mode(O.TRIG_LIBM)
+        c.close()
+
+
 def test_degenerate_scenes(capi, O):
     """Empty scene and a single triangle (the BVH builder synthesises the root)."""
     u = O.make_uniforms(32, 32)
