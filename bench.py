@@ -167,7 +167,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel_ms": kernel_ms, "algorithmic_bytes_per_ray": bytes_per_ray,
                          "bytes_per_launch": rays_per_launch * bytes_per_ray, **mix,
-                         "note": "scene (5.3 KB) is LDS-resident: algorithmic bytes are served from LDS, real HBM traffic is ~20 B per pixel-sample (SURVEY 8d caveat)"},
+                         "note": "the 5.8 KB scene is LDS-resident: the algorithmic bytes are served from LDS, so frac > 1 is expected; real HBM traffic (`traffic`, rocprofv3 FETCH_SIZE+WRITE_SIZE) is the offset read, the float4 write and spill scratch (SURVEY 8d caveat)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(buffers)
