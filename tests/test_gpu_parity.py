@@ -418,6 +418,73 @@ def test_golden_frames_on_gpu(capi, O, cornell, golden):
         c.close()
 
 
+@pytest.mark.parametrize("fsplit", [2, 4])
+@pytest.mark.parametrize("force_global", [0, 1])
+def test_frame_split_schedule_is_bit_exact(capi, O, cornell, fsplit, force_global):
+    """TRG_OPT_FRAME_SPLIT: 2 or 4 wavefronts share a pixel's frames and one of them folds the parked radiances in
+    frame order -- bit-identical to the oracle in the strict build (spp not a multiple of the chunk, more frames than
+    one chunk parks, ragged image sizes, continuation, row bands), within tolerance in the fast build."""
+    for (w, h, spp, bounces) in ((96, 64, 4, 3), (33, 17, 7, 5), (40, 40, 19, 2), (64, 8, 2, 3)):
+        off = O.pixel_offsets(w, h)
+        c = make_ctx(O, cornell, w, h, offsets=off)
+        try:
+            O.set_trig_mode(O.TRIG_PORTABLE)
+            ref, st = O.render(cornell, w, h, spp, bounces, offsets=off)
+            c.set_option(capi.OPT_FORCE_GLOBAL, force_global)
+            c.set_option(capi.OPT_FRAME_SPLIT, fsplit)
+            c.set_option(capi.OPT_STRICT, 1)
+            c.reset_stats()
+            c.render(0, spp, bounces)
+            img, gs = c.read_accum(), c.stats()
+            assert np.array_equal(_bits(img), _bits(ref)), (w, h, spp, bounces)
+            assert (gs.primary_rays, gs.bounce_rays, gs.shadow_rays, gs.shaded_hits) == (st.primary_rays, st.bounce_rays, st.shadow_rays, st.shaded_hits)
+            # continuation + uneven row bands, mixed with the frame-serial kernel
+            c.render(0, 1, bounces)
+            c.set_option(capi.OPT_FRAME_SPLIT, 1)
+            c.render(1, 1, bounces)
+            c.set_option(capi.OPT_FRAME_SPLIT, fsplit)
+            if spp > 2:
+                for row0, rows in ((0, 3), (3, h - 4), (h - 1, 1)):
+                    c.render(2, spp - 2, bounces, row0, rows)
+            assert np.array_equal(_bits(c.read_accum()), _bits(ref))
+            # counters instantiation
+            c.set_option(capi.OPT_COUNTERS, 1)
+            c.reset_stats()
+            c.render(0, spp, bounces)
+            assert np.array_equal(_bits(c.read_accum()), _bits(ref))
+            assert c.stats().node_fetches > 0
+            c.set_option(capi.OPT_COUNTERS, 0)
+            # fast build: tolerance against the faithful (libm) oracle
+            O.set_trig_mode(O.TRIG_LIBM)
+            ref_l, _ = O.render(cornell, w, h, spp, bounces, offsets=off)
+            c.set_option(capi.OPT_STRICT, 0)
+            c.render(0, spp, bounces)
+            rmse, frac_ok, _ = image_metrics(c.read_accum(), ref_l)
+            assert rmse <= TOL_RMSE and frac_ok >= TOL_FRAC, (rmse, frac_ok)
+        finally:
+            O.set_trig_mode(O.TRIG_LIBM)
+            c.close()
+
+
+def test_frame_split_auto_selection(capi, O, cornell):
+    """Auto mode (default) picks the frame-parallel schedule for small grids; whatever it picks, the strict result is
+    the frame-serial one bit for bit, and bad values are rejected."""
+    w, h = 320, 200
+    c = make_ctx(O, cornell, w, h)
+    try:
+        c.set_option(capi.OPT_STRICT, 1)
+        c.set_option(capi.OPT_FRAME_SPLIT, 1)
+        c.render(0, 16, 3)
+        serial = c.read_accum()
+        c.set_option(capi.OPT_FRAME_SPLIT, 0)
+        c.render(0, 16, 3)
+        assert np.array_equal(_bits(serial), _bits(c.read_accum()))
+        with pytest.raises(capi.TrgError):
+            c.set_option(capi.OPT_FRAME_SPLIT, 3)
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_continuation_bands_and_determinism(capi, O, cornell, kernel):
     """Size-independent properties: frames [0,6) == [0,2)+[2,6); union of row bands == full frame;

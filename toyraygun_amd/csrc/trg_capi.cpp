@@ -36,6 +36,7 @@ struct trg_ctx {
     bool opt_strict = false, opt_counters = false, opt_force_global = false, opt_timing = true;
     int opt_kernel = TRG_KERNEL_DIRECT;
     bool opt_gpu_build = false;
+    int opt_fsplit = 0;  // 0 = auto
     double last_build_ms = 0.0;
     bool gpu_built = false;
     uint32_t bvh_nodes = 0, bvh_depth = 0, bvh_leaves = 0;
@@ -66,7 +67,7 @@ static inline uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
 constexpr uint32_t kStackLdsLevels = 16;  // HBM scenes: stack levels kept in LDS (deeper ones spill to global scratch)
 
 struct LdsPlan { bool lds_scene; uint32_t stack_off, red_off, pool_off, total, klds, overflow_levels; };
-static int plan_lds(trg_ctx *c, LdsPlan &p, bool pool = false) {
+static int plan_lds(trg_ctx *c, LdsPlan &p, bool pool = false, uint32_t fp_slots = 0) {
     p.lds_scene = !c->opt_force_global && c->sc.lds_stage_bytes != 0 && c->sc.lds_stage_bytes <= kMaxLdsScene;
     uint32_t levels;
     if (p.lds_scene) {
@@ -85,10 +86,28 @@ static int plan_lds(trg_ctx *c, LdsPlan &p, bool pool = false) {
         const uint32_t slots = (uint32_t)kBlock * (uint32_t)kPoolS;
         p.total = p.pool_off + slots * kPoolSlotBytes + 4u * slots * 2u + 16u;  // slots, two lists of 2P u16, counters
     }
-    const uint32_t limit = pool ? 160u * 1024u : 64u * 1024u;
+    if (fp_slots) p.total = p.pool_off + fp_slots * (uint32_t)kBlock * 12u;  // render_fp_kernel: parked radiances, 3 floats x 256 pixel-frames per slot group
+    const uint32_t limit = (pool || fp_slots) ? 160u * 1024u : 64u * 1024u;  // above 64 KB the launcher opts in per kernel
     if (p.total > limit)
         return fail(c, TRG_ERR_RANGE, "BVH depth %u needs %u B of LDS per workgroup (limit %u)", c->bvh_depth, p.total, limit);
     return TRG_OK;
+}
+
+// How many wavefronts share a pixel's frames (render_fp_kernel) for a launch of `rows` rows and `spp` frames.
+// render_kernel walks the frames of a pixel serially in one lane: best while the 16x16-tile grid oversubscribes
+// the chip many times over (kResidentGroups workgroups fit at once), wasteful when it does not -- the launch then
+// ends with CUs idle behind a few workgroups' serial chains.  Splitting the frames over 4 (2) waves multiplies the
+// workgroups and divides the chain.  Measured on C2 row bands (profiles/r01/fsplit.md): 4 lanes win below ~4
+// resident sets (1/2, 1/4, 1/8 of a 1080p frame: -8 %, -18 %, -36 %) and lose above (full 1080p +1.6 %, 4K +9 %:
+// every workgroup stages the scene and folds once more per pixel).
+constexpr uint32_t kFpMaxRounds = 4;         // parked rounds per fold: 3 KB of LDS per round
+constexpr uint32_t kResidentGroups = 1536;   // 256 CUs x 6 workgroups of 4 waves at 6 waves/SIMD
+static uint32_t choose_fsplit(const trg_ctx *c, uint32_t spp, uint32_t rows) {
+    if (c->opt_fsplit == 1 || spp < 2) return 1u;
+    if (c->opt_fsplit == 2 || c->opt_fsplit == 4) return (uint32_t)c->opt_fsplit;
+    const uint64_t groups = (uint64_t)((c->w + kTileW - 1) / kTileW) * ((rows + kTileH - 1) / kTileH);
+    if (groups > 4ull * kResidentGroups) return 1u;
+    return spp >= 4 ? 4u : 2u;
 }
 
 // global scratch for the stack levels that do not fit in LDS: overflow_levels x grid_threads ints
@@ -331,8 +350,12 @@ int trg_render(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces,
     if (spp == 0 || rows == 0) { c->last_ms = 0.0; return TRG_OK; }
     HIPCHK(c, hipSetDevice(c->device));
     const bool pool = c->opt_kernel == TRG_KERNEL_POOL;
+    // frame lanes per workgroup (render_fp_kernel) -- see choose_fsplit
+    uint32_t fsplit = pool ? 1u : choose_fsplit(c, spp, rows);
+    uint32_t fp_rounds = fsplit > 1 ? std::min<uint32_t>((spp + fsplit - 1) / fsplit, kFpMaxRounds) : 0u;
     LdsPlan plan;
-    if (int rc = plan_lds(c, plan, pool)) return rc;
+    if (fsplit > 1 && c->opt_fsplit == 0 && plan_lds(c, plan, false, fp_rounds) != TRG_OK) { fsplit = 1u; fp_rounds = 0u; }  // auto: no room to park
+    if (int rc = plan_lds(c, plan, pool, fp_rounds)) return rc;
 
     RenderParams p{};
     p.u = c->u;
@@ -341,9 +364,13 @@ int trg_render(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces,
     p.accum = c->accum;
     p.counters = c->counters;
     p.frame_begin = frame_begin; p.spp = spp; p.bounces = bounces; p.row0 = row0; p.rows = rows;
-    p.tiles_x = (c->w + kTileW - 1) / kTileW;
     p.stack_off = plan.stack_off; p.red_off = plan.red_off; p.pool_off = plan.pool_off;
-    const uint32_t tiles_y = (rows + kTileH - 1) / kTileH;
+    p.fsplit = fsplit; p.fp_rounds = fp_rounds;
+    // workgroup tile: 16x16 pixels, or (4/fsplit) 8x8 sub-tiles side by side when the frames are split over waves
+    const uint32_t tile_w = fsplit > 1 ? 8u * (kWaves / fsplit) : (uint32_t)kTileW, tile_h = fsplit > 1 ? 8u : (uint32_t)kTileH;
+    p.tiles_x = (c->w + tile_w - 1) / tile_w;
+    const uint32_t tiles_y = (rows + tile_h - 1) / tile_h;
+    if ((uint64_t)p.tiles_x * tiles_y > 0x7FFFFFFFull) return fail(c, TRG_ERR_RANGE, "trg_render: grid too large");
     const uint32_t grid = p.tiles_x * tiles_y;
     if (int rc = ensure_stack_scratch(c, plan, (uint64_t)grid * kBlock, p.stack)) return rc;
 
@@ -352,6 +379,9 @@ int trg_render(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces,
     if (pool)
         e = c->opt_strict ? launch_render_pool_strict(p, plan.lds_scene, c->opt_counters, grid, plan.total, c->stream)
                           : launch_render_pool_fast(p, plan.lds_scene, c->opt_counters, grid, plan.total, c->stream);
+    else if (fsplit > 1)
+        e = c->opt_strict ? launch_render_fp_strict(p, plan.lds_scene, c->opt_counters, grid, plan.total, c->stream)
+                          : launch_render_fp_fast(p, plan.lds_scene, c->opt_counters, grid, plan.total, c->stream);
     else
         e = c->opt_strict ? launch_render_strict(p, plan.lds_scene, c->opt_counters, grid, plan.total, c->stream)
                           : launch_render_fast(p, plan.lds_scene, c->opt_counters, grid, plan.total, c->stream);
@@ -418,6 +448,10 @@ int trg_set_option(trg_ctx *c, int option, int64_t value) {
     case TRG_OPT_FORCE_GLOBAL: c->opt_force_global = value != 0; break;
     case TRG_OPT_TIMING: c->opt_timing = value != 0; break;
     case TRG_OPT_GPU_BUILD: c->opt_gpu_build = value != 0; break;
+    case TRG_OPT_FRAME_SPLIT:
+        if (value != 0 && value != 1 && value != 2 && value != 4) return fail(c, TRG_ERR_INVALID, "trg_set_option: frame split must be 0 (auto), 1, 2 or 4");
+        c->opt_fsplit = (int)value;
+        break;
     case TRG_OPT_KERNEL:
         if (value != TRG_KERNEL_DIRECT && value != TRG_KERNEL_POOL) return fail(c, TRG_ERR_INVALID, "trg_set_option: unknown kernel %lld", (long long)value);
         c->opt_kernel = (int)value;

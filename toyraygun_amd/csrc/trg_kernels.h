@@ -51,7 +51,9 @@ struct RenderParams {
     uint32_t frame_begin, spp, bounces, row0, rows, tiles_x;
     uint32_t stack_off;            // byte offset of the traversal stacks in dynamic LDS
     uint32_t red_off;              // byte offset of the counter-reduction scratch in dynamic LDS
-    uint32_t pool_off;             // render_pool_kernel: byte offset of the path pool (slots, lists, counters)
+    uint32_t pool_off;             // render_pool_kernel: byte offset of the path pool (slots, lists, counters);
+                                   // render_fp_kernel: byte offset of the parked per-frame radiances
+    uint32_t fsplit, fp_rounds;    // render_fp_kernel: frame lanes per workgroup (2 or 4), rounds parked per fold
     StackDesc stack;
 };
 
@@ -75,6 +77,8 @@ constexpr bool kWideHbm = (TRG_TRAV_HBM == 3);
                                    size_t lds_bytes, hipStream_t s);                                             \
     hipError_t launch_render_pool_##SFX(const RenderParams &p, bool lds_scene, bool counters, uint32_t grid,     \
                                         size_t lds_bytes, hipStream_t s);                                        \
+    hipError_t launch_render_fp_##SFX(const RenderParams &p, bool lds_scene, bool counters, uint32_t grid,       \
+                                      size_t lds_bytes, hipStream_t s);                                          \
     hipError_t launch_trace_##SFX(const TraceParams &p, bool lds_scene, bool any_hit, size_t lds_bytes,          \
                                   hipStream_t s);                                                                \
     hipError_t launch_halton_##SFX(const uint32_t *i, const uint32_t *d, uint32_t n, float *out, hipStream_t s); \

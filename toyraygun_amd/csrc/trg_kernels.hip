@@ -51,8 +51,6 @@ TRG_DEV uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
-// minimum waves per SIMD the register allocator must leave room for (6 -> at most 80 VGPRs): +5 % on C2
-// over the unconstrained 91-VGPR / 5-wave build, a dozen cold values go to scratch
 // The shading event of one bounce (primaryHit, Raytracing.metal:115-215) for the lane's current ray and its
 // nearest-hit record: updates throughput / radiance / path state, moves the ray to the continuation ray and
 // returns the shadow ray to trace.  Shared by both loop shapes of render_kernel.
@@ -102,6 +100,70 @@ TRG_DEV ShadeOut shade_event(const trg_uniforms &u, const SceneView &sc, const H
     return out;
 }
 
+// One path: raygen, then `bounces` x [nearest hit, shading event, shadow ray] -- the radiance this frame adds to the
+// pixel's texel (what the reference's render target holds before accumulate).  Shared by the frame-serial and the
+// frame-parallel megakernels.
+struct PathCounters { uint32_t primary, bounce, shadow, shaded; };
+template <bool LDS_SCENE, bool COUNT, typename STK>
+TRG_DEV V3 path_radiance(const trg::RenderParams &p, const SceneView &sc, STK stk, uint32_t x, uint32_t y, uint32_t hidx, bool valid,
+                         V3 light_color, PathCounters &pc, Counters &cnt) {
+    uint32_t &n_primary = pc.primary, &n_bounce = pc.bounce, &n_shadow = pc.shadow, &n_shaded = pc.shaded;
+    V3 o, d;
+    raygen(p.u, x, y, hidx, o, d);
+    V3 thr = mk(1.0f, 1.0f, 1.0f);  // ray.color
+    V3 rad = mk(0.0f, 0.0f, 0.0f);  // the render target texel of this frame
+    uint32_t rmask = 3u;            // RAY_MASK_PRIMARY
+    bool active = valid;
+    if (active) n_primary++;
+
+    if (LDS_SCENE) {
+        // LDS-resident scene: per bounce, a wave-synchronous nearest-hit trace, the shading event, a
+        // wave-synchronous any-hit trace.
+        for (uint32_t b = 0; b < p.bounces; ++b) {
+            if (__ballot(active) == 0ull) break;  // whole wavefront terminated
+            const bool last = (b + 1u == p.bounces);  // wave-uniform
+            if (active) {
+                if (b > 0) n_bounce++;
+                Hit h;
+                const bool found = traverse<false, COUNT, trg::kBlock, false>(sc, o, d, INFINITY, rmask, h, stk, cnt);
+                const ShadeOut so = shade_event(p.u, sc, h, found, b, last, hidx, o, d, thr, rad, rmask, active, light_color, n_shaded);
+                if (so.want_shadow) {
+                    n_shadow++;
+                    Hit sh;
+                    const bool occluded = traverse<true, COUNT, trg::kBlock, false>(sc, o, so.sdir, so.smax, 1u, sh, stk, cnt);
+                    if (!occluded) rad = rad + so.scol;  // Raytracing.metal:240-241
+                }
+            }
+        }
+    } else {
+        // HBM-resident scene: the primary ray alone; afterwards every shading event yields a (shadow ray,
+        // continuation ray) pair that the lane traces back to back in one loop (traverse_pair): +5 % on C4.
+        // (On the LDS-resident Cornell box pairing costs 7 %: the bounce-0 shadow rays are coherent and cheap,
+        // and the incoherent continuation rays give the wavefront nothing to overlap them with.)
+        Hit h; h.t = -1.0f; h.prim = -1; h.u = 0.0f; h.v = 0.0f;
+        bool found = false;
+        if (p.bounces > 0u && active) found = traverse<false, COUNT, trg::kBlock, true>(sc, o, d, INFINITY, rmask, h, stk, cnt);
+        for (uint32_t b = 0; b < p.bounces; ++b) {
+            if (__ballot(active) == 0ull) break;
+            const bool last = (b + 1u == p.bounces);
+            ShadeOut so; so.want_shadow = false; so.want_next = false; so.sdir = mk(0.0f, 0.0f, 1.0f); so.scol = mk(0.0f, 0.0f, 0.0f); so.smax = -1.0f;
+            if (active) so = shade_event(p.u, sc, h, found, b, last, hidx, o, d, thr, rad, rmask, active, light_color, n_shaded);
+            if (__ballot(so.want_shadow || so.want_next) != 0ull) {
+                bool occluded = false;
+                traverse_pair<COUNT, trg::kBlock, true>(sc, o, so.want_shadow, so.sdir, so.smax, so.want_next, d, rmask, occluded, h, found, stk, cnt);
+                if (so.want_shadow) {
+                    n_shadow++;
+                    if (!occluded) rad = rad + so.scol;
+                }
+                if (so.want_next) n_bounce++;
+            }
+        }
+    }
+    return rad;
+}
+
+// minimum waves per SIMD the register allocator must leave room for (6 -> at most 80 VGPRs): +5 % on C2
+// over the unconstrained 91-VGPR / 5-wave build, a dozen cold values go to scratch
 #ifndef TRG_EXP_WAVES
 #define TRG_EXP_WAVES 6
 #endif
@@ -133,7 +195,7 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES : TRG_EXP_WA
     const bool valid = (x < p.u.width) && (y < p.row0 + p.rows) && (y < p.u.height);
     const uint32_t pix = y * p.u.width + x;
 
-    uint32_t n_primary = 0, n_bounce = 0, n_shadow = 0, n_shaded = 0;
+    PathCounters pc; pc.primary = 0; pc.bounce = 0; pc.shadow = 0; pc.shaded = 0;
     Counters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.wnodes = 0; cnt.wtris = 0;
 
     const uint32_t offset = valid ? p.offsets[pix] : 0u;
@@ -144,57 +206,7 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES : TRG_EXP_WA
 
     for (uint32_t f = p.frame_begin; f < p.frame_begin + p.spp; ++f) {
         const uint32_t hidx = offset + f;  // Raytracing.metal:67: offset + uniforms.frameIndex (wraps mod 2^32)
-        V3 o, d;
-        raygen(p.u, x, y, hidx, o, d);
-        V3 thr = mk(1.0f, 1.0f, 1.0f);  // ray.color
-        V3 rad = mk(0.0f, 0.0f, 0.0f);  // the render target texel of this frame
-        uint32_t rmask = 3u;            // RAY_MASK_PRIMARY
-        bool active = valid;
-        if (active) n_primary++;
-
-        if (LDS_SCENE) {
-            // LDS-resident scene: per bounce, a wave-synchronous nearest-hit trace, the shading event, a
-            // wave-synchronous any-hit trace.
-            for (uint32_t b = 0; b < p.bounces; ++b) {
-                if (__ballot(active) == 0ull) break;  // whole wavefront terminated
-                const bool last = (b + 1u == p.bounces);  // wave-uniform
-                if (active) {
-                    if (b > 0) n_bounce++;
-                    Hit h;
-                    const bool found = traverse<false, COUNT, trg::kBlock, false>(sc, o, d, INFINITY, rmask, h, stk, cnt);
-                    const ShadeOut so = shade_event(p.u, sc, h, found, b, last, hidx, o, d, thr, rad, rmask, active, light_color, n_shaded);
-                    if (so.want_shadow) {
-                        n_shadow++;
-                        Hit sh;
-                        const bool occluded = traverse<true, COUNT, trg::kBlock, false>(sc, o, so.sdir, so.smax, 1u, sh, stk, cnt);
-                        if (!occluded) rad = rad + so.scol;  // Raytracing.metal:240-241
-                    }
-                }
-            }
-        } else {
-            // HBM-resident scene: the primary ray alone; afterwards every shading event yields a (shadow ray,
-            // continuation ray) pair that the lane traces back to back in one loop (traverse_pair): +5 % on C4.
-            // (On the LDS-resident Cornell box pairing costs 7 %: the bounce-0 shadow rays are coherent and cheap,
-            // and the incoherent continuation rays give the wavefront nothing to overlap them with.)
-            Hit h; h.t = -1.0f; h.prim = -1; h.u = 0.0f; h.v = 0.0f;
-            bool found = false;
-            if (p.bounces > 0u && active) found = traverse<false, COUNT, trg::kBlock, true>(sc, o, d, INFINITY, rmask, h, stk, cnt);
-            for (uint32_t b = 0; b < p.bounces; ++b) {
-                if (__ballot(active) == 0ull) break;
-                const bool last = (b + 1u == p.bounces);
-                ShadeOut so; so.want_shadow = false; so.want_next = false; so.sdir = mk(0.0f, 0.0f, 1.0f); so.scol = mk(0.0f, 0.0f, 0.0f); so.smax = -1.0f;
-                if (active) so = shade_event(p.u, sc, h, found, b, last, hidx, o, d, thr, rad, rmask, active, light_color, n_shaded);
-                if (__ballot(so.want_shadow || so.want_next) != 0ull) {
-                    bool occluded = false;
-                    traverse_pair<COUNT, trg::kBlock, true>(sc, o, so.want_shadow, so.sdir, so.smax, so.want_next, d, rmask, occluded, h, found, stk, cnt);
-                    if (so.want_shadow) {
-                        n_shadow++;
-                        if (!occluded) rad = rad + so.scol;
-                    }
-                    if (so.want_next) n_bounce++;
-                }
-            }
-        }
+        const V3 rad = path_radiance<LDS_SCENE, COUNT>(p, sc, stk, x, y, hidx, valid, light_color, pc, cnt);
         // Accumulate.metal:19-39
         if (f == 0) {
             acc = rad;
@@ -212,7 +224,103 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES : TRG_EXP_WA
 
     // ray counters: wavefront reduce -> workgroup reduce in LDS -> one atomic per counter per workgroup,
     // spread over kCounterSlots slots
-    uint32_t vals[8] = { n_primary, n_bounce, n_shadow, n_shaded, cnt.nodes, cnt.tris, cnt.wnodes, cnt.wtris };
+    uint32_t vals[8] = { pc.primary, pc.bounce, pc.shadow, pc.shaded, cnt.nodes, cnt.tris, cnt.wnodes, cnt.wtris };
+    uint32_t *red = reinterpret_cast<uint32_t *>(smem + p.red_off);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (!COUNT && k >= 4) break;
+        const uint32_t s = wave_sum(vals[k]);
+        if (lane == 0) red[wave * 8 + k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < (COUNT ? 8 : 4)) {
+        const uint32_t k = threadIdx.x;
+        unsigned long long s = 0;
+        for (int wv = 0; wv < trg::kWaves; ++wv) s += red[wv * 8 + k];
+        if (s) atomicAdd(&p.counters[(blockIdx.x % trg::kCounterSlots) * trg::kCounterWords + k], s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// render_fp_kernel: the frame-parallel schedule of the same megakernel, for launches whose pixel grid alone does
+// not fill the chip (a row band of a multi-GPU job, a small window).  render_kernel gives a pixel to ONE lane that
+// walks its `spp` frames one after the other, so a launch of fewer workgroups than the 256 CUs can hold takes as
+// long as that serial chain however idle the machine is.  Here a workgroup covers 4/F 8x8 sub-tiles side by side
+// and F "frame lanes": wave (sub, fl) traces frames fl, fl+F, fl+2F ... of its sub-tile and parks each frame's
+// radiance in LDS; after every R rounds the fl=0 wave of each sub-tile folds the parked radiances into the running
+// average IN FRAME ORDER -- the same float operations in the same order as Accumulate.metal, so the result is
+// bit-identical to render_kernel's (strict build tested bit-exact against the oracle and against render_kernel).
+// F x as many workgroups, each with 1/F of the serial work.
+// ---------------------------------------------------------------------------------------------
+template <bool LDS_SCENE, bool COUNT>
+__global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES : TRG_EXP_WAVES_HBM) void render_fp_kernel(const trg::RenderParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const SceneView sc = scene_view<LDS_SCENE>(p.sc, smem);
+    LdsStackT<trg::kBlock, !LDS_SCENE> stk;
+    stk.base = reinterpret_cast<int *>(smem + p.stack_off) + threadIdx.x;
+    stk.klds = (int)p.stack.klds;
+    stk.gstride = gridDim.x * trg::kBlock;
+    stk.gbase = p.stack.overflow ? p.stack.overflow + (size_t)blockIdx.x * trg::kBlock + threadIdx.x : nullptr;
+
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t F = p.fsplit, subt = trg::kWaves / F;   // frame lanes, sub-tiles per workgroup (F in {2,4})
+    const uint32_t sub = wave % subt, fl = wave / subt;
+    const uint32_t tiles_y = gridDim.x / p.tiles_x;          // centre-out tile order, as render_kernel
+    const uint32_t crank = blockIdx.x / tiles_y, by = blockIdx.x % tiles_y;
+    const uint32_t cleft = (p.tiles_x - 1u) / 2u;
+    const uint32_t bx = (crank & 1u) ? cleft + 1u + crank / 2u : cleft - crank / 2u;
+    const uint32_t x = (bx * subt + sub) * 8u + (lane & 7);
+    const uint32_t y = p.row0 + by * 8u + (lane >> 3);
+    const bool valid = (x < p.u.width) && (y < p.row0 + p.rows) && (y < p.u.height);
+    const uint32_t pix = y * p.u.width + x;
+
+    PathCounters pc; pc.primary = 0; pc.bounce = 0; pc.shadow = 0; pc.shaded = 0;
+    Counters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.wnodes = 0; cnt.wtris = 0;
+
+    const uint32_t offset = valid ? p.offsets[pix] : 0u;
+    v4f *accum = reinterpret_cast<v4f *>(p.accum);
+    V3 acc = mk(0.0f, 0.0f, 0.0f);
+    if (fl == 0 && valid && p.frame_begin > 0) { const v4f a = accum[pix]; acc = mk(a.x, a.y, a.z); }
+    const V3 light_color = mk(p.u.light_color[0], p.u.light_color[1], p.u.light_color[2]);
+
+    // parked radiance: slot-major, component, then the 64*subt pixels of the workgroup (conflict-free rows)
+    float *park = reinterpret_cast<float *>(smem + p.pool_off);
+    const uint32_t npx = 64u * subt, mypx = sub * 64u + lane;
+    const uint32_t chunk = p.fp_rounds * F;
+    for (uint64_t rel = 0; rel < p.spp; rel += chunk) {
+        for (uint32_t r = 0; r < p.fp_rounds; ++r) {
+            const uint64_t i = rel + (uint64_t)r * F + fl;
+            if (i >= p.spp) break;   // wave-uniform
+            const uint32_t hidx = offset + p.frame_begin + (uint32_t)i;  // Raytracing.metal:67
+            const V3 rad = path_radiance<LDS_SCENE, COUNT>(p, sc, stk, x, y, hidx, valid, light_color, pc, cnt);
+            float *slot = park + (size_t)(r * F + fl) * 3u * npx + mypx;
+            slot[0] = rad.x; slot[npx] = rad.y; slot[2u * npx] = rad.z;
+        }
+        __syncthreads();
+        if (fl == 0) {
+            for (uint32_t s = 0; s < chunk && rel + s < p.spp; ++s) {
+                const uint32_t f = p.frame_begin + (uint32_t)(rel + s);
+                const float *slot = park + (size_t)s * 3u * npx + mypx;
+                const V3 rad = mk(slot[0], slot[npx], slot[2u * npx]);
+                // Accumulate.metal:19-39
+                if (f == 0) {
+                    acc = rad;
+                } else {
+                    const V3 prev = acc * (float)f;
+                    const V3 c = rad + prev;
+                    const float f1 = (float)(f + 1u);
+                    acc = mk(c.x / f1, c.y / f1, c.z / f1);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (fl == 0 && valid) {
+        v4f outv; outv.x = acc.x; outv.y = acc.y; outv.z = acc.z; outv.w = 1.0f;
+        accum[pix] = outv;
+    }
+
+    uint32_t vals[8] = { pc.primary, pc.bounce, pc.shadow, pc.shaded, cnt.nodes, cnt.tris, cnt.wnodes, cnt.wtris };
     uint32_t *red = reinterpret_cast<uint32_t *>(smem + p.red_off);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -537,6 +645,15 @@ hipError_t SFX(launch_render_pool)(const RenderParams &p, bool lds_scene, bool c
     }
     if (counters) return launch_big_lds(render_pool_kernel<false, true, S>, p, grid, lds_bytes, s);
     return launch_big_lds(render_pool_kernel<false, false, S>, p, grid, lds_bytes, s);
+}
+
+hipError_t SFX(launch_render_fp)(const RenderParams &p, bool lds_scene, bool counters, uint32_t grid, size_t lds_bytes, hipStream_t s) {
+    if (lds_scene) {
+        if (counters) return launch_big_lds(render_fp_kernel<true, true>, p, grid, lds_bytes, s);
+        return launch_big_lds(render_fp_kernel<true, false>, p, grid, lds_bytes, s);
+    }
+    if (counters) return launch_big_lds(render_fp_kernel<false, true>, p, grid, lds_bytes, s);
+    return launch_big_lds(render_fp_kernel<false, false>, p, grid, lds_bytes, s);
 }
 
 hipError_t SFX(launch_trace)(const TraceParams &p, bool lds_scene, bool any_hit, size_t lds_bytes, hipStream_t s) {
