@@ -5,7 +5,7 @@ cd /root/repo
 name=$1; shift
 out=exp_build/$name; mkdir -p $out
 C=${SRC:-toyraygun_amd/csrc}
-F="-O3 -std=c++17 -fPIC -fvisibility=hidden -Iinclude -I/root/repo/toyraygun_amd/csrc --offload-arch=gfx950"
+F="-O3 -std=c++17 -fPIC -fno-slp-vectorize -fvisibility=hidden -Iinclude -I/root/repo/toyraygun_amd/csrc --offload-arch=gfx950"
 hipcc $F -DTRG_STRICT=0 "$@" -c $C/trg_kernels.hip -o $out/kf.o &
 hipcc $F -DTRG_STRICT=1 -ffp-contract=off "$@" -c $C/trg_kernels.hip -o $out/ks.o &
 hipcc $F -x hip "$@" -c $C/trg_capi.cpp -o $out/capi.o &

@@ -54,11 +54,15 @@ def build(force=False, verbose=False):
     common = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include")]
     hidden = ["-fvisibility=hidden"]
     dev = ["--offload-arch=" + ARCH]
+    # -fno-slp-vectorize: the SLP vectoriser pairs the Halton digit chains of two dimensions into v_pk_mul_f32 /
+    # v_pk_fma_f32, which are not faster than two scalar ops on gfx950 and cost 10 VGPRs + scratch spills
+    # (80 VGPRs + 48 B scratch -> 70 VGPRs, none): +9 % on C2, +2.5 % on C4 (profiles/r01/experiments.md)
+    kern = dev + ["-fno-slp-vectorize"]
 
     objs = []
     units = [
-        ("trg_kernels_fast.o", os.path.join(CSRC, "trg_kernels.hip"), dev + ["-DTRG_STRICT=0"]),
-        ("trg_kernels_strict.o", os.path.join(CSRC, "trg_kernels.hip"), dev + ["-DTRG_STRICT=1", "-ffp-contract=off"]),
+        ("trg_kernels_fast.o", os.path.join(CSRC, "trg_kernels.hip"), kern + ["-DTRG_STRICT=0"]),
+        ("trg_kernels_strict.o", os.path.join(CSRC, "trg_kernels.hip"), kern + ["-DTRG_STRICT=1", "-ffp-contract=off"]),
         ("trg_build.o", os.path.join(CSRC, "trg_build.hip"), dev),
         ("trg_capi.o", os.path.join(CSRC, "trg_capi.cpp"), ["-x", "hip", "--offload-arch=" + ARCH]),
         ("bvh_build.o", os.path.join(CSRC, "bvh_build.cpp"), ["-x", "hip", "--offload-arch=" + ARCH]),

@@ -101,7 +101,7 @@ static int plan_lds(trg_ctx *c, LdsPlan &p, bool pool = false, uint32_t fp_slots
 // resident sets (1/2, 1/4, 1/8 of a 1080p frame: -8 %, -18 %, -36 %) and lose above (full 1080p +1.6 %, 4K +9 %:
 // every workgroup stages the scene and folds once more per pixel).
 constexpr uint32_t kFpMaxRounds = 4;         // parked rounds per fold: 3 KB of LDS per round
-constexpr uint32_t kResidentGroups = 1536;   // 256 CUs x 6 workgroups of 4 waves at 6 waves/SIMD
+constexpr uint32_t kResidentGroups = 1536;   // 256 CUs x 6 workgroups of 4 waves (the HBM kernels' 6 waves/SIMD; LDS scenes: 8)
 static uint32_t choose_fsplit(const trg_ctx *c, uint32_t spp, uint32_t rows) {
     if (c->opt_fsplit == 1 || spp < 2) return 1u;
     if (c->opt_fsplit == 2 || c->opt_fsplit == 4) return (uint32_t)c->opt_fsplit;

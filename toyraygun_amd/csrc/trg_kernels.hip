@@ -162,10 +162,11 @@ TRG_DEV V3 path_radiance(const trg::RenderParams &p, const SceneView &sc, STK st
     return rad;
 }
 
-// minimum waves per SIMD the register allocator must leave room for (6 -> at most 80 VGPRs): +5 % on C2
-// over the unconstrained 91-VGPR / 5-wave build, a dozen cold values go to scratch
+// minimum waves per SIMD the register allocator must leave room for.  Scene in LDS: 8 (at most 64 VGPRs; VALU-bound,
+// more waves hide the LDS latency: +3 % C2, +5 % at 8 bounces over 6).  Scene in HBM: 6 (at most 80 VGPRs; 8 spills
+// the 4-wide node registers and is 35 % slower, 5 loses 5 % of latency hiding).
 #ifndef TRG_EXP_WAVES
-#define TRG_EXP_WAVES 6
+#define TRG_EXP_WAVES 8
 #endif
 #ifndef TRG_EXP_WAVES_HBM
 #define TRG_EXP_WAVES_HBM 6
@@ -252,8 +253,11 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES : TRG_EXP_WA
 // bit-identical to render_kernel's (strict build tested bit-exact against the oracle and against render_kernel).
 // F x as many workgroups, each with 1/F of the serial work.
 // ---------------------------------------------------------------------------------------------
+#ifndef TRG_EXP_WAVES_FP
+#define TRG_EXP_WAVES_FP 6   // its grids do not fill the chip anyway: 80 VGPRs without spills beats 8 waves by 1.5 %
+#endif
 template <bool LDS_SCENE, bool COUNT>
-__global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES : TRG_EXP_WAVES_HBM) void render_fp_kernel(const trg::RenderParams p) {
+__global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES_FP : TRG_EXP_WAVES_HBM) void render_fp_kernel(const trg::RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const SceneView sc = scene_view<LDS_SCENE>(p.sc, smem);
     LdsStackT<trg::kBlock, !LDS_SCENE> stk;
