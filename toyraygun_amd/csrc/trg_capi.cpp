@@ -267,13 +267,14 @@ int trg_load_scene(trg_ctx *c, const float *pos, const float *nrm, const float *
     // [ BVH2 nodes | triangle records | normals | colours | material ids ] [ 4-wide nodes | 128 B pad ]
     // The first bracket is what a workgroup stages into LDS when it is small enough; scenes that can only be
     // traversed from HBM skip the BVH2 nodes when the HBM kernels use the 4-wide tree.
-    const uint64_t small_bytes = (uint64_t)bvh.n_nodes * 64u + (uint64_t)nt_rec * 48u + (uint64_t)attr_tris * 76u + 64u;
+    const uint64_t small_bytes = (uint64_t)bvh.n_nodes * kLdsNodeBytes + (uint64_t)nt_rec * 48u + (uint64_t)attr_tris * 76u + 64u;
     const bool lds_candidate = small_bytes <= kMaxLdsScene;
     const bool keep_bvh2 = lds_candidate || !kWideHbm;
     SceneDesc sc{};
     sc.n_nodes = keep_bvh2 ? bvh.n_nodes : 0u; sc.n_tris = n_tris;
     sc.off_nodes = 0;
-    sc.off_tris = align16(sc.off_nodes + sc.n_nodes * 64u);
+    const uint32_t node_bytes = lds_candidate ? kLdsNodeBytes : 64u;
+    sc.off_tris = align16(sc.off_nodes + sc.n_nodes * node_bytes);
     sc.off_normals = align16(sc.off_tris + nt_rec * 48u);
     sc.off_colors = align16(sc.off_normals + attr_tris * 36u);
     sc.off_mats = align16(sc.off_colors + attr_tris * 36u);
@@ -288,7 +289,30 @@ int trg_load_scene(trg_ctx *c, const float *pos, const float *nrm, const float *
     if (total > 0xFFFFFFF0ull) return fail(c, TRG_ERR_RANGE, "trg_load_scene: scene needs %llu B on the device (limit 4 GiB)", (unsigned long long)total);
     sc.blob_bytes = (uint32_t)total;
     std::vector<unsigned char> host(sc.blob_bytes, 0);
-    if (sc.n_nodes) memcpy(&host[sc.off_nodes], bvh.nodes.data(), (size_t)sc.n_nodes * 64u);
+    if (sc.n_nodes && lds_candidate && kSignedLds) {
+        // sign-ordered LDS nodes (trav_node_step_signed): per axis the slab planes of both children as
+        // (lo_a, hi_a, lo_b, hi_b) and swapped; children of inner nodes become byte offsets
+        for (uint32_t i = 0; i < sc.n_nodes; ++i) {
+            const F4 *n = &bvh.nodes[(size_t)i * 4];  // (ax0,ax1,ay0,ay1) (bx0,bx1,by0,by1) (az0,az1,bz0,bz1) (c0,c1,-,-)
+            float *o = reinterpret_cast<float *>(&host[sc.off_nodes + (size_t)i * kLdsNodeBytes]);
+            const float px[4] = { n[0].x, n[0].y, n[1].x, n[1].y }, py[4] = { n[0].z, n[0].w, n[1].z, n[1].w };
+            const float pz[4] = { n[2].x, n[2].y, n[2].z, n[2].w };
+            const float *axes[3] = { px, py, pz };
+            for (int a = 0; a < 3; ++a) {
+                const float *p = axes[a];
+                float *q = o + a * 8;
+                q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; q[3] = p[3];
+                q[4] = p[1]; q[5] = p[0]; q[6] = p[3]; q[7] = p[2];
+            }
+            int32_t ch[2];
+            memcpy(ch, &n[3].x, 8);
+            for (int k = 0; k < 2; ++k)
+                if (ch[k] >= 0) ch[k] *= (int32_t)kLdsNodeBytes;
+            memcpy(o + 24, ch, 8);
+        }
+    } else if (sc.n_nodes) {
+        memcpy(&host[sc.off_nodes], bvh.nodes.data(), (size_t)sc.n_nodes * 64u);
+    }
     memcpy(&host[sc.off_tris], bvh.tris.data(), bvh.tris.size() * sizeof(F4));
     float *hn = reinterpret_cast<float *>(&host[sc.off_normals]);
     float *hc = reinterpret_cast<float *>(&host[sc.off_colors]);

@@ -443,6 +443,7 @@ struct Trav {
     Hit hit;
     bool found;
     int node, sp;
+    int sx, sy, sz;  // sign-ordered LDS nodes (TRG_TRAV_LDS == 4): byte offset of the slab pair to read per axis
 };
 
 TRG_DEV void trav_begin(Trav &tv, V3 o, V3 d, float tmax, uint32_t rmask) {
@@ -459,6 +460,10 @@ TRG_DEV void trav_begin(Trav &tv, V3 o, V3 d, float tmax, uint32_t rmask) {
     tv.hit.t = -1.0f; tv.hit.prim = -1; tv.hit.u = 0.0f; tv.hit.v = 0.0f;
     tv.found = false;
     tv.node = 0; tv.sp = 0;
+    // slab copy per axis: +0 when the ray travels towards +axis (near plane = lo), +16 when it travels towards -axis
+    tv.sx = (int)((__float_as_uint(dx) >> 31) << 4);
+    tv.sy = 32 + (int)((__float_as_uint(dy) >> 31) << 4);
+    tv.sz = 64 + (int)((__float_as_uint(dz) >> 31) << 4);
 }
 
 // One inner-node step: test both child boxes, descend into the nearer hit child, push the other, or pop.
@@ -494,8 +499,47 @@ TRG_DEV void trav_node_math(const v4f n0, const v4f n1, const v4f n2, const v4f 
     tv.node = next; tv.sp = sp;
 }
 
+// The same step on a SIGN-ORDERED node (LDS-resident scenes, TRG_TRAV_LDS == 4).  A 112-byte node keeps, per axis,
+// the four slab planes of its two children twice: as (lo_a, hi_a, lo_b, hi_b) and as (hi_a, lo_a, hi_b, lo_b).  A
+// lane reads the copy that matches the sign of its ray direction (an address offset fixed per ray), so x = near
+// plane, y = far plane without the 12 min/max that order them -- the values are the same floats the min/max would
+// pick (the slab product is monotonic in the plane), so hits are unchanged.  Children are byte offsets of nodes
+// (>= 0) or leaf codes (< 0); 112 = 28 banks, so random nodes spread over 16 bank groups like the 64-byte layout.
+constexpr int kSignedNodeBytes = 112;
 template <bool COUNT, int BLOCK, typename STK>
+TRG_DEV void trav_node_step_signed(const SceneView &sc, Trav &tv, STK stk, Counters &cnt) {
+    if (COUNT) { cnt.nodes++; if (mbcnt64(__ballot(1)) == 0) cnt.wnodes++; }
+    const char *n = reinterpret_cast<const char *>(sc.nodes) + tv.node;
+    const v4f X = *reinterpret_cast<const v4f *>(n + tv.sx);
+    const v4f Y = *reinterpret_cast<const v4f *>(n + tv.sy);
+    const v4f Z = *reinterpret_cast<const v4f *>(n + tv.sz);
+    const int c0 = *reinterpret_cast<const int *>(n + 96), c1 = *reinterpret_cast<const int *>(n + 100);
+    const float anx = X.x * tv.idx - tv.oix, afx = X.y * tv.idx - tv.oix, bnx = X.z * tv.idx - tv.oix, bfx = X.w * tv.idx - tv.oix;
+    const float any_ = Y.x * tv.idy - tv.oiy, afy = Y.y * tv.idy - tv.oiy, bny = Y.z * tv.idy - tv.oiy, bfy = Y.w * tv.idy - tv.oiy;
+    const float anz = Z.x * tv.idz - tv.oiz, afz = Z.y * tv.idz - tv.oiz, bnz = Z.z * tv.idz - tv.oiz, bfz = Z.w * tv.idz - tv.oiz;
+    const float amin = fmaxf(fmaxf(anx, any_), fmaxf(anz, 0.0f));
+    const float amax = fminf(fminf(afx, afy), fminf(afz, tv.best));
+    const float bmin = fmaxf(fmaxf(bnx, bny), fmaxf(bnz, 0.0f));
+    const float bmax = fminf(fminf(bfx, bfy), fminf(bfz, tv.best));
+    const bool ha = amin <= amax, hb = bmin <= bmax;
+    const bool both = ha && hb, none = !(ha || hb);
+    const bool first1 = hb && (!ha || bmin < amin);
+    const int nearc = first1 ? c1 : c0, farc = first1 ? c0 : c1;
+    if (both) stk.push(tv.sp, farc);
+    int sp = tv.sp + (both ? 1 : 0);
+    int next = nearc;
+    if (none) {
+        const bool empty = sp == 0;
+        sp -= empty ? 0 : 1;
+        const int popped = stk.pop(sp);
+        next = empty ? kNodeDone : popped;
+    }
+    tv.node = next; tv.sp = sp;
+}
+
+template <bool COUNT, int BLOCK, bool SIGNED = false, typename STK>
 TRG_DEV void trav_node_step(const SceneView &sc, Trav &tv, STK stk, Counters &cnt) {
+    if (SIGNED) { trav_node_step_signed<COUNT, BLOCK>(sc, tv, stk, cnt); return; }
     const v4f *n = sc.nodes + tv.node * 4;
     const v4f n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
     trav_node_math<COUNT, BLOCK>(n0, n1, n2, n3, tv, stk, cnt);
@@ -640,11 +684,12 @@ TRG_DEV void trav_step_unified(const SceneView &sc, Trav &tv, bool any, STK stk,
     }
 }
 
-// traversal schedules: 0 = while-while on BVH2, 1 = unified step on BVH2 (node + triangle every iteration),
+// traversal schedules: 0 = while-while on BVH2, 4 = while-while on sign-ordered BVH2 nodes (LDS scenes only; the host
+// stages that layout when TRG_TRAV_LDS == 4), 1 = unified step on BVH2 (node + triangle every iteration),
 // 3 = unified step on the 4-wide tree (the host uploads 4-wide nodes for HBM scenes when TRG_TRAV_HBM == 3).  (A third schedule,
 // one block kind per iteration chosen by a lane-count vote, measured no better on C4 and 9 % worse on C2.)
 #ifndef TRG_TRAV_LDS
-#define TRG_TRAV_LDS 0
+#define TRG_TRAV_LDS 4
 #endif
 #ifndef TRG_TRAV_HBM
 #define TRG_TRAV_HBM 3
@@ -667,7 +712,7 @@ TRG_DEV bool traverse(const SceneView &sc, V3 o, V3 d, float tmax_ray, uint32_t 
         while (tv.node != kNodeDone) trav_step_unified<COUNT, BLOCK>(sc, tv, ANY, stk, cnt);
     } else {
         for (;;) {
-            while (tv.node >= 0) trav_node_step<COUNT, BLOCK>(sc, tv, stk, cnt);
+            while (tv.node >= 0) trav_node_step<COUNT, BLOCK, mode == 4>(sc, tv, stk, cnt);
             if (tv.node == kNodeDone) break;
             trav_leaf_step<COUNT, BLOCK>(sc, tv, ANY, stk, cnt);
             if (tv.node == kNodeDone) break;
@@ -699,7 +744,7 @@ TRG_DEV void traverse_pair(const SceneView &sc, V3 org, bool has_shadow, V3 sdir
         } else if (mode == 1) {
             trav_step_unified<COUNT, BLOCK>(sc, tv, any, stk, cnt);
         } else {
-            while (tv.node >= 0) trav_node_step<COUNT, BLOCK>(sc, tv, stk, cnt);
+            while (tv.node >= 0) trav_node_step<COUNT, BLOCK, mode == 4>(sc, tv, stk, cnt);
             if (tv.node != kNodeDone) trav_leaf_step<COUNT, BLOCK>(sc, tv, any, stk, cnt);
         }
         if (tv.node == kNodeDone) {
@@ -782,7 +827,7 @@ TRG_DEV void trace_queue(const SceneView &sc, const PoolView pv, const unsigned 
                 } else if (mode == 1) {
                     trav_step_unified<COUNT, BLOCK>(sc, tv, any, stk, cnt);
                 } else {
-                    while (tv.node >= 0) trav_node_step<COUNT, BLOCK>(sc, tv, stk, cnt);
+                    while (tv.node >= 0) trav_node_step<COUNT, BLOCK, mode == 4>(sc, tv, stk, cnt);
                     if (tv.node == kNodeDone) break;
                     trav_leaf_step<COUNT, BLOCK>(sc, tv, any, stk, cnt);
                 }

@@ -71,6 +71,13 @@ struct TraceParams {
 #define TRG_TRAV_HBM 3
 #endif
 constexpr bool kWideHbm = (TRG_TRAV_HBM == 3);
+// which node layout LDS-resident scenes are staged in; must match TRG_TRAV_LDS in trg_device.h
+#ifndef TRG_TRAV_LDS
+#define TRG_TRAV_LDS 4
+#endif
+constexpr bool kSignedLds = (TRG_TRAV_LDS == 4);
+constexpr uint32_t kLdsNodeBytes = kSignedLds ? 112u : 64u;
+static_assert(!kSignedLds || kWideHbm, "sign-ordered LDS nodes replace the BVH2 array: the HBM kernels must use the 4-wide tree");
 
 #define TRG_DECL_LAUNCHERS(SFX)                                                                                   \
     hipError_t launch_render_##SFX(const RenderParams &p, bool lds_scene, bool counters, uint32_t grid,          \
