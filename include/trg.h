@@ -167,6 +167,12 @@ TRG_API int trg_debug_build_bvh(const float *positions3, const uint32_t *indices
 TRG_API int trg_debug_build_bvh4(const float *positions3, const uint32_t *indices, const uint32_t *material_ids, uint32_t n_verts,
                                  uint32_t n_tris, float *nodes4_out, uint32_t nodes4_cap, uint32_t *n_nodes4, uint32_t *depth4);
 
+/* host-only: the same 4-wide nodes in the 64-byte quantised form the HBM kernels actually load (16 dwords per node:
+ * origin.xyz scale.x | qlo.x qhi.x qlo.y qhi.y | qlo.z qhi.z scale.y scale.z | child[4]; one byte per child in each
+ * q dword; plane = origin + q * scale).  Node i of this array is node i of trg_debug_build_bvh4. */
+TRG_API int trg_debug_build_bvh4q(const float *positions3, const uint32_t *indices, const uint32_t *material_ids, uint32_t n_verts,
+                                  uint32_t n_tris, uint32_t *nodes4q_out, uint32_t nodes4_cap, uint32_t *n_nodes4);
+
 /* --- N1: ACES tonemap + sRGB of the accumulation buffer to RGBA8 (PostProcessing.metal:44-57;
  *     common.h:36-43,163-171).  flip_y != 0 writes the top image row first (PNG order). */
 TRG_API int trg_postprocess(trg_ctx *ctx, uint8_t *rgba8, int flip_y);

@@ -226,6 +226,42 @@ def test_wide_bvh_is_sound(built, O):
         assert depth4 <= 20
 
 
+def test_quantised_wide_nodes_are_conservative(built, O):
+    """The 64-byte quantised nodes the HBM kernels load (q4node.h): every decoded child box contains the float box it
+    was made from (so no triangle the float tree reaches can be culled), is tight to within one quantisation step,
+    children are unchanged, unused slots decode to an inverted box, scales are powers of two."""
+    from toyraygun_amd import capi
+    rng = np.random.default_rng(7)
+    soup = rng.uniform(-50, 50, (300, 1, 3)).astype(np.float32) + rng.normal(0, 0.5, (300, 3, 3)).astype(np.float32)
+    scenes = [O.OracleScene.cornell_box().buffers(), O.OracleScene.cornell_lattice(6).buffers(), O.OracleScene().buffers(),
+              dict(positions=soup.reshape(-1, 3), indices=np.arange(900, dtype=np.uint32), material_ids=np.ones(300, np.uint32)),
+              # flat (zero extent on one axis) and far from the origin
+              dict(positions=np.array([[1e4, 5, 0], [1e4 + 1, 5, 0], [1e4, 5, 1], [1e4 + 2, 5, 3], [1e4 + 3, 5, 3], [1e4 + 2, 5, 4]], np.float32),
+                   indices=np.arange(6, dtype=np.uint32), material_ids=np.ones(2, np.uint32))]
+    for b in scenes:
+        nodes4, _ = capi.debug_build_bvh4(b["positions"], b["indices"], b["material_ids"])
+        q = capi.debug_build_bvh4q(b["positions"], b["indices"], b["material_ids"])
+        assert q.shape == (nodes4.shape[0], 16)
+        child = nodes4[:, 24:28].copy().view(np.int32)
+        assert np.array_equal(q[:, 12:16].view(np.int32), child)
+        origin = q[:, 0:3].copy().view(np.float32).astype(np.float64)
+        scale = np.stack([q[:, 3], q[:, 10], q[:, 11]], 1).copy().view(np.float32).astype(np.float64)
+        m, _e = np.frexp(scale)
+        assert (m == 0.5).all()                                   # powers of two
+        qd = {0: (q[:, 4], q[:, 5]), 1: (q[:, 6], q[:, 7]), 2: (q[:, 8], q[:, 9])}
+        for k in range(4):
+            used = child[:, k] != -2 ** 31
+            for a in range(3):
+                ql = ((qd[a][0] >> (8 * k)) & 255).astype(np.float64)
+                qh = ((qd[a][1] >> (8 * k)) & 255).astype(np.float64)
+                lo = nodes4[:, a * 8 + k].astype(np.float64)
+                hi = nodes4[:, a * 8 + 4 + k].astype(np.float64)
+                dlo, dhi = origin[:, a] + ql * scale[:, a], origin[:, a] + qh * scale[:, a]
+                assert (dlo[used] <= lo[used]).all() and (dhi[used] >= hi[used]).all()
+                assert (lo[used] - dlo[used] < scale[used, a]).all() and (dhi[used] - hi[used] < scale[used, a]).all()
+                assert (ql[~used] == 255).all() and (qh[~used] == 0).all()
+
+
 def test_halton_device_identities():
     """The two arithmetic identities behind the device Halton code, checked exhaustively in C
     (tests/helpers/halton_identities.c): fp32 digit extraction for every n < 2^22 and every prime of the table,

@@ -85,6 +85,7 @@ _SYMBOLS = [
     ("trg_debug_build_bvh", C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32,
                                       C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("trg_debug_build_bvh4", C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("trg_debug_build_bvh4q", C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
 ]
 SYMBOL_NAMES = [s[0] for s in _SYMBOLS]
 
@@ -275,3 +276,20 @@ def debug_build_bvh4(positions, indices, material_ids):
     if rc != OK:
         raise TrgError(rc, "trg_debug_build_bvh4")
     return nodes, dp.value
+
+
+def debug_build_bvh4q(positions, indices, material_ids):
+    """Host-only quantised 4-wide BVH (no GPU): nodes4q[n,16] uint32, node i = node i of debug_build_bvh4."""
+    L = load()
+    pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+    idx = np.ascontiguousarray(indices, np.uint32).reshape(-1)
+    mat = np.ascontiguousarray(material_ids, np.uint32).reshape(-1)
+    nn = C.c_uint32()
+    rc = L.trg_debug_build_bvh4q(_ptr(pos), _ptr(idx), _ptr(mat), pos.shape[0], mat.shape[0], None, 0, C.byref(nn))
+    if rc != OK:
+        raise TrgError(rc, "trg_debug_build_bvh4q")
+    nodes = np.zeros((nn.value, 16), np.uint32)
+    rc = L.trg_debug_build_bvh4q(_ptr(pos), _ptr(idx), _ptr(mat), pos.shape[0], mat.shape[0], _ptr(nodes), nn.value, C.byref(nn))
+    if rc != OK:
+        raise TrgError(rc, "trg_debug_build_bvh4q")
+    return nodes

@@ -1,6 +1,7 @@
 // bvh_build.cpp -- binned-SAH BVH2 builder, flattened into the "two child boxes per node" layout the
 // gfx950 traversal kernel reads with four 16-byte loads (see bvh_build.h).
 #include "bvh_build.h"
+#include "q4node.h"
 
 #include <algorithm>
 #include <cmath>
@@ -280,6 +281,9 @@ void build_bvh(const float *pos, const uint32_t *idx, const uint32_t *masks, uin
         n[6] = F4{ bits_f((uint32_t)w.child[0]), bits_f((uint32_t)w.child[1]), bits_f((uint32_t)w.child[2]), bits_f((uint32_t)w.child[3]) };
         n[7] = F4{ 0.f, 0.f, 0.f, 0.f };
     }
+
+    out.nodes4q.assign((size_t)out.n_nodes4 * 16, 0u);
+    for (size_t i = 0; i < wide.size(); ++i) quantize_node4(&out.nodes4[i * 8].x, &out.nodes4q[i * 16]);
 
     // SAH cost (reporting only)
     double cost = 0.0;

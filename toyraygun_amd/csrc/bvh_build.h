@@ -26,7 +26,8 @@ struct F4 { float x, y, z, w; };
 //    child encoding as above; an unused slot holds 0x80000000 and is never entered.
 struct Bvh {
     std::vector<F4> nodes;   // 4 per node (BVH2)
-    std::vector<F4> nodes4;  // 8 per node (BVH4 collapse of the same tree)
+    std::vector<F4> nodes4;  // 8 per node (BVH4 collapse of the same tree), float boxes: what the quantiser and the tests see
+    std::vector<uint32_t> nodes4q;  // 16 dwords per node: the quantised 64-byte form the HBM kernels traverse (q4node.h)
     std::vector<F4> tris;    // 3 per triangle
     uint32_t n_nodes = 0, n_leaves = 0, depth = 0, max_leaf = 0;
     uint32_t n_nodes4 = 0, depth4 = 0;

@@ -12,6 +12,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
+#include "q4node.h"
 #include "trg_build.h"
 
 namespace trg {
@@ -163,6 +164,17 @@ __global__ void emit_wide_kernel(const Box3 *prim_boxes, const unsigned long lon
     o[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
+// float 4-wide nodes -> the 64-byte quantised nodes the kernels traverse (same encoder as the host build)
+__global__ void quantize_nodes4_kernel(const float4 *nodes4, uint32_t n, uint4 *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float in[32];
+    for (int r = 0; r < 8; ++r) { const float4 v = nodes4[(size_t)i * 8 + r]; in[r * 4] = v.x; in[r * 4 + 1] = v.y; in[r * 4 + 2] = v.z; in[r * 4 + 3] = v.w; }
+    uint32_t q[16];
+    trg::quantize_node4(in, q);
+    for (int r = 0; r < 4; ++r) out[(size_t)i * 4 + r] = make_uint4(q[r * 4], q[r * 4 + 1], q[r * 4 + 2], q[r * 4 + 3]);
+}
+
 struct Tmp {
     void *p = nullptr;
     ~Tmp() { if (p) (void)hipFree(p); }
@@ -223,6 +235,12 @@ hipError_t gpu_build_lbvh(const float *d_pos, const uint32_t *d_idx, const uint3
     *n_nodes4 = last_idx + last_kept;
     *depth4 = (uint32_t)(md / 2 + 1);
     return hipSuccess;
+}
+
+hipError_t gpu_quantize_nodes4(const float4 *d_nodes4, uint32_t n_nodes4, void *d_out, hipStream_t s) {
+    if (n_nodes4 == 0) return hipSuccess;
+    hipLaunchKernelGGL(quantize_nodes4_kernel, dim3((n_nodes4 + 127) / 128), dim3(128), 0, s, d_nodes4, n_nodes4, static_cast<uint4 *>(d_out));
+    return hipGetLastError();
 }
 
 }  // namespace trg

@@ -13,6 +13,7 @@
 
 #include "../../include/trg.h"
 #include "bvh_build.h"
+#include "q4node.h"
 #include "trg_build.h"
 #include "trg_kernels.h"
 
@@ -165,7 +166,7 @@ static int load_scene_gpu_build(trg_ctx *c, const float *pos, const float *nrm, 
     sc.off_nodes4 = (align16(sc.off_mats + n_tris * 4u) + 127u) & ~127u;
     sc.n_nodes4 = n4;
     sc.lds_stage_bytes = 0;
-    const uint64_t total = (uint64_t)sc.off_nodes4 + (uint64_t)n4 * 128u + 128u;
+    const uint64_t total = (uint64_t)sc.off_nodes4 + (uint64_t)n4 * kQ4NodeBytes + 128u;
     if (total > 0xFFFFFFF0ull) return fail(c, TRG_ERR_RANGE, "trg_load_scene: scene needs %llu B on the device (limit 4 GiB)", (unsigned long long)total);
     sc.blob_bytes = (uint32_t)total;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -177,7 +178,7 @@ static int load_scene_gpu_build(trg_ctx *c, const float *pos, const float *nrm, 
     HIPCHK(c, hipMemcpyAsync(c->blob + sc.off_normals, nrm, (size_t)n_tris * 36, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->blob + sc.off_colors, col, (size_t)n_tris * 36, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->blob + sc.off_mats, mat, (size_t)n_tris * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->blob + sc.off_nodes4, d_nodes4.p, (size_t)n4 * 128, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, gpu_quantize_nodes4((const float4 *)d_nodes4.p, n4, c->blob + sc.off_nodes4, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     sc.blob = c->blob;
     c->sc = sc;
@@ -264,7 +265,7 @@ int trg_load_scene(trg_ctx *c, const float *pos, const float *nrm, const float *
     // (Raytracing.metal:104-108), so they are copied as they are.
     const uint32_t nt_rec = (uint32_t)(bvh.tris.size() / 3);
     const uint32_t attr_tris = std::max(n_tris, 1u);
-    // [ BVH2 nodes | triangle records | normals | colours | material ids ] [ 4-wide nodes | 128 B pad ]
+    // [ BVH2 nodes | triangle records | normals | colours | material ids ] [ quantised 4-wide nodes | 128 B pad ]
     // The first bracket is what a workgroup stages into LDS when it is small enough; scenes that can only be
     // traversed from HBM skip the BVH2 nodes when the HBM kernels use the 4-wide tree.
     const uint64_t small_bytes = (uint64_t)bvh.n_nodes * kLdsNodeBytes + (uint64_t)nt_rec * 48u + (uint64_t)attr_tris * 76u + 64u;
@@ -279,13 +280,10 @@ int trg_load_scene(trg_ctx *c, const float *pos, const float *nrm, const float *
     sc.off_colors = align16(sc.off_normals + attr_tris * 36u);
     sc.off_mats = align16(sc.off_colors + attr_tris * 36u);
     sc.off_nodes4 = align16(sc.off_mats + attr_tris * 4u);
-    sc.off_nodes4 = (sc.off_nodes4 + 127u) & ~127u;  // 128-byte nodes on 128-byte lines
+    sc.off_nodes4 = (sc.off_nodes4 + 127u) & ~127u;  // 64-byte nodes, two per 128-byte line
     sc.n_nodes4 = kWideHbm ? bvh.n_nodes4 : 0u;
     sc.lds_stage_bytes = lds_candidate ? align16(sc.off_mats + attr_tris * 4u) : 0u;
-#if defined(TRG_TRAV_LDS) && TRG_TRAV_LDS == 3  // experiment: LDS-resident scenes traverse the 4-wide tree too
-    if (lds_candidate) sc.lds_stage_bytes = align16(sc.off_nodes4 + sc.n_nodes4 * 128u);
-#endif
-    const uint64_t total = (uint64_t)sc.off_nodes4 + (uint64_t)sc.n_nodes4 * 128u + 128u;
+    const uint64_t total = (uint64_t)sc.off_nodes4 + (uint64_t)sc.n_nodes4 * kQ4NodeBytes + 128u;
     if (total > 0xFFFFFFF0ull) return fail(c, TRG_ERR_RANGE, "trg_load_scene: scene needs %llu B on the device (limit 4 GiB)", (unsigned long long)total);
     sc.blob_bytes = (uint32_t)total;
     std::vector<unsigned char> host(sc.blob_bytes, 0);
@@ -321,7 +319,7 @@ int trg_load_scene(trg_ctx *c, const float *pos, const float *nrm, const float *
         memcpy(hc, col, (size_t)n_tris * 36);
         memcpy(&host[sc.off_mats], mat, (size_t)n_tris * 4);
     }
-    if (sc.n_nodes4) memcpy(&host[sc.off_nodes4], bvh.nodes4.data(), (size_t)sc.n_nodes4 * 128u);
+    if (sc.n_nodes4) memcpy(&host[sc.off_nodes4], bvh.nodes4q.data(), (size_t)sc.n_nodes4 * kQ4NodeBytes);
 
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->blob) { (void)hipFree(c->blob); c->blob = nullptr; c->scene_loaded = false; }
@@ -549,6 +547,21 @@ int trg_debug_build_bvh4(const float *positions3, const uint32_t *indices, const
     if (nodes4_out) {
         if (nodes4_cap < bvh.n_nodes4) return TRG_ERR_RANGE;
         memcpy(nodes4_out, bvh.nodes4.data(), (size_t)bvh.n_nodes4 * 128);
+    }
+    return TRG_OK;
+}
+
+int trg_debug_build_bvh4q(const float *positions3, const uint32_t *indices, const uint32_t *material_ids, uint32_t n_verts,
+                          uint32_t n_tris, uint32_t *nodes4q_out, uint32_t nodes4_cap, uint32_t *n_nodes4) {
+    if (n_tris && (!positions3 || !indices || !material_ids)) return TRG_ERR_INVALID;
+    for (size_t i = 0; i < (size_t)n_tris * 3; ++i)
+        if (indices[i] >= n_verts) return TRG_ERR_INVALID;
+    Bvh bvh;
+    build_bvh(positions3, indices, material_ids, n_tris, bvh);
+    if (n_nodes4) *n_nodes4 = bvh.n_nodes4;
+    if (nodes4q_out) {
+        if (nodes4_cap < bvh.n_nodes4) return TRG_ERR_RANGE;
+        memcpy(nodes4q_out, bvh.nodes4q.data(), (size_t)bvh.n_nodes4 * kQ4NodeBytes);
     }
     return TRG_OK;
 }

@@ -593,24 +593,34 @@ TRG_DEV void trav_leaf_step(const SceneView &sc, Trav &tv, bool any, STK stk, Co
         (ca) = cc_;                                       \
     }
 
-TRG_DEV float box_entry(float lx, float hx, float ly, float hy, float lz, float hz, const Trav &tv, int child) {
-    const float x0 = lx * tv.idx - tv.oix, x1 = hx * tv.idx - tv.oix;
-    const float y0 = ly * tv.idy - tv.oiy, y1 = hy * tv.idy - tv.oiy;
-    const float z0 = lz * tv.idz - tv.oiz, z1 = hz * tv.idz - tv.oiz;
-    const float tmin = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
-    const float tmax = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tv.best));
-    return (tmin <= tmax && child != kNodeDone) ? tmin : INFINITY;  // +inf = not entered (miss or unused slot)
-}
-
+// One 4-wide step on a QUANTISED node (q4node.h): 64 bytes = four 16-byte loads.  plane = origin + q * scale, so
+// t = (plane - o) / d = q * (scale / d) + (origin / d - o / d): two ray-dependent constants per axis (A, B), then one
+// v_cvt_f32_ubyteN + one fma per plane.  The near / far plane dwords are picked by the sign of the direction (one
+// select per axis for all four children), which also removes the per-child min/max ordering.
 template <bool COUNT, int BLOCK, typename STK>
-TRG_DEV void trav_node4_math(const v4f lox, const v4f hix, const v4f loy, const v4f hiy, const v4f loz, const v4f hiz,
-                             const v4f ch, Trav &tv, STK stk, Counters &cnt) {
+TRG_DEV void trav_node4_math(const v4f q0, const v4f q1, const v4f q2, const v4f ch, Trav &tv, STK stk, Counters &cnt) {
     if (COUNT) { cnt.nodes += 2; if (mbcnt64(__ballot(1)) == 0) cnt.wnodes++; }  // 4 boxes = 2 BVH2-equivalent fetches
     int c0 = __float_as_int(ch.x), c1 = __float_as_int(ch.y), c2 = __float_as_int(ch.z), c3 = __float_as_int(ch.w);
-    float t0 = box_entry(lox.x, hix.x, loy.x, hiy.x, loz.x, hiz.x, tv, c0);
-    float t1 = box_entry(lox.y, hix.y, loy.y, hiy.y, loz.y, hiz.y, tv, c1);
-    float t2 = box_entry(lox.z, hix.z, loy.z, hiy.z, loz.z, hiz.z, tv, c2);
-    float t3 = box_entry(lox.w, hix.w, loy.w, hiy.w, loz.w, hiz.w, tv, c3);
+    const float ax = q0.w * tv.idx, ay = q2.z * tv.idy, az = q2.w * tv.idz;
+    const float bx = q0.x * tv.idx - tv.oix, by = q0.y * tv.idy - tv.oiy, bz = q0.z * tv.idz - tv.oiz;
+    const bool negx = tv.sx != 0, negy = tv.sy != 32, negz = tv.sz != 64;
+    const uint32_t lox = __float_as_uint(q1.x), hix = __float_as_uint(q1.y), loy = __float_as_uint(q1.z), hiy = __float_as_uint(q1.w);
+    const uint32_t loz = __float_as_uint(q2.x), hiz = __float_as_uint(q2.y);
+    const uint32_t nx = negx ? hix : lox, fx = negx ? lox : hix;
+    const uint32_t ny = negy ? hiy : loy, fy = negy ? loy : hiy;
+    const uint32_t nz = negz ? hiz : loz, fz = negz ? loz : hiz;
+    float t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float tnx = (float)((nx >> (8 * k)) & 255u) * ax + bx, tfx = (float)((fx >> (8 * k)) & 255u) * ax + bx;
+        const float tny = (float)((ny >> (8 * k)) & 255u) * ay + by, tfy = (float)((fy >> (8 * k)) & 255u) * ay + by;
+        const float tnz = (float)((nz >> (8 * k)) & 255u) * az + bz, tfz = (float)((fz >> (8 * k)) & 255u) * az + bz;
+        const float tmin = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
+        const float tmax = fminf(fminf(tfx, tfy), fminf(tfz, tv.best));
+        const int c = k == 0 ? c0 : (k == 1 ? c1 : (k == 2 ? c2 : c3));
+        t[k] = (tmin <= tmax && c != kNodeDone) ? tmin : INFINITY;  // +inf = not entered (miss or unused slot)
+    }
+    float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
     const int n_hit = (t0 < INFINITY ? 1 : 0) + (t1 < INFINITY ? 1 : 0) + (t2 < INFINITY ? 1 : 0) + (t3 < INFINITY ? 1 : 0);
     // sort the four (entry distance, child) pairs, nearest first (5-comparator network); misses sink to the end
     TRG_CSWAP(t0, c0, t1, c1) TRG_CSWAP(t2, c2, t3, c3) TRG_CSWAP(t0, c0, t2, c2) TRG_CSWAP(t1, c1, t3, c3) TRG_CSWAP(t1, c1, t2, c2)
@@ -631,18 +641,18 @@ TRG_DEV void trav_node4_math(const v4f lox, const v4f hix, const v4f loy, const 
     tv.node = next; tv.sp = sp;
 }
 
-// one unit of work per lane per iteration on the 4-wide tree: a node (eight 16-byte loads = one 128-byte line)
-// or one triangle of the current leaf (the same eight loads, three of them used)
+// one unit of work per lane per iteration on the 4-wide tree: a quantised node (four 16-byte loads = 64 bytes)
+// or one triangle of the current leaf (the first three of the same loads)
 template <bool COUNT, int BLOCK, typename STK>
 TRG_DEV void trav_step_wide(const SceneView &sc, Trav &tv, bool any, STK stk, Counters &cnt) {
     const bool inner = tv.node >= 0;
     const uint32_t code = (uint32_t)~tv.node;
     const uint32_t first = code >> 3, left = code & 7u;
-    const v4f *ptr = inner ? sc.nodes + (size_t)tv.node * 8 : sc.tris + (size_t)first * 3;
+    const v4f *ptr = inner ? sc.nodes + (size_t)tv.node * 4 : sc.tris + (size_t)first * 3;
     const v4f q0 = ptr[0], q1 = ptr[1], q2 = ptr[2];
     if (inner) {
-        const v4f q3 = ptr[3], q4 = ptr[4], q5 = ptr[5], q6 = ptr[6];
-        trav_node4_math<COUNT, BLOCK>(q0, q1, q2, q3, q4, q5, q6, tv, stk, cnt);
+        const v4f q3 = ptr[3];
+        trav_node4_math<COUNT, BLOCK>(q0, q1, q2, q3, tv, stk, cnt);
     } else {
         const bool stop = trav_tri_math<COUNT>(q0, q1, q2, tv, any, cnt);
         const bool more = left != 0u;

@@ -30,7 +30,7 @@ TRG_DEV SceneView scene_view(const trg::SceneDesc &sc, unsigned char *smem) {
         const uint32_t n16 = sc.lds_stage_bytes >> 4;
         for (uint32_t i = threadIdx.x; i < n16; i += trg::kBlock) dst[i] = src[i];
         __syncthreads();
-        v.nodes = reinterpret_cast<const v4f *>(smem + (TRG_TRAV_LDS == 3 ? sc.off_nodes4 : sc.off_nodes));
+        v.nodes = reinterpret_cast<const v4f *>(smem + sc.off_nodes);
         v.tris = reinterpret_cast<const v4f *>(smem + sc.off_tris);
         v.normals = reinterpret_cast<const float *>(smem + sc.off_normals);
         v.colors = reinterpret_cast<const float *>(smem + sc.off_colors);
@@ -163,13 +163,13 @@ TRG_DEV V3 path_radiance(const trg::RenderParams &p, const SceneView &sc, STK st
 }
 
 // minimum waves per SIMD the register allocator must leave room for.  Scene in LDS: 8 (at most 64 VGPRs; VALU-bound,
-// more waves hide the LDS latency: +3 % C2, +5 % at 8 bounces over 6).  Scene in HBM: 6 (at most 80 VGPRs; 8 spills
-// the 4-wide node registers and is 35 % slower, 5 loses 5 % of latency hiding).
+// more waves hide the LDS latency: +3 % C2, +5 % at 8 bounces over 6).  Scene in HBM: 7 (at most 72 VGPRs; 8 spills
+// and is 40 % slower, 6 loses 5 % of latency hiding; with the quantised 64-byte nodes 7 = 72 VGPRs is the sweet spot).
 #ifndef TRG_EXP_WAVES
 #define TRG_EXP_WAVES 8
 #endif
 #ifndef TRG_EXP_WAVES_HBM
-#define TRG_EXP_WAVES_HBM 6
+#define TRG_EXP_WAVES_HBM 7
 #endif
 template <bool LDS_SCENE, bool COUNT>
 __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES : TRG_EXP_WAVES_HBM) void render_kernel(const trg::RenderParams p) {
