@@ -35,16 +35,7 @@ def cornell_buffers():
     return host.Scene.cornell_box().buffers(), host.uniforms(W, H)[0]
 
 
-def algorithmic_bytes_per_ray(st, pixel_samples):
-    """32*n_nodes + 48*n_tris + 76*p_shaded + 20/r, nodes in BVH2-equivalent boxes
-    (one 64-byte node fetch = two child boxes)."""
-    rays = st.primary_rays + st.bounce_rays + st.shadow_rays
-    n_nodes = 2.0 * st.node_fetches / rays
-    n_tris = st.tri_tests / rays
-    p_shaded = st.shaded_hits / rays
-    rbar = rays / pixel_samples
-    return 32.0 * n_nodes + 48.0 * n_tris + 76.0 * p_shaded + 20.0 / rbar, dict(
-        nodes_per_ray=n_nodes, tris_per_ray=n_tris, shaded_per_ray=p_shaded, rays_per_pixel_sample=rbar)
+from toyraygun_amd.roofline import algorithmic_bytes_per_ray  # SURVEY 8(d) figure from the kernel's counters
 
 
 def cpu_baseline(buffers_unused):
@@ -163,11 +154,11 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Cornell box (36 triangles) 1920x1080, 16 spp, 3 bounces (BASELINE configs[1])",
                        "rays_per_step": rays_total / args.steps, "sharding": "row bands + RCCL all-gather (double-buffered, gather k overlaps render k+1)" if distributed else "none",
-                       "kernel": "render_kernel<LDS scene> (fast build)"},
+                       "kernel": ("render_kernel" if st.last_frame_split <= 1 else "render_fp_kernel, %d frame lanes" % st.last_frame_split) + "<LDS scene> (fast build)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel_ms": kernel_ms, "algorithmic_bytes_per_ray": bytes_per_ray,
                          "bytes_per_launch": rays_per_launch * bytes_per_ray, **mix,
-                         "note": "the 5.8 KB scene is LDS-resident: the algorithmic bytes are served from LDS, so frac > 1 is expected; real HBM traffic (`traffic`, rocprofv3 FETCH_SIZE+WRITE_SIZE) is the offset read, the float4 write and spill scratch (SURVEY 8d caveat)"},
+                         "note": "the scene (%.1f KB on the device) is LDS-resident:" % (cst.scene_bytes / 1024.0) + " the algorithmic bytes are served from LDS, so frac > 1 is expected; real HBM traffic (`traffic`, rocprofv3 FETCH_SIZE+WRITE_SIZE) is the offset read, the float4 write and spill scratch (SURVEY 8d caveat)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(buffers)

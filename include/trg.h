@@ -64,8 +64,8 @@ typedef struct trg_stats {
      * counted iff it is actually traversed: primary rays, bounce rays (nearest-hit, bounce >= 1)
      * and shadow rays (any-hit) submitted with maxDistance >= 0. */
     uint64_t primary_rays, bounce_rays, shadow_rays, shaded_hits;
-    /* filled only while TRG_OPT_COUNTERS is on: 64-byte node fetches (= 2 BVH2-equivalent boxes
-     * each) and ray/triangle tests */
+    /* filled only while TRG_OPT_COUNTERS is on: node steps in units of two child boxes (a BVH2 node of an
+     * LDS-resident scene = 1, a 4-wide node of an HBM-resident scene = 2) and ray/triangle tests */
     uint64_t node_fetches, tri_tests;
     /* wave-level loop trips of the traversal (TRG_OPT_COUNTERS): node_fetches / (64 * wave_node_iters) is the
      * lane utilisation of the node loop, likewise for triangles */
@@ -76,7 +76,8 @@ typedef struct trg_stats {
     uint32_t bvh_nodes, bvh_depth, bvh_leaves, scene_in_lds, lds_bytes;
     uint64_t scene_bytes;   /* bytes of nodes + triangle records + attributes on the device */
     double last_build_ms;   /* acceleration-structure build of the last trg_load_scene: host wall time, or HIP-event time when built on the GPU */
-    uint32_t gpu_built, bvh_nodes4, bvh_depth4, _pad;
+    uint32_t gpu_built, bvh_nodes4, bvh_depth4;
+    uint32_t last_frame_split; /* frame lanes the last trg_render used (TRG_OPT_FRAME_SPLIT; 1 = render_kernel, 2/4 = render_fp_kernel) */
 } trg_stats;
 
 enum trg_option {

@@ -2,6 +2,7 @@
 import sys, json, time; sys.path.insert(0, ".")
 import numpy as np
 from toyraygun_amd import capi, host
+from toyraygun_amd.roofline import algorithmic_bytes_per_ray
 
 def run(tag, w, h, spp, bounces, scene, kernel=0, reps=3):
     c = capi.Context(w, h)
@@ -13,8 +14,8 @@ def run(tag, w, h, spp, bounces, scene, kernel=0, reps=3):
     for i in range(reps):
         c.reset_stats(); c.render(0, spp, bounces); st = c.stats(); ts.append(st.last_render_ms)
     c.set_option(capi.OPT_COUNTERS, 1); c.reset_stats(); c.render(0, min(spp, 16), bounces); cs = c.stats()
-    rays = cs.rays; nn = 2.0 * cs.node_fetches / rays; nt = cs.tri_tests / rays; ps = cs.shaded_hits / rays
-    rb = rays / (w * h * min(spp, 16)); bpr = 32 * nn + 48 * nt + 76 * ps + 20 / rb
+    bpr, mix = algorithmic_bytes_per_ray(cs, w * h * min(spp, 16))
+    nn, nt, rb = mix["nodes_per_ray"], mix["tris_per_ray"], mix["rays_per_pixel_sample"]
     ms = min(ts)
     out = dict(config=tag, w=w, h=h, spp=spp, bounces=bounces, tris=int(b["material_ids"].shape[0]), kernel=["direct", "pool"][kernel],
                ms=round(ms, 3), rays=int(st.rays), grays_per_s=round(st.rays / ms / 1e6, 2), bytes_per_ray=round(bpr, 1),

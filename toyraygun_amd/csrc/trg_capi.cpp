@@ -43,6 +43,7 @@ struct trg_ctx {
     uint32_t bvh_nodes = 0, bvh_depth = 0, bvh_leaves = 0;
     double last_ms = 0.0, total_ms = 0.0;
     uint32_t renders = 0;
+    uint32_t last_fsplit = 1;
     std::string err;
 };
 
@@ -409,6 +410,7 @@ int trg_render(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces,
                           : launch_render_fast(p, plan.lds_scene, c->opt_counters, grid, plan.total, c->stream);
     if (e != hipSuccess) return fail(c, TRG_ERR_DEVICE, "trg_render: launch failed: %s", hipGetErrorString(e));
     c->renders++;
+    c->last_fsplit = fsplit;
     if (c->opt_timing) {
         HIPCHK(c, hipEventRecord(c->ev1, c->stream));
         HIPCHK(c, hipEventSynchronize(c->ev1));
@@ -446,6 +448,7 @@ int trg_get_stats(trg_ctx *c, trg_stats *out) {
     out->scene_bytes = c->sc.blob_bytes;
     out->last_build_ms = c->last_build_ms; out->gpu_built = c->gpu_built ? 1u : 0u;
     out->bvh_nodes4 = c->bvh_nodes4; out->bvh_depth4 = c->bvh_depth4;
+    out->last_frame_split = c->last_fsplit;
     if (c->scene_loaded) {
         LdsPlan plan;
         if (plan_lds(c, plan, c->opt_kernel == TRG_KERNEL_POOL) == TRG_OK) { out->scene_in_lds = plan.lds_scene ? 1u : 0u; out->lds_bytes = plan.total; }
