@@ -296,18 +296,21 @@ int trg_load_scene(trg_ctx *c, const float *pos, const float *nrm, const float *
             float *o = reinterpret_cast<float *>(&host[sc.off_nodes + (size_t)i * kLdsNodeBytes]);
             const float px[4] = { n[0].x, n[0].y, n[1].x, n[1].y }, py[4] = { n[0].z, n[0].w, n[1].z, n[1].w };
             const float pz[4] = { n[2].x, n[2].y, n[2].z, n[2].w };
-            const float *axes[3] = { px, py, pz };
-            for (int a = 0; a < 3; ++a) {
-                const float *p = axes[a];
-                float *q = o + a * 8;
-                q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; q[3] = p[3];
-                q[4] = p[1]; q[5] = p[0]; q[6] = p[3]; q[7] = p[2];
-            }
             int32_t ch[2];
             memcpy(ch, &n[3].x, 8);
             for (int k = 0; k < 2; ++k)
                 if (ch[k] >= 0) ch[k] *= (int32_t)kLdsNodeBytes;
-            memcpy(o + 24, ch, 8);
+            // X+ X- Y+ Y- at 0 / 16 / 32 / 48; Z+ at 64 and Z- at 96, each followed by the child pair (+ 8 bytes of padding)
+            const float *axes[3] = { px, py, pz };
+            const int at[3][2] = { { 0, 4 }, { 8, 12 }, { 16, 24 } };  // float index of the + and - copy
+            for (int a = 0; a < 3; ++a) {
+                const float *p = axes[a];
+                float *q = o + at[a][0], *r = o + at[a][1];
+                q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; q[3] = p[3];
+                r[0] = p[1]; r[1] = p[0]; r[2] = p[3]; r[3] = p[2];
+            }
+            memcpy(o + 20, ch, 8);
+            memcpy(o + 28, ch, 8);
         }
     } else if (sc.n_nodes) {
         memcpy(&host[sc.off_nodes], bvh.nodes.data(), (size_t)sc.n_nodes * 64u);

@@ -412,18 +412,27 @@ TRG_DEV bool tri_test(const v4f a, const v4f b, const v4f c, V3 o, V3 d, float t
 // HBM keep the first klds levels in LDS and spill deeper levels to a per-thread column of a global scratch
 // buffer: the 4-wide tree can need 3 x depth entries in the worst case, typical rays need about a dozen,
 // and LDS spent on never-used levels is occupancy lost.
+// The stack pointer a traversal carries is opaque: stk.first() is the empty stack, it moves by STK::unit per entry.
+// Without overflow it IS the LDS byte address of the next free entry (unit = BLOCK ints), so push and pop are a bare
+// ds_write_b32 / ds_read_b32 with no address arithmetic; with overflow it is the level index.
+typedef __attribute__((address_space(3))) int lds_int_t;
 template <int BLOCK, bool OVERFLOW = false>
 struct LdsStackT {
     int *base;         // LDS, already offset by the thread index
     int *gbase;        // global overflow column of this thread (nullptr when unused)
     uint32_t gstride;  // elements between consecutive overflow levels
     int klds;          // levels held in LDS
+    static constexpr int unit = OVERFLOW ? 1 : BLOCK * 4;
+    TRG_DEV int first() const { return OVERFLOW ? 0 : (int)(uint32_t)(uintptr_t)(lds_int_t *)base; }
+    TRG_DEV bool empty(int sp) const { return sp == first(); }
     TRG_DEV void push(int sp, int v) {
-        if (!OVERFLOW || sp < klds) base[sp * BLOCK] = v;
+        if (!OVERFLOW) *(lds_int_t *)(uintptr_t)(uint32_t)sp = v;
+        else if (sp < klds) base[sp * BLOCK] = v;
         else gbase[(size_t)(sp - klds) * gstride] = v;
     }
     TRG_DEV int pop(int sp) {
-        if (!OVERFLOW || sp < klds) return base[sp * BLOCK];
+        if (!OVERFLOW) return *(lds_int_t *)(uintptr_t)(uint32_t)sp;
+        if (sp < klds) return base[sp * BLOCK];
         return gbase[(size_t)(sp - klds) * gstride];
     }
 };
@@ -446,7 +455,7 @@ struct Trav {
     int sx, sy, sz;  // sign-ordered LDS nodes (TRG_TRAV_LDS == 4): byte offset of the slab pair to read per axis
 };
 
-TRG_DEV void trav_begin(Trav &tv, V3 o, V3 d, float tmax, uint32_t rmask) {
+TRG_DEV void trav_begin(Trav &tv, V3 o, V3 d, float tmax, uint32_t rmask, int sp0, uint32_t node_base = 0u) {
     // Reciprocal direction with zero components pushed to +-1e-30: the slab products stay finite (no
     // inf - inf = NaN whose fmin/fmax would pick the wrong endpoint), and a ray that moves 1e-30 per
     // unit t along an axis is parallel to the slab for every practical purpose.
@@ -459,11 +468,12 @@ TRG_DEV void trav_begin(Trav &tv, V3 o, V3 d, float tmax, uint32_t rmask) {
     tv.tmax = tmax; tv.best = tmax; tv.rmask = rmask;
     tv.hit.t = -1.0f; tv.hit.prim = -1; tv.hit.u = 0.0f; tv.hit.v = 0.0f;
     tv.found = false;
-    tv.node = 0; tv.sp = 0;
-    // slab copy per axis: +0 when the ray travels towards +axis (near plane = lo), +16 when it travels towards -axis
-    tv.sx = (int)((__float_as_uint(dx) >> 31) << 4);
-    tv.sy = 32 + (int)((__float_as_uint(dy) >> 31) << 4);
-    tv.sz = 64 + (int)((__float_as_uint(dz) >> 31) << 4);
+    tv.node = 0; tv.sp = sp0;  // sp0 = stk.first(): the empty stack
+    // sign-ordered LDS nodes: LDS address of the slab copy to read per axis, for node 0 (node_base = LDS address of the
+    // node array).  X+ X- at +0 / +16, Y+ Y- at +32 / +48, Z+ Z- at +64 / +96 (each Z copy is followed by the child pair).
+    tv.sx = (int)(node_base + ((__float_as_uint(dx) >> 31) << 4));
+    tv.sy = (int)(node_base + 32u + ((__float_as_uint(dy) >> 31) << 4));
+    tv.sz = (int)(node_base + 64u + ((__float_as_uint(dz) >> 31) << 5));
 }
 
 // One inner-node step: test both child boxes, descend into the nearer hit child, push the other, or pop.
@@ -488,49 +498,59 @@ TRG_DEV void trav_node_math(const v4f n0, const v4f n1, const v4f n2, const v4f 
     const bool first1 = hb && (!ha || bmin < amin);  // child 1 is the (nearer) one to enter
     const int nearc = first1 ? c1 : c0, farc = first1 ? c0 : c1;
     if (both) stk.push(tv.sp, farc);
-    int sp = tv.sp + (both ? 1 : 0);
+    int sp = tv.sp + (both ? STK::unit : 0);
     int next = nearc;
     if (none) {
-        const bool empty = sp == 0;
-        sp -= empty ? 0 : 1;
+        const bool empty = stk.empty(sp);
+        sp -= empty ? 0 : STK::unit;
         const int popped = stk.pop(sp);  // when empty this reads level 0 (in bounds) and is discarded
         next = empty ? kNodeDone : popped;
     }
     tv.node = next; tv.sp = sp;
 }
 
-// The same step on a SIGN-ORDERED node (LDS-resident scenes, TRG_TRAV_LDS == 4).  A 112-byte node keeps, per axis,
+// The same step on a SIGN-ORDERED node (LDS-resident scenes, TRG_TRAV_LDS == 4).  A 144-byte node keeps, per axis,
 // the four slab planes of its two children twice: as (lo_a, hi_a, lo_b, hi_b) and as (hi_a, lo_a, hi_b, lo_b).  A
-// lane reads the copy that matches the sign of its ray direction (an address offset fixed per ray), so x = near
-// plane, y = far plane without the 12 min/max that order them -- the values are the same floats the min/max would
-// pick (the slab product is monotonic in the plane), so hits are unchanged.  Children are byte offsets of nodes
-// (>= 0) or leaf codes (< 0); 112 = 28 banks, so random nodes spread over 16 bank groups like the 64-byte layout.
-constexpr int kSignedNodeBytes = 112;
+// lane reads the copy that matches the sign of its ray direction (an LDS address fixed per ray, trav_begin), so
+// x = near plane, y = far plane without the 12 min/max that order them -- the values are the same floats the
+// min/max would pick (the slab product is monotonic in the plane), so hits are unchanged.  The child pair sits
+// behind BOTH Z copies, so it is read off the Z address too: three address adds per node in all.  Children are
+// byte offsets of nodes (>= 0) or leaf codes (< 0); 144 = 36 banks, so random nodes spread over 16 bank groups.
+constexpr int kSignedNodeBytes = 144;
+typedef __attribute__((address_space(3))) v4f lds_v4f_t;
+TRG_DEV float min_raw(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 template <bool COUNT, int BLOCK, typename STK>
 TRG_DEV void trav_node_step_signed(const SceneView &sc, Trav &tv, STK stk, Counters &cnt) {
     if (COUNT) { cnt.nodes++; if (mbcnt64(__ballot(1)) == 0) cnt.wnodes++; }
-    const char *n = reinterpret_cast<const char *>(sc.nodes) + tv.node;
-    const v4f X = *reinterpret_cast<const v4f *>(n + tv.sx);
-    const v4f Y = *reinterpret_cast<const v4f *>(n + tv.sy);
-    const v4f Z = *reinterpret_cast<const v4f *>(n + tv.sz);
-    const int c0 = *reinterpret_cast<const int *>(n + 96), c1 = *reinterpret_cast<const int *>(n + 100);
+    const uint32_t az_addr = (uint32_t)(tv.node + tv.sz);
+    const v4f X = *(const lds_v4f_t *)(uintptr_t)(uint32_t)(tv.node + tv.sx);
+    const v4f Y = *(const lds_v4f_t *)(uintptr_t)(uint32_t)(tv.node + tv.sy);
+    const v4f Z = *(const lds_v4f_t *)(uintptr_t)az_addr;
+    const int c0 = *(const lds_int_t *)(uintptr_t)(az_addr + 16u), c1 = *(const lds_int_t *)(uintptr_t)(az_addr + 20u);
     const float anx = X.x * tv.idx - tv.oix, afx = X.y * tv.idx - tv.oix, bnx = X.z * tv.idx - tv.oix, bfx = X.w * tv.idx - tv.oix;
     const float any_ = Y.x * tv.idy - tv.oiy, afy = Y.y * tv.idy - tv.oiy, bny = Y.z * tv.idy - tv.oiy, bfy = Y.w * tv.idy - tv.oiy;
     const float anz = Z.x * tv.idz - tv.oiz, afz = Z.y * tv.idz - tv.oiz, bnz = Z.z * tv.idz - tv.oiz, bfz = Z.w * tv.idz - tv.oiz;
     const float amin = fmaxf(fmaxf(anx, any_), fmaxf(anz, 0.0f));
-    const float amax = fminf(fminf(afx, afy), fminf(afz, tv.best));
+    // min_raw: a bare v_min_f32.  fminf would first canonicalise tv.best (a loop-carried value the compiler cannot
+    // prove quiet) with one more instruction per node; the slab products are never NaN (trav_begin) and best is a
+    // finite distance or +inf, so the plain instruction is the same function here.
+    const float amax = fminf(fminf(afx, afy), min_raw(afz, tv.best));
     const float bmin = fmaxf(fmaxf(bnx, bny), fmaxf(bnz, 0.0f));
-    const float bmax = fminf(fminf(bfx, bfy), fminf(bfz, tv.best));
+    const float bmax = fminf(fminf(bfx, bfy), min_raw(bfz, tv.best));
     const bool ha = amin <= amax, hb = bmin <= bmax;
     const bool both = ha && hb, none = !(ha || hb);
     const bool first1 = hb && (!ha || bmin < amin);
     const int nearc = first1 ? c1 : c0, farc = first1 ? c0 : c1;
     if (both) stk.push(tv.sp, farc);
-    int sp = tv.sp + (both ? 1 : 0);
+    int sp = tv.sp + (both ? STK::unit : 0);
     int next = nearc;
     if (none) {
-        const bool empty = sp == 0;
-        sp -= empty ? 0 : 1;
+        const bool empty = stk.empty(sp);
+        sp -= empty ? 0 : STK::unit;
         const int popped = stk.pop(sp);
         next = empty ? kNodeDone : popped;
     }
@@ -574,8 +594,8 @@ TRG_DEV void trav_leaf_step(const SceneView &sc, Trav &tv, bool any, STK stk, Co
         const v4f a = tr[0], b = tr[1], c = tr[2];
         if (trav_tri_math<COUNT>(a, b, c, tv, any, cnt)) { stop = true; break; }
     }
-    const bool empty = tv.sp == 0;
-    int sp = tv.sp - ((stop || empty) ? 0 : 1);
+    const bool empty = stk.empty(tv.sp);
+    int sp = tv.sp - ((stop || empty) ? 0 : STK::unit);
     const int popped = stk.pop(sp);
     tv.node = (stop || empty) ? kNodeDone : popped;
     tv.sp = sp;
@@ -626,15 +646,15 @@ TRG_DEV void trav_node4_math(const v4f q0, const v4f q1, const v4f q2, const v4f
     TRG_CSWAP(t0, c0, t1, c1) TRG_CSWAP(t2, c2, t3, c3) TRG_CSWAP(t0, c0, t2, c2) TRG_CSWAP(t1, c1, t3, c3) TRG_CSWAP(t1, c1, t2, c2)
     int sp = tv.sp;
     if (n_hit >= 4) stk.push(sp, c3);
-    sp += n_hit >= 4 ? 1 : 0;
+    sp += n_hit >= 4 ? STK::unit : 0;
     if (n_hit >= 3) stk.push(sp, c2);
-    sp += n_hit >= 3 ? 1 : 0;
+    sp += n_hit >= 3 ? STK::unit : 0;
     if (n_hit >= 2) stk.push(sp, c1);
-    sp += n_hit >= 2 ? 1 : 0;
+    sp += n_hit >= 2 ? STK::unit : 0;
     int next = c0;
     if (n_hit == 0) {
-        const bool empty = sp == 0;
-        sp -= empty ? 0 : 1;
+        const bool empty = stk.empty(sp);
+        sp -= empty ? 0 : STK::unit;
         const int popped = stk.pop(sp);
         next = empty ? kNodeDone : popped;
     }
@@ -656,9 +676,9 @@ TRG_DEV void trav_step_wide(const SceneView &sc, Trav &tv, bool any, STK stk, Co
     } else {
         const bool stop = trav_tri_math<COUNT>(q0, q1, q2, tv, any, cnt);
         const bool more = left != 0u;
-        const bool empty = tv.sp == 0;
+        const bool empty = stk.empty(tv.sp);
         const bool do_pop = !stop && !more && !empty;
-        const int sp = tv.sp - (do_pop ? 1 : 0);
+        const int sp = tv.sp - (do_pop ? STK::unit : 0);
         const int popped = stk.pop(sp);
         const int advanced = ~(int)(((first + 1u) << 3) | (left - 1u));
         tv.node = stop ? kNodeDone : (more ? advanced : (empty ? kNodeDone : popped));
@@ -684,9 +704,9 @@ TRG_DEV void trav_step_unified(const SceneView &sc, Trav &tv, bool any, STK stk,
     } else {
         const bool stop = trav_tri_math<COUNT>(q0, q1, q2, tv, any, cnt);
         const bool more = left != 0u;
-        const bool empty = tv.sp == 0;
+        const bool empty = stk.empty(tv.sp);
         const bool do_pop = !stop && !more && !empty;
-        const int sp = tv.sp - (do_pop ? 1 : 0);
+        const int sp = tv.sp - (do_pop ? STK::unit : 0);
         const int popped = stk.pop(sp);
         const int advanced = ~(int)(((first + 1u) << 3) | (left - 1u));
         tv.node = stop ? kNodeDone : (more ? advanced : (empty ? kNodeDone : popped));
@@ -705,6 +725,12 @@ TRG_DEV void trav_step_unified(const SceneView &sc, Trav &tv, bool any, STK stk,
 #define TRG_TRAV_HBM 3
 #endif
 
+// LDS address of the node array when the traversal reads sign-ordered LDS nodes (UNIFIED = false selects the LDS schedule)
+template <bool UNIFIED>
+TRG_DEV uint32_t lds_node_base(const SceneView &sc) {
+    return (!UNIFIED && TRG_TRAV_LDS == 4) ? (uint32_t)(uintptr_t)(const lds_v4f_t *)sc.nodes : 0u;
+}
+
 // Nearest-hit (ANY=false) or any-hit (ANY=true) query for one ray per lane.
 template <bool ANY, bool COUNT, int BLOCK, bool UNIFIED = false, typename STK>
 TRG_DEV bool traverse(const SceneView &sc, V3 o, V3 d, float tmax_ray, uint32_t rmask, Hit &hit, STK stk,
@@ -714,7 +740,7 @@ TRG_DEV bool traverse(const SceneView &sc, V3 o, V3 d, float tmax_ray, uint32_t 
     return !ANY;
 #endif
     Trav tv;
-    trav_begin(tv, o, d, tmax_ray, rmask);
+    trav_begin(tv, o, d, tmax_ray, rmask, stk.first(), lds_node_base<UNIFIED>(sc));
     constexpr int mode = UNIFIED ? TRG_TRAV_HBM : TRG_TRAV_LDS;
     if (mode == 3) {
         while (tv.node != kNodeDone) trav_step_wide<COUNT, BLOCK>(sc, tv, ANY, stk, cnt);
@@ -744,7 +770,7 @@ TRG_DEV void traverse_pair(const SceneView &sc, V3 org, bool has_shadow, V3 sdir
     nhit.t = -1.0f; nhit.prim = -1; nhit.u = 0.0f; nhit.v = 0.0f;
     int phase = has_shadow ? 0 : (has_next ? 1 : 2);
     Trav tv;
-    trav_begin(tv, org, phase == 0 ? sdir : ndir, phase == 0 ? smax : INFINITY, phase == 0 ? 1u : nmask);
+    trav_begin(tv, org, phase == 0 ? sdir : ndir, phase == 0 ? smax : INFINITY, phase == 0 ? 1u : nmask, stk.first(), lds_node_base<UNIFIED>(sc));
     if (phase == 2) tv.node = kNodeDone;
     constexpr int mode = UNIFIED ? TRG_TRAV_HBM : TRG_TRAV_LDS;
     while (phase < 2) {
@@ -761,7 +787,7 @@ TRG_DEV void traverse_pair(const SceneView &sc, V3 org, bool has_shadow, V3 sdir
             if (phase == 0) {
                 occluded = tv.found;
                 phase = has_next ? 1 : 2;
-                if (phase == 1) trav_begin(tv, org, ndir, INFINITY, nmask);
+                if (phase == 1) trav_begin(tv, org, ndir, INFINITY, nmask, stk.first(), lds_node_base<UNIFIED>(sc));
             } else {
                 nhit = tv.hit; nfound = tv.found;
                 phase = 2;
@@ -804,7 +830,7 @@ TRG_DEV void trace_queue(const SceneView &sc, const PoolView pv, const unsigned 
     bool busy = false, exhausted = false, any = false;
     uint32_t slot = 0;
     Trav tv;
-    trav_begin(tv, mk(0.0f, 0.0f, 0.0f), mk(0.0f, 0.0f, 1.0f), 0.0f, 0u);
+    trav_begin(tv, mk(0.0f, 0.0f, 0.0f), mk(0.0f, 0.0f, 1.0f), 0.0f, 0u, stk.first(), lds_node_base<UNIFIED>(sc));
     tv.node = kNodeDone;
     for (;;) {
         // ---- refill: idle lanes take the next list entries ----
@@ -824,7 +850,7 @@ TRG_DEV void trace_queue(const SceneView &sc, const PoolView pv, const unsigned 
                 const v4f r0 = pv.R0[slot];  // the shadow ray starts where the next ray starts
                 const v4f r1 = any ? pv.SH[slot] : pv.R1[slot];
                 trav_begin(tv, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), any ? r1.w : r0.w,
-                           any ? 1u : (uint32_t)__float_as_int(r1.w));
+                           any ? 1u : (uint32_t)__float_as_int(r1.w), stk.first(), lds_node_base<UNIFIED>(sc));
                 busy = true;
             }
         }

@@ -76,7 +76,7 @@ constexpr bool kWideHbm = (TRG_TRAV_HBM == 3);
 #define TRG_TRAV_LDS 4
 #endif
 constexpr bool kSignedLds = (TRG_TRAV_LDS == 4);
-constexpr uint32_t kLdsNodeBytes = kSignedLds ? 112u : 64u;
+constexpr uint32_t kLdsNodeBytes = kSignedLds ? 144u : 64u;
 static_assert(!kSignedLds || kWideHbm, "sign-ordered LDS nodes replace the BVH2 array: the HBM kernels must use the 4-wide tree");
 
 #define TRG_DECL_LAUNCHERS(SFX)                                                                                   \
