@@ -22,6 +22,11 @@ import os
 import sys
 import time
 
+# two launches overlap only when their streams sit on different hardware queues: HIP spreads streams round-robin over
+# GPU_MAX_HW_QUEUES (default 4) queues, and this process has five streams (two render, one communication, the
+# context's own, torch's) -- give every stream its own queue.  Must be set before the HIP runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -78,7 +83,9 @@ def main():
     from toyraygun_amd.dist import DistributedRenderer
 
     buffers, uniforms = cornell_buffers()
-    r = DistributedRenderer(W, H, local_rank, pipelined=distributed or bool(os.environ.get("TRG_FORCE_GATHER")))
+    # two frame buffers, two alternating render streams (+ a communication stream): consecutive steps are independent
+    # images, so step k+1 fills the CUs that the tail of step k leaves idle, and the gather of k overlaps the render of k+1
+    r = DistributedRenderer(W, H, local_rank, pipelined=not os.environ.get("TRG_BENCH_SERIAL"))
     r.load_scene(buffers)
     r.ctx.set_uniforms(uniforms)
     r.ctx.set_pixel_offsets_seed()
@@ -104,19 +111,16 @@ def main():
     for _ in range(args.warmup):
         r.render(0, SPP, BOUNCES, gather=gather)
     sync_all()
-    # average launch duration of the megakernel: HIP events on the stream it runs on (trg_render brackets the
-    # launch with hipEventRecord on the context's stream).  Single GPU: measured on every timed step.  Multi GPU:
-    # measured here on 3 extra launches, because the event wait is a host sync that would serialise the
-    # render/gather pipeline inside the timed region.
-    kernel_ms_pre = None
-    if gather:
-        r.ctx.reset_stats()
-        for _ in range(3):
-            r.ctx.render(0, SPP, BOUNCES, r.row0, r.rows)
-        pst = r.ctx.stats()
-        kernel_ms_pre = pst.total_render_ms / max(pst.renders, 1)
-        r.ctx.set_option(capi.OPT_TIMING, 0)
-        sync_all()
+    # average launch duration of the megakernel: HIP events on the stream it runs on (trg_render brackets the launch with
+    # hipEventRecord on the context's stream), measured here on 3 launches that run alone -- the event wait is a host
+    # sync, which would serialise the pipeline inside the timed region (and there two launches overlap on purpose).
+    r.ctx.reset_stats()
+    for _ in range(3):
+        r.ctx.render(0, SPP, BOUNCES, r.row0, r.rows)
+    pst = r.ctx.stats()
+    kernel_ms_pre = pst.total_render_ms / max(pst.renders, 1)
+    r.ctx.set_option(capi.OPT_TIMING, 0)
+    sync_all()
     r.ctx.reset_stats()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -126,7 +130,7 @@ def main():
     st = r.ctx.stats()
 
     rays_local = float(st.rays)
-    kernel_ms = kernel_ms_pre if kernel_ms_pre is not None else st.total_render_ms / max(st.renders, 1)
+    kernel_ms = kernel_ms_pre
     if distributed:
         t = torch.tensor([dt, rays_local, kernel_ms], dtype=torch.float64, device=dev)
         tmax = t.clone()
@@ -154,6 +158,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Cornell box (36 triangles) 1920x1080, 16 spp, 3 bounces (BASELINE configs[1])",
                        "rays_per_step": rays_total / args.steps, "sharding": "row bands + RCCL all-gather (double-buffered, gather k overlaps render k+1)" if distributed else "none",
+                       "pipeline": ("2 frames in flight on alternating streams: step k+1 fills the CUs the tail of step k leaves idle "
+                                    "(kernel_ms below is one launch running alone)") if getattr(r, "_overlap", False) else "serial launches",
                        "kernel": ("render_kernel" if st.last_frame_split <= 1 else "render_fp_kernel, %d frame lanes" % st.last_frame_split) + "<LDS scene> (fast build)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel_ms": kernel_ms, "algorithmic_bytes_per_ray": bytes_per_ray,

@@ -128,7 +128,10 @@ TRG_API int trg_set_pixel_offsets_seed(trg_ctx *ctx, uint32_t seed); /* offset(x
  *     `bounces` x [nearest-hit, primaryHit, any-hit, shadowHit], then accumulate, for frames
  *     frameIndexBegin .. frameIndexBegin+spp-1 over image rows [row0, row0+rows), in ONE launch.
  *     Result: running average in the float4 accumulation buffer (row 0 = scene bottom).  If
- *     frameIndexBegin > 0 the buffer must hold the average of frames [0, frameIndexBegin). */
+ *     frameIndexBegin > 0 the buffer must hold the average of frames [0, frameIndexBegin).
+ *     Asynchronous when TRG_OPT_TIMING is 0.  Launches of one context into DIFFERENT accumulation buffers (trg_bind_accum) on
+ *     different streams (trg_set_stream) may be in flight together when the scene is LDS-resident (trg_stats.scene_in_lds);
+ *     an HBM-resident scene shares one traversal-stack scratch per context, so keep its launches on one stream. */
 TRG_API int trg_render(trg_ctx *ctx, uint32_t frameIndexBegin, uint32_t spp, uint32_t bounces, uint32_t row0, uint32_t rows);
 
 /* --- read back the accumulation target (what the reference hands to its blit pass,

@@ -8,7 +8,10 @@ code at all; this is new.
 
 Streams: the megakernel runs on a render stream, the collective on a communication stream, ordered by
 events.  With two frame buffers (`pipelined=True`) the gather of frame k overlaps the render of frame
-k+1 -- at 8 GPUs a band of C2 renders in ~0.45 ms, about as long as the 33 MB gather takes.
+k+1, and consecutive frames render on TWO alternating streams: a launch ends with a tail in which most CUs
+are idle behind the last workgroups (a workgroup of a band lives about a quarter of the launch), and the
+next frame's workgroups fill those CUs instead of waiting for the drain.  Frames are independent images
+(own buffer, own stream); within a frame nothing changes.
 """
 import os
 
@@ -62,7 +65,8 @@ class DistributedRenderer:
         # torch owns the frames (so RCCL can see them); the kernel writes into them through trg_bind_accum
         self.frames = [torch.zeros((height, width, 4), dtype=torch.float32, device=self.device)
                        for _ in range(2 if pipelined else 1)]
-        self.render_stream = torch.cuda.Stream(self.device)
+        self.render_streams = [torch.cuda.Stream(self.device) for _ in range(2 if pipelined else 1)]
+        self.render_stream = self.render_streams[0]
         self.comm_stream = torch.cuda.Stream(self.device) if pipelined else self.render_stream
         self.ctx.set_stream(self.render_stream.cuda_stream)
         self.ctx.bind_accum(self.frames[0].data_ptr())
@@ -71,9 +75,14 @@ class DistributedRenderer:
         self._gathered = [None] * len(self.frames)  # event: last gather into frames[i] has finished
         self.frame = self.frames[0]
         self._needs_gather = self.world > 1 or bool(os.environ.get("TRG_FORCE_GATHER"))
+        self._last_stream = self.render_stream
+        self._overlap = False
 
     def load_scene(self, buffers):
         self.ctx.load_scene(buffers["positions"], buffers["normals"], buffers["colors"], buffers["indices"], buffers["material_ids"])
+        # two launches of one context may only be in flight together when they share no scratch: an HBM-resident scene
+        # spills deep traversal-stack levels to a per-context global buffer, so its frames stay on one stream
+        self._overlap = len(self.render_streams) > 1 and bool(self.ctx.stats().scene_in_lds)
 
     def render(self, frame_begin, spp, bounces, gather=True):
         """Render this rank's band; with gather=True every rank ends up with the whole frame.
@@ -81,15 +90,19 @@ class DistributedRenderer:
         i = self._step % len(self.frames)
         self._step += 1
         frame = self.frames[i]
+        rs = self.render_streams[i] if getattr(self, "_overlap", False) else self.render_stream
         if len(self.frames) > 1:
             self.ctx.bind_accum(frame.data_ptr())
+            if rs is not self._last_stream:
+                self.ctx.set_stream(rs.cuda_stream)
+                self._last_stream = rs
             if self._gathered[i] is not None:  # the previous gather into this buffer must be done
-                self.render_stream.wait_event(self._gathered[i])
+                rs.wait_event(self._gathered[i])
         self.ctx.render(frame_begin, spp, bounces, self.row0, self.rows)
         if gather and self._needs_gather:
-            if self.comm_stream is not self.render_stream:
+            if self.comm_stream is not rs:
                 done = torch.cuda.Event()
-                done.record(self.render_stream)
+                done.record(rs)
                 self.comm_stream.wait_event(done)
             with torch.cuda.stream(self.comm_stream):
                 gather_bands(frame, self.world, self.rank, self.group)
@@ -101,7 +114,8 @@ class DistributedRenderer:
         return frame
 
     def synchronize(self):
-        self.render_stream.synchronize()
+        for rs in self.render_streams:
+            rs.synchronize()
         self.comm_stream.synchronize()
 
     def close(self):
