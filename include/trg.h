@@ -87,6 +87,8 @@ enum trg_option {
     TRG_OPT_TIMING = 4,       /* 1 (default): bracket trg_render with HIP events (forces a stream sync) */
     TRG_OPT_GPU_BUILD = 6,    /* 1: the next trg_load_scene builds the BVH on the GPU (LBVH, 4-wide, HBM traversal only); 0 (default): host SAH build */
     TRG_OPT_KERNEL = 5,       /* which megakernel trg_render launches: TRG_KERNEL_DIRECT (default) or TRG_KERNEL_POOL */
+    TRG_OPT_LAUNCHES_IN_FLIGHT = 8, /* hint, default 1: how many trg_render launches of this context the caller keeps in flight on different
+                                 streams.  With 2 or more the automatic frame split favours throughput (the overlap hides a launch's tail) */
     TRG_OPT_FRAME_SPLIT = 7   /* TRG_KERNEL_DIRECT only: frame lanes per workgroup. 1: a pixel's frames run one after the other in one
                                  lane; 2 or 4: that many wavefronts share a pixel's frames (same result bit for bit; fills the chip
                                  when the pixel grid alone does not -- small windows, row bands of a multi-GPU job);

@@ -5,12 +5,14 @@ from toyraygun_amd import capi, host
 from toyraygun_amd.dist import DistributedRenderer, band_rows
 W, H = 1920, 1080
 b = host.Scene.cornell_box().buffers()
-for pipelined in (True, False, True):
-    r = DistributedRenderer(W, H, 0, pipelined=pipelined)
+import itertools
+for (pipelined, depth), fs in itertools.product(((True, 2), (False, 1)), (0,)):
+    r = DistributedRenderer(W, H, 0, pipelined=pipelined, depth=depth)
     r.load_scene(b); r.ctx.set_uniforms(host.uniforms(W, H)[0]); r.ctx.set_pixel_offsets_seed()
     r.ctx.set_option(capi.OPT_TIMING, 0)
+    r.ctx.set_option(capi.OPT_FRAME_SPLIT, fs)
     out = []
-    for n in (1, 2, 4, 8):
+    for n in (1, 2, 3, 4, 6, 8):
         r.row0, r.rows = band_rows(H, n, n // 2)
         for _ in range(5):
             r.render(0, 16, 3, gather=False)
@@ -21,5 +23,5 @@ for pipelined in (True, False, True):
             r.render(0, 16, 3, gather=False)
         r.synchronize()
         out.append("N=%d %.3f" % (n, (time.perf_counter() - t0) / K * 1e3))
-    print("two streams" if pipelined else "one stream ", " | ".join(out), "overlap", r._overlap, [x.cuda_stream for x in r.render_streams], flush=True)
+    print("%d streams fsplit %d" % (depth, fs), " | ".join(out), "overlap", r._overlap, [x.cuda_stream for x in r.render_streams], flush=True)
     r.close()

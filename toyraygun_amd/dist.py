@@ -52,7 +52,7 @@ def gather_bands(full, world, rank, group=None):
 class DistributedRenderer:
     """Row-band sharded renderer over an initialised process group (one rank per GPU)."""
 
-    def __init__(self, width, height, device_index, group=None, pipelined=False):
+    def __init__(self, width, height, device_index, group=None, pipelined=False, depth=2):
         from . import capi
         self.capi = capi
         self.group = group
@@ -64,8 +64,8 @@ class DistributedRenderer:
         self.ctx = capi.Context(width, height, device=device_index)
         # torch owns the frames (so RCCL can see them); the kernel writes into them through trg_bind_accum
         self.frames = [torch.zeros((height, width, 4), dtype=torch.float32, device=self.device)
-                       for _ in range(2 if pipelined else 1)]
-        self.render_streams = [torch.cuda.Stream(self.device) for _ in range(2 if pipelined else 1)]
+                       for _ in range(depth if pipelined else 1)]
+        self.render_streams = [torch.cuda.Stream(self.device) for _ in range(depth if pipelined else 1)]
         self.render_stream = self.render_streams[0]
         self.comm_stream = torch.cuda.Stream(self.device) if pipelined else self.render_stream
         self.ctx.set_stream(self.render_stream.cuda_stream)
@@ -83,6 +83,7 @@ class DistributedRenderer:
         # two launches of one context may only be in flight together when they share no scratch: an HBM-resident scene
         # spills deep traversal-stack levels to a per-context global buffer, so its frames stay on one stream
         self._overlap = len(self.render_streams) > 1 and bool(self.ctx.stats().scene_in_lds)
+        self.ctx.set_option(self.capi.OPT_LAUNCHES_IN_FLIGHT, len(self.render_streams) if self._overlap else 1)
 
     def render(self, frame_begin, spp, bounces, gather=True):
         """Render this rank's band; with gather=True every rank ends up with the whole frame.
