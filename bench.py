@@ -23,7 +23,7 @@ import sys
 import time
 
 # two launches overlap only when their streams sit on different hardware queues: HIP spreads streams round-robin over
-# GPU_MAX_HW_QUEUES (default 4) queues, and this process has five streams (two render, one communication, the
+# GPU_MAX_HW_QUEUES (default 4) queues, and this process has seven streams (four render, one communication, the
 # context's own, torch's) -- give every stream its own queue.  Must be set before the HIP runtime starts.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
@@ -83,8 +83,9 @@ def main():
     from toyraygun_amd.dist import DistributedRenderer
 
     buffers, uniforms = cornell_buffers()
-    # two frame buffers, two alternating render streams (+ a communication stream): consecutive steps are independent
-    # images, so step k+1 fills the CUs that the tail of step k leaves idle, and the gather of k overlaps the render of k+1
+    # four frame buffers on four alternating render streams (+ a communication stream): consecutive steps are independent
+    # images, so the next steps fill the CUs that the tail of step k leaves idle (or that a small row band never fills),
+    # and the gather of k overlaps the renders that follow
     r = DistributedRenderer(W, H, local_rank, pipelined=not os.environ.get("TRG_BENCH_SERIAL"))
     r.load_scene(buffers)
     r.ctx.set_uniforms(uniforms)
@@ -157,9 +158,9 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Cornell box (36 triangles) 1920x1080, 16 spp, 3 bounces (BASELINE configs[1])",
-                       "rays_per_step": rays_total / args.steps, "sharding": "row bands + RCCL all-gather (double-buffered, gather k overlaps render k+1)" if distributed else "none",
-                       "pipeline": ("2 frames in flight on alternating streams: step k+1 fills the CUs the tail of step k leaves idle "
-                                    "(kernel_ms below is one launch running alone)") if getattr(r, "_overlap", False) else "serial launches",
+                       "rays_per_step": rays_total / args.steps, "sharding": "row bands + RCCL all-gather (gather of step k overlaps the renders that follow)" if distributed else "none",
+                       "pipeline": ("%d frames in flight on alternating streams: later steps fill the CUs the tail of step k leaves idle "
+                                    "(kernel_ms below is one launch running alone)" % len(r.render_streams)) if getattr(r, "_overlap", False) else "serial launches",
                        "kernel": ("render_kernel" if st.last_frame_split <= 1 else "render_fp_kernel, %d frame lanes" % st.last_frame_split) + "<LDS scene> (fast build)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel_ms": kernel_ms, "algorithmic_bytes_per_ray": bytes_per_ray,

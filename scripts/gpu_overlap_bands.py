@@ -1,13 +1,19 @@
-"""Steady-state ms per step of one rank's row band, serial launches vs two frames in flight (no gather): python scripts/gpu_overlap_bands.py"""
+"""Steady-state ms per step of one rank's row band vs frames in flight (no gather), one process per configuration
+(streams map round-robin onto GPU_MAX_HW_QUEUES hardware queues): python scripts/gpu_overlap_bands.py [depth]"""
 import sys, time; sys.path.insert(0, ".")
 import torch
 from toyraygun_amd import capi, host
 from toyraygun_amd.dist import DistributedRenderer, band_rows
 W, H = 1920, 1080
 b = host.Scene.cornell_box().buffers()
-import itertools
-for (pipelined, depth), fs in itertools.product(((True, 2), (False, 1)), (0,)):
-    r = DistributedRenderer(W, H, 0, pipelined=pipelined, depth=depth)
+import os, subprocess
+if len(sys.argv) == 1:
+    for d in (1, 2, 4, 0):
+        subprocess.run([sys.executable, __file__, str(d)], env=dict(os.environ, GPU_MAX_HW_QUEUES="8"))
+    sys.exit(0)
+depth = int(sys.argv[1]); fs = 0
+for pipelined in (depth != 1,):
+    r = DistributedRenderer(W, H, 0, pipelined=pipelined, depth=depth or None)
     r.load_scene(b); r.ctx.set_uniforms(host.uniforms(W, H)[0]); r.ctx.set_pixel_offsets_seed()
     r.ctx.set_option(capi.OPT_TIMING, 0)
     r.ctx.set_option(capi.OPT_FRAME_SPLIT, fs)
@@ -23,5 +29,5 @@ for (pipelined, depth), fs in itertools.product(((True, 2), (False, 1)), (0,)):
             r.render(0, 16, 3, gather=False)
         r.synchronize()
         out.append("N=%d %.3f" % (n, (time.perf_counter() - t0) / K * 1e3))
-    print("%d streams fsplit %d" % (depth, fs), " | ".join(out), "overlap", r._overlap, [x.cuda_stream for x in r.render_streams], flush=True)
+    print("%s streams" % (depth or "auto(full frame)"), " | ".join(out), "overlap", r._overlap, [x.cuda_stream for x in r.render_streams], flush=True)
     r.close()

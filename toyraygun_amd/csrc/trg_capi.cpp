@@ -109,10 +109,11 @@ static uint32_t choose_fsplit(const trg_ctx *c, uint32_t spp, uint32_t rows) {
     if (c->opt_fsplit == 1 || spp < 2) return 1u;
     if (c->opt_fsplit == 2 || c->opt_fsplit == 4) return (uint32_t)c->opt_fsplit;
     const uint64_t groups = (uint64_t)((c->w + kTileW - 1) / kTileW) * ((rows + kTileH - 1) / kTileH);
-    // a caller that overlaps consecutive launches (two frames in flight) hides the tail by itself: then the frame-serial
-    // kernel wins down to about one resident set (C2 bands, two streams: 1/2 frame 0.99 vs 1.20 ms, 1/4 0.52 vs 0.61,
-    // 1/6 0.44 vs 0.42, 1/8 0.37 vs 0.31)
-    if (groups > (c->opt_in_flight >= 2 ? 1ull : 4ull) * kResidentGroups) return 1u;
+    // a caller that overlaps consecutive launches (k frames in flight on k streams) hides the tail by itself: then the
+    // frame-serial kernel wins as soon as the launches in flight together hold about two resident sets of workgroups
+    // (C2 bands, ms per step, frame-serial vs 4 lanes: 1/4 frame 0.56 vs 0.63 at k = 2; 1/8 frame 0.375 vs 0.314 at
+    // k = 2, 0.295 vs 0.312 at k = 3, 0.273 vs 0.311 at k = 4)
+    if (c->opt_in_flight >= 2 ? groups * (uint64_t)c->opt_in_flight >= 2ull * kResidentGroups : groups > 4ull * kResidentGroups) return 1u;
     return spp >= 4 ? 4u : 2u;
 }
 

@@ -52,7 +52,7 @@ def gather_bands(full, world, rank, group=None):
 class DistributedRenderer:
     """Row-band sharded renderer over an initialised process group (one rank per GPU)."""
 
-    def __init__(self, width, height, device_index, group=None, pipelined=False, depth=2):
+    def __init__(self, width, height, device_index, group=None, pipelined=False, depth=None):
         from . import capi
         self.capi = capi
         self.group = group
@@ -60,6 +60,13 @@ class DistributedRenderer:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.w, self.h = width, height
         self.device = torch.device("cuda", device_index)
+        self.row0, self.rows = band_rows(height, self.world, self.rank)
+        if depth is None:
+            # frames in flight: 2 hide the tail of a launch that fills the chip; a small band (a fraction of one resident set
+            # of workgroups) needs more to fill it at all.  4 is never worse than 2 (C2 ms per step, 2 -> 4 in flight: full
+            # frame 2.05 -> 2.05, 1/4 0.52 -> 0.50, 1/8 0.31 -> 0.27), costs three more 33 MB buffers and, with the
+            # communication stream, the context's and torch's, still fits the 8 hardware queues bench.py asks for.
+            depth = 4
         torch.cuda.set_device(self.device)
         self.ctx = capi.Context(width, height, device=device_index)
         # torch owns the frames (so RCCL can see them); the kernel writes into them through trg_bind_accum
@@ -70,7 +77,6 @@ class DistributedRenderer:
         self.comm_stream = torch.cuda.Stream(self.device) if pipelined else self.render_stream
         self.ctx.set_stream(self.render_stream.cuda_stream)
         self.ctx.bind_accum(self.frames[0].data_ptr())
-        self.row0, self.rows = band_rows(height, self.world, self.rank)
         self._step = 0
         self._gathered = [None] * len(self.frames)  # event: last gather into frames[i] has finished
         self.frame = self.frames[0]
