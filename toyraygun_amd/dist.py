@@ -15,8 +15,12 @@ next frame's workgroups fill those CUs instead of waiting for the drain.  Frames
 """
 import os
 
-import torch
-import torch.distributed as dist
+# launches overlap only when their streams sit on different hardware queues; HIP spreads streams round-robin over
+# GPU_MAX_HW_QUEUES (default 4).  Read when the HIP runtime starts, so this only helps if nothing touched the GPU yet.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 
 def band_rows(height, world, rank):
