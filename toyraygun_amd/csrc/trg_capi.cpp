@@ -28,8 +28,11 @@ struct trg_ctx {
     uint32_t *offsets = nullptr;
     unsigned long long *counters = nullptr;
     unsigned char *blob = nullptr;
-    int *stack_scratch = nullptr;      // global overflow levels of the traversal stacks (grow-only)
-    size_t stack_scratch_bytes = 0;
+    // global overflow levels of the traversal stacks (grow-only), one buffer per launch the caller keeps in flight
+    // (TRG_OPT_LAUNCHES_IN_FLIGHT): launch k uses slot k mod in_flight, so overlapping launches never share one
+    static constexpr int kScratchSlots = 16;
+    int *stack_scratch[kScratchSlots] = {};
+    size_t stack_scratch_bytes[kScratchSlots] = {};
     uint32_t bvh_depth4 = 0, bvh_nodes4 = 0;
     SceneDesc sc{};
     bool scene_loaded = false, have_uniforms = false, have_offsets = false;
@@ -45,6 +48,7 @@ struct trg_ctx {
     double last_ms = 0.0, total_ms = 0.0;
     uint32_t renders = 0;
     uint32_t last_fsplit = 1;
+    uint32_t launches = 0;   // trg_render launches since create (never reset: picks the scratch slot)
     std::string err;
 };
 
@@ -118,18 +122,18 @@ static uint32_t choose_fsplit(const trg_ctx *c, uint32_t spp, uint32_t rows) {
 }
 
 // global scratch for the stack levels that do not fit in LDS: overflow_levels x grid_threads ints
-static int ensure_stack_scratch(trg_ctx *c, const LdsPlan &plan, uint64_t grid_threads, StackDesc &out) {
+static int ensure_stack_scratch(trg_ctx *c, const LdsPlan &plan, uint64_t grid_threads, StackDesc &out, int slot = 0) {
     out.klds = plan.klds;
     out.overflow = nullptr;
     if (plan.overflow_levels == 0) return TRG_OK;
     const size_t need = (size_t)plan.overflow_levels * grid_threads * sizeof(int);
-    if (need > c->stack_scratch_bytes) {
-        if (c->stack_scratch) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->stack_scratch); c->stack_scratch = nullptr; c->stack_scratch_bytes = 0; }
-        hipError_t e = hipMalloc((void **)&c->stack_scratch, need);
+    if (need > c->stack_scratch_bytes[slot]) {
+        if (c->stack_scratch[slot]) { (void)hipDeviceSynchronize(); (void)hipFree(c->stack_scratch[slot]); c->stack_scratch[slot] = nullptr; c->stack_scratch_bytes[slot] = 0; }
+        hipError_t e = hipMalloc((void **)&c->stack_scratch[slot], need);
         if (e != hipSuccess) return fail(c, TRG_ERR_NOMEM, "stack scratch hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
-        c->stack_scratch_bytes = need;
+        c->stack_scratch_bytes[slot] = need;
     }
-    out.overflow = c->stack_scratch;
+    out.overflow = c->stack_scratch[slot];
     return TRG_OK;
 }
 
@@ -240,7 +244,8 @@ void trg_destroy(trg_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     if (c->blob) (void)hipFree(c->blob);
-    if (c->stack_scratch) (void)hipFree(c->stack_scratch);
+    for (int k = 0; k < trg_ctx::kScratchSlots; ++k)
+        if (c->stack_scratch[k]) (void)hipFree(c->stack_scratch[k]);
     if (c->counters) (void)hipFree(c->counters);
     if (c->offsets) (void)hipFree(c->offsets);
     if (c->accum_own) (void)hipFree(c->accum_own);
@@ -403,7 +408,7 @@ int trg_render(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces,
     const uint32_t tiles_y = (rows + tile_h - 1) / tile_h;
     if ((uint64_t)p.tiles_x * tiles_y > 0x7FFFFFFFull) return fail(c, TRG_ERR_RANGE, "trg_render: grid too large");
     const uint32_t grid = p.tiles_x * tiles_y;
-    if (int rc = ensure_stack_scratch(c, plan, (uint64_t)grid * kBlock, p.stack)) return rc;
+    if (int rc = ensure_stack_scratch(c, plan, (uint64_t)grid * kBlock, p.stack, (int)(c->launches % (uint32_t)c->opt_in_flight))) return rc;
 
     if (c->opt_timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     hipError_t e;
@@ -418,6 +423,7 @@ int trg_render(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces,
                           : launch_render_fast(p, plan.lds_scene, c->opt_counters, grid, plan.total, c->stream);
     if (e != hipSuccess) return fail(c, TRG_ERR_DEVICE, "trg_render: launch failed: %s", hipGetErrorString(e));
     c->renders++;
+    c->launches++;
     c->last_fsplit = fsplit;
     if (c->opt_timing) {
         HIPCHK(c, hipEventRecord(c->ev1, c->stream));

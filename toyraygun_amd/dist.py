@@ -90,9 +90,8 @@ class DistributedRenderer:
 
     def load_scene(self, buffers):
         self.ctx.load_scene(buffers["positions"], buffers["normals"], buffers["colors"], buffers["indices"], buffers["material_ids"])
-        # two launches of one context may only be in flight together when they share no scratch: an HBM-resident scene
-        # spills deep traversal-stack levels to a per-context global buffer, so its frames stay on one stream
-        self._overlap = len(self.render_streams) > 1 and bool(self.ctx.stats().scene_in_lds)
+        # tell the library how many launches overlap: each gets its own traversal-stack scratch, and the frame split adapts
+        self._overlap = len(self.render_streams) > 1
         self.ctx.set_option(self.capi.OPT_LAUNCHES_IN_FLIGHT, len(self.render_streams) if self._overlap else 1)
 
     def render(self, frame_begin, spp, bounces, gather=True):
