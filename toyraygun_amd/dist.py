@@ -6,12 +6,14 @@ full-frame device tensor; ONE all-gather at the end lands every band in place on
 pixels: no reduction, no change of floating-point summation order).  The reference has no multi-GPU
 code at all; this is new.
 
-Streams: the megakernel runs on a render stream, the collective on a communication stream, ordered by
-events.  With two frame buffers (`pipelined=True`) the gather of frame k overlaps the render of frame
-k+1, and consecutive frames render on TWO alternating streams: a launch ends with a tail in which most CUs
-are idle behind the last workgroups (a workgroup of a band lives about a quarter of the launch), and the
-next frame's workgroups fill those CUs instead of waiting for the drain.  Frames are independent images
-(own buffer, own stream); within a frame nothing changes.
+Streams: the megakernel runs on render streams, the collective on a communication stream, ordered by
+events.  With `pipelined=True` every frame has its own buffer, so the gather of frame k overlaps the
+renders that follow, and consecutive frames render on FOUR alternating streams: a launch ends with a
+tail in which most CUs are idle behind the last workgroups (a workgroup of a full C2 frame lives about
+a quarter of the launch) and a small row band never fills the chip at all; the next frames' workgroups
+use those CUs instead of waiting for the drain.  Frames are independent images (own buffer, own
+stream); within a frame nothing changes, and the library is told how many launches overlap
+(TRG_OPT_LAUNCHES_IN_FLIGHT: separate stack scratch per launch, frame split chosen accordingly).
 """
 import os
 
