@@ -292,6 +292,89 @@ def _random_soup(O, n, seed):
     return s
 
 
+@pytest.mark.parametrize("scale,shift,gpu_build", [(100.0, (5000.0, -3000.0, 800.0), 0), (0.01, (-7.0, 3.0, 11.0), 0),
+                                                   (100.0, (5000.0, -3000.0, 800.0), 1)])
+def test_intersector_far_from_the_origin(capi, O, scale, shift, gpu_build):
+    """Quantised wide nodes (8-bit child boxes against the node box) and the LBVH on geometry that is large / tiny and far
+    from the origin: nearest and any-hit queries stay bit-identical to the oracle, whose own tree uses float boxes."""
+    rng = np.random.default_rng(77)
+    n = 2500
+    ctr = rng.uniform(-1, 1, (n, 3))
+    tri = (ctr[:, None, :] + rng.normal(0, 0.05, (n, 3, 3))) * scale + np.asarray(shift)
+    tri = tri.astype(np.float32)
+    s = O.OracleScene()
+    eye = np.eye(4, dtype=np.float32)
+    for k in range(n):
+        s.add_geometry(tri[k], [0, 1, 2], eye, (0.5, 0.5, 0.5), 1)
+    b = s.buffers()
+    rays = np.zeros(30000, O.RAY_DTYPE)
+    rays["origin"] = (rng.uniform(-1.2, 1.2, (30000, 3)) * scale + np.asarray(shift)).astype(np.float32)
+    d = rng.normal(size=(30000, 3))
+    d[:300, 0] = 0.0; d[300:600, 1] = 0.0; d[600:700, :2] = 0.0     # axis-parallel rays: zero direction components
+    rays["direction"] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    rays["mask"] = 1
+    rays["maxDistance"] = np.where(rng.random(30000) < 0.3, rng.uniform(0.05, 2.0, 30000) * scale, np.inf).astype(np.float32)
+    ref = O.intersect_nearest(s, rays)
+    assert (ref["distance"] >= 0).mean() > 0.2
+    c = capi.Context(16, 16)
+    try:
+        c.set_option(capi.OPT_GPU_BUILD, gpu_build)
+        c.load_scene(b["positions"], b["normals"], b["colors"], b["indices"], b["material_ids"])
+        assert c.stats().scene_in_lds == 0
+        for strict in (1, 0):
+            c.set_option(capi.OPT_STRICT, strict)
+            got = c.trace(rays)
+            if strict:
+                assert np.array_equal(got.view(np.uint8), ref.view(np.uint8))
+            else:  # shipped build: same primitive on all but edge-grazing rays, distances within rounding
+                same = got["primitiveIndex"] == ref["primitiveIndex"]
+                assert same.mean() > 0.999
+                hit = same & (ref["distance"] >= 0)
+                assert np.allclose(got["distance"][hit], ref["distance"][hit], rtol=1e-4, atol=1e-6 * scale)
+            assert np.array_equal(c.trace(rays, any_hit=True) >= 0, O.intersect_any(s, rays) >= 0) or not strict
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("n,seed", [(40, 11), (120, 12)])
+def test_lds_resident_soup_parity(capi, O, n, seed):
+    """The same hostile soup small enough to be staged in LDS (sign-ordered BVH2 nodes): the intersector and the whole
+    path, strict build bit-exact against the oracle, the LDS-resident and the forced-HBM (quantised 4-wide) traversal of
+    the SAME scene agreeing with it and with each other, frame split and tiny / ragged image sizes included."""
+    scene = _random_soup(O, n, seed)
+    b = scene.buffers()
+    rays = _rays(O, 20000, 300 + seed, hi=(0.95, 1.9, 0.95))
+    ref_hits = O.intersect_nearest(scene, rays, brute=True)
+    ref_any = O.intersect_any(scene, rays) >= 0
+    for (w, h) in ((64, 48), (1, 1), (9, 1), (3, 19)):
+        off = O.pixel_offsets(w, h)
+        O.set_trig_mode(O.TRIG_PORTABLE)
+        try:
+            img_ref, rst = O.render(scene, w, h, 5, 4, offsets=off)
+        finally:
+            O.set_trig_mode(O.TRIG_LIBM)
+        c = capi.Context(w, h)
+        try:
+            c.load_scene(b["positions"], b["normals"], b["colors"], b["indices"], b["material_ids"])
+            c.set_uniforms(O.uniforms_bytes(O.make_uniforms(w, h)))
+            c.set_pixel_offsets(off)
+            c.set_option(capi.OPT_STRICT, 1)
+            for force_global in (0, 1):
+                c.set_option(capi.OPT_FORCE_GLOBAL, force_global)
+                if (w, h) == (64, 48):
+                    assert np.array_equal(c.trace(rays).view(np.uint8), ref_hits.view(np.uint8))
+                    assert np.array_equal(c.trace(rays, any_hit=True) >= 0, ref_any)
+                for fsplit in (1, 2, 4):
+                    c.set_option(capi.OPT_FRAME_SPLIT, fsplit)
+                    c.reset_stats()
+                    c.render(0, 5, 4)
+                    st = c.stats()
+                    assert np.array_equal(_bits(c.read_accum()), _bits(img_ref)), (w, h, force_global, fsplit)
+                    assert st.rays == rst.rays and st.scene_in_lds == (0 if force_global else 1)
+        finally:
+            c.close()
+
+
 @pytest.mark.parametrize("n,seed,gpu_build", [(300, 1, 0), (300, 2, 1), (3000, 3, 0), (3000, 4, 1)])
 def test_random_triangle_soup_parity(capi, O, n, seed, gpu_build):
     """Fuzz: the intersector and the whole path on random, partly degenerate geometry -- strict build bit-exact against

@@ -144,7 +144,11 @@ void build_bvh(const float *pos, const uint32_t *idx, const uint32_t *masks, uin
     // widened by far more than that so a triangle the Moeller-Trumbore test accepts is always reached.
     float diag = 0.f;
     if (ntris) diag = std::max({ scene.hi[0] - scene.lo[0], scene.hi[1] - scene.lo[1], scene.hi[2] - scene.lo[2] });
-    const float pad = 2e-5f * std::max(diag, 1e-3f);
+    // ... and by a few ulps of the largest coordinate: the slab test evaluates plane * (1/d) - origin * (1/d), whose
+    // rounding error grows with the distance from the origin, not with the size of the scene (a 2 cm object 10 m away)
+    float maxabs = 0.f;
+    if (ntris) for (int a = 0; a < 3; ++a) maxabs = std::max({ maxabs, std::fabs(scene.lo[a]), std::fabs(scene.hi[a]) });
+    const float pad = std::max(2e-5f * std::max(diag, 1e-3f), 4e-6f * maxabs);
 
     // ---- flatten: inner build nodes become device nodes, in depth-first order ----
     std::vector<int32_t> dev_index(B.nodes.size(), -1);

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -147,7 +148,9 @@ static int load_scene_gpu_build(trg_ctx *c, const float *pos, const float *nrm, 
         for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); }
     }
     const float diag = std::max({ hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2] });
-    const float pad = 2e-5f * std::max(diag, 1e-3f);  // same conservative padding as bvh_build.cpp
+    float maxabs = 0.f;
+    for (int a = 0; a < 3; ++a) maxabs = std::max({ maxabs, std::fabs(lo[a]), std::fabs(hi[a]) });
+    const float pad = std::max(2e-5f * std::max(diag, 1e-3f), 4e-6f * maxabs);  // same conservative padding as bvh_build.cpp
     struct Dev { void *p = nullptr; ~Dev() { if (p) (void)hipFree(p); } } d_pos, d_idx, d_mat, d_nodes4, d_tris;
     HIPCHK(c, hipMalloc(&d_pos.p, (size_t)n_verts * 12)); HIPCHK(c, hipMalloc(&d_idx.p, (size_t)n_tris * 12));
     HIPCHK(c, hipMalloc(&d_mat.p, (size_t)n_tris * 4)); HIPCHK(c, hipMalloc(&d_nodes4.p, (size_t)(n_tris - 1) * 128));
