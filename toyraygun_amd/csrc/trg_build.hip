@@ -127,12 +127,17 @@ __global__ void refit_kernel(const Box3 *prim_boxes, const unsigned long long *k
 }
 
 // depth of every internal node (root = 0) by walking up; kept[i] = depth even = becomes a 4-wide node
-__global__ void depth_kernel(const int *parent_int, int n_int, uint32_t *kept, int *max_depth) {
+// An internal node whose two children are single triangles never becomes a node of its own: the triangles sit next to
+// each other in the sorted order, so whoever references it references a two-triangle leaf instead (the host builder's
+// leaves hold up to two triangles as well).  The root is exempt.
+__device__ __forceinline__ bool is_pair(const int *left, const int *right, int i) { return i > 0 && left[i] < 0 && right[i] < 0; }
+
+__global__ void depth_kernel(const int *parent_int, const int *left, const int *right, int n_int, uint32_t *kept, int *max_depth) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_int) return;
     int d = 0;
     for (int p = parent_int[i]; p >= 0; p = parent_int[p]) ++d;
-    kept[i] = (d & 1) == 0 ? 1u : 0u;
+    kept[i] = ((d & 1) == 0 && !is_pair(left, right, i)) ? 1u : 0u;
     atomicMax(max_depth, d);
 }
 
@@ -144,7 +149,7 @@ __global__ void emit_wide_kernel(const Box3 *prim_boxes, const unsigned long lon
     int child[4]; int n = 0;
     const int c2[2] = { left[i], right[i] };
     for (int k = 0; k < 2; ++k) {
-        if (c2[k] >= 0) { child[n++] = left[c2[k]]; child[n++] = right[c2[k]]; }
+        if (c2[k] >= 0 && !is_pair(left, right, c2[k])) { child[n++] = left[c2[k]]; child[n++] = right[c2[k]]; }
         else child[n++] = c2[k];
     }
     float v[6][4]; int ref[4];
@@ -154,7 +159,8 @@ __global__ void emit_wide_kernel(const Box3 *prim_boxes, const unsigned long lon
         if (k >= n) continue;
         const int c = child[k];
         const Box3 *b;
-        if (c >= 0) { b = &node_boxes[c]; ref[k] = (int)wide_index[c]; }          // grandchild: kept (depth + 2)
+        if (c >= 0 && is_pair(left, right, c)) { b = &node_boxes[c]; ref[k] = ~(int)((((uint32_t)~left[c]) << 3) | 1u); }  // two-triangle leaf
+        else if (c >= 0) { b = &node_boxes[c]; ref[k] = (int)wide_index[c]; }          // grandchild: kept (depth + 2)
         else { const uint32_t r = (uint32_t)~c; b = &prim_boxes[(uint32_t)(keys[r] & 0xFFFFFFFFull)]; ref[k] = ~(int)(r << 3); }  // leaf of one triangle
         for (int a = 0; a < 3; ++a) { v[a * 2][k] = b->lo[a]; v[a * 2 + 1][k] = b->hi[a]; }
     }
@@ -219,7 +225,8 @@ hipError_t gpu_build_lbvh(const float *d_pos, const uint32_t *d_idx, const uint3
                        par_l.as<int>());
     hipLaunchKernelGGL(refit_kernel, dim3((n + T - 1) / T), dim3(T), 0, s, boxes.as<Box3>(), keys, n, left.as<int>(), right.as<int>(),
                        par_i.as<int>(), par_l.as<int>(), nboxes.as<Box3>(), arrive.as<int>());
-    hipLaunchKernelGGL(depth_kernel, dim3((n_int + T - 1) / T), dim3(T), 0, s, par_i.as<int>(), n_int, kept.as<uint32_t>(), maxd.as<int>());
+    hipLaunchKernelGGL(depth_kernel, dim3((n_int + T - 1) / T), dim3(T), 0, s, par_i.as<int>(), left.as<int>(), right.as<int>(), n_int,
+                       kept.as<uint32_t>(), maxd.as<int>());
     tmp_bytes = 0;
     BCHK(rocprim::exclusive_scan(nullptr, tmp_bytes, kept.as<uint32_t>(), widx.as<uint32_t>(), 0u, (size_t)n_int, rocprim::plus<uint32_t>(), s));
     BCHK(scan_tmp.alloc(tmp_bytes));
