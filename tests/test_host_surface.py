@@ -262,6 +262,21 @@ def test_quantised_wide_nodes_are_conservative(built, O):
                 assert (ql[~used] == 255).all() and (qh[~used] == 0).all()
 
 
+def test_host_builder_under_sanitizers():
+    """The host BVH builder, the 4-wide collapse and the node quantiser compiled with -fsanitize=address,undefined
+    (g++, CPU only: GPU sanitizers are not available) on empty, tiny, degenerate-heavy and 200 k-triangle inputs."""
+    import tempfile
+    csrc = os.path.join(ROOT, "toyraygun_amd", "csrc")
+    with tempfile.TemporaryDirectory() as td:
+        exe = os.path.join(td, "san")
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                               "-fno-omit-frame-pointer", "-I" + csrc, os.path.join(ROOT, "tests", "helpers", "bvh_sanitize.cpp"),
+                               os.path.join(csrc, "bvh_build.cpp"), "-o", exe])
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "n=200000" in r.stdout and "ERROR" not in r.stderr and "runtime error" not in r.stderr
+
+
 def test_halton_device_identities():
     """The two arithmetic identities behind the device Halton code, checked exhaustively in C
     (tests/helpers/halton_identities.c): fp32 digit extraction for every n < 2^22 and every prime of the table,
