@@ -164,7 +164,8 @@ def main():
                                     "(kernel_ms below is one launch running alone)" % len(r.render_streams)) if getattr(r, "_overlap", False) else "serial launches",
                        "kernel": ("render_kernel" if st.last_frame_split <= 1 else "render_fp_kernel, %d frame lanes" % st.last_frame_split) + "<LDS scene> (fast build)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel_ms": kernel_ms, "algorithmic_bytes_per_ray": bytes_per_ray,
+                         "traffic": traffic, "kernel_ms": kernel_ms, "kernel_alone_mrays_per_s": rays_per_launch / (kernel_ms * 1e-3) / 1e6,
+                         "algorithmic_bytes_per_ray": bytes_per_ray,
                          "bytes_per_launch": rays_per_launch * bytes_per_ray, **mix,
                          "note": "the scene (%.1f KB on the device) is LDS-resident:" % (cst.scene_bytes / 1024.0) + " the algorithmic bytes are served from LDS, so frac > 1 is expected; real HBM traffic (`traffic`, rocprofv3 FETCH_SIZE+WRITE_SIZE) is the offset read, the float4 write and spill scratch (SURVEY 8d caveat)"},
         }
