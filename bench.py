@@ -124,28 +124,36 @@ def main():
     r.ctx.set_option(capi.OPT_TIMING, 0)
     sync_all()
     r.ctx.reset_stats()
+    r.time_launches = True   # HIP events around every launch, on the stream it runs on, no host sync
     t0 = time.perf_counter()
     for _ in range(args.steps):
         r.render(0, SPP, BOUNCES, gather=gather)
     sync_all()
     dt = time.perf_counter() - t0
+    r.time_launches = False
+    launch_ms = r.launch_ms()
     st = r.ctx.stats()
 
     rays_local = float(st.rays)
-    kernel_ms = kernel_ms_pre
+    # average launch duration over the timed region (what rocprofv3 --kernel-trace reports for the same command).  With
+    # several launches in flight each one shares the GPU and lasts longer than alone; `concurrency` = sum of the launch
+    # durations / wall time says how many overlapped, and kernel_ms / concurrency is the time the GPU spent per launch.
+    kernel_ms = sum(launch_ms) / max(len(launch_ms), 1)
+    concurrency = max(1.0, sum(launch_ms) / (dt * 1e3))
     if distributed:
-        t = torch.tensor([dt, rays_local, kernel_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt, rays_local, kernel_ms / concurrency], dtype=torch.float64, device=dev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt, rays_total, kernel_ms = float(tmax[0]), float(tsum[1]), float(tmax[2])
+        dt, rays_total, kernel_eff_ms = float(tmax[0]), float(tsum[1]), float(tmax[2])
     else:
         rays_total = rays_local
+        kernel_eff_ms = kernel_ms / concurrency
 
     if rank == 0:
         value = rays_total / dt / 1e6
-        achieved = rays_per_launch * bytes_per_ray / (kernel_ms * 1e-3) / 1e9  # GB/s, dominant kernel on this rank
+        achieved = rays_per_launch * bytes_per_ray / (kernel_eff_ms * 1e-3) / 1e9  # GB/s, dominant kernel (slowest rank)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_c2.json")
         if world == 1 and os.path.exists(tpath):
@@ -161,10 +169,11 @@ def main():
             "config": {"workload": "Cornell box (36 triangles) 1920x1080, 16 spp, 3 bounces (BASELINE configs[1])",
                        "rays_per_step": rays_total / args.steps, "sharding": "row bands + RCCL all-gather (gather of step k overlaps the renders that follow)" if distributed else "none",
                        "pipeline": ("%d frames in flight on alternating streams: later steps fill the CUs the tail of step k leaves idle "
-                                    "(kernel_ms below is one launch running alone)" % len(r.render_streams)) if getattr(r, "_overlap", False) else "serial launches",
+                                    "(roofline.kernel_ms = average launch duration while they overlap; kernel_alone_ms = one launch by itself)" % len(r.render_streams)) if getattr(r, "_overlap", False) else "serial launches",
                        "kernel": ("render_kernel" if st.last_frame_split <= 1 else "render_fp_kernel, %d frame lanes" % st.last_frame_split) + "<LDS scene> (fast build)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel_ms": kernel_ms, "kernel_alone_mrays_per_s": rays_per_launch / (kernel_ms * 1e-3) / 1e6,
+                         "traffic": traffic, "kernel_ms": kernel_ms, "launches_in_flight": concurrency, "kernel_ms_per_launch_effective": kernel_eff_ms,
+                         "kernel_alone_ms": kernel_ms_pre, "kernel_alone_mrays_per_s": rays_per_launch / (kernel_ms_pre * 1e-3) / 1e6,
                          "algorithmic_bytes_per_ray": bytes_per_ray,
                          "bytes_per_launch": rays_per_launch * bytes_per_ray, **mix,
                          "note": "the scene (%.1f KB on the device) is LDS-resident:" % (cst.scene_bytes / 1024.0) + " the algorithmic bytes are served from LDS, so frac > 1 is expected; real HBM traffic (`traffic`, rocprofv3 FETCH_SIZE+WRITE_SIZE) is the offset read, the float4 write and spill scratch (SURVEY 8d caveat)"},

@@ -36,6 +36,22 @@ for cfg in ("c2", "c4"):
         stats = [r for r in csv.DictReader(open(f))][:4]
         open(f"{out}/{cfg}_kernel_stats.csv", "w").write(open(f).read())
     summary[cfg] = {"kernel_stats_top": stats, "pmc_per_launch": counters}
+# per-launch view of the C2 trace: bench.py runs 3 launches alone (HIP-event timed) and then keeps 4 in flight, so the
+# kernel_stats average mixes two populations; list them apart (overlap = launches whose interval intersects another one's)
+launches = []
+for f in glob.glob(f"{out}/c2_trace/*/*_kernel_trace.csv"):
+    for r in csv.DictReader(open(f)):
+        if "render_kernel<true, false>" in r["Kernel_Name"]:
+            launches.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+launches.sort()
+alone, shared = [], []
+for i, (a, b) in enumerate(launches):
+    over = any(j != i and launches[j][0] < b and launches[j][1] > a for j in range(len(launches)))
+    (shared if over else alone).append((b - a) / 1e6)
+if launches:
+    summary["c2"]["launches"] = {"alone_ms": alone, "overlapped_ms": shared,
+                                 "overlapped_mean_ms": sum(shared) / max(len(shared), 1), "alone_mean_ms": sum(alone) / max(len(alone), 1)}
+    print("c2 launches alone:", [round(x, 3) for x in alone], "overlapped:", [round(x, 3) for x in shared])
 json.dump(summary, open(f"{out}/summary.json", "w"), indent=1)
 for cfg in summary:
     for k, cs in summary[cfg]["pmc_per_launch"].items():

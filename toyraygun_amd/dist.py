@@ -89,6 +89,8 @@ class DistributedRenderer:
         self._needs_gather = self.world > 1 or bool(os.environ.get("TRG_FORCE_GATHER"))
         self._last_stream = self.render_stream
         self._overlap = False
+        self.time_launches = False   # bracket every launch with timing events on its stream (no host sync); see launch_ms()
+        self._timed = []
 
     def load_scene(self, buffers):
         self.ctx.load_scene(buffers["positions"], buffers["normals"], buffers["colors"], buffers["indices"], buffers["material_ids"])
@@ -110,7 +112,14 @@ class DistributedRenderer:
                 self._last_stream = rs
             if self._gathered[i] is not None:  # the previous gather into this buffer must be done
                 rs.wait_event(self._gathered[i])
-        self.ctx.render(frame_begin, spp, bounces, self.row0, self.rows)
+        if self.time_launches:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(rs)
+            self.ctx.render(frame_begin, spp, bounces, self.row0, self.rows)
+            e1.record(rs)
+            self._timed.append((e0, e1))
+        else:
+            self.ctx.render(frame_begin, spp, bounces, self.row0, self.rows)
         if gather and self._needs_gather:
             if self.comm_stream is not rs:
                 done = torch.cuda.Event()
@@ -124,6 +133,13 @@ class DistributedRenderer:
                     self._gathered[i] = ev
         self.frame = frame
         return frame
+
+    def launch_ms(self):
+        """Durations (ms) of the launches rendered while time_launches was set, from events on their own streams; call after
+        synchronize().  Overlapping launches share the GPU, so each lasts longer than it would alone."""
+        out = [a.elapsed_time(b) for a, b in self._timed]
+        self._timed = []
+        return out
 
     def synchronize(self):
         for rs in self.render_streams:
