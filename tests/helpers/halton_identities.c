@@ -1,6 +1,7 @@
 /* Exhaustive CPU validation of the two identities the device Halton code relies on (trg_device.h halton_c):
  *  (1) for every prime base b of the table and every integer n < 2^22:  floor((n + 0.5) * fl(1/b)) == n div b
  *      and fma(-q, b, n) == n mod b;
+ *  (3) the same quotient identity for every power b^k <= 2^22 (the digits are then independent of one another);
  *  (2) the closed form of the base-2 radical inverse equals the reference's fp32 loop (strided sample here;
  *      the full 2^32 sweep was run once when the code was written: 0 mismatches).
  * Build: gcc -O2 -fopenmp -mfma -ffp-contract=off halton_identities.c -lm */
@@ -22,6 +23,20 @@ int main(){
     }
   }
   printf("bad=%ld\n",bad);
+  // (3) every quotient straight from n: floor((n + 0.5) * fl(1 / b^k)) == n div b^k for all n < 2^22 and all b^k <= 2^22
+  long bad3=0; long powers=0;
+  for(int d=1; d<64; ++d){
+    uint32_t b=P[d];
+    for(uint64_t m=(uint64_t)b*b; m<=(1ull<<22); m*=b){
+      float rcp=1.0f/(float)m; uint32_t mm=(uint32_t)m; powers++;
+      #pragma omp parallel for reduction(+:bad3)
+      for(uint32_t n=0;n<(1u<<22);++n){
+        float q=floorf(((float)n+0.5f)*rcp);
+        if((uint32_t)q!=n/mm) bad3++;
+      }
+    }
+  }
+  printf("bad3=%ld powers=%ld\n",bad3,powers);
   // base-2 closed form vs loop, sampled + structured
   long bad2=0;
   #pragma omp parallel for reduction(+:bad2)

@@ -287,7 +287,7 @@ def test_halton_device_identities():
         exe = os.path.join(td, "hi")
         subprocess.check_call(["gcc", "-O2", "-fopenmp", "-mfma", "-ffp-contract=off", src, "-o", exe, "-lm"])
         out = subprocess.run([exe], capture_output=True, text=True, timeout=600).stdout
-    assert "bad=0" in out and "bad2=0" in out, out
+    assert "bad=0" in out and "bad2=0" in out and "bad3=0" in out, out
 
 
 def test_bvh_is_deterministic_and_shallow_enough(built, O):

@@ -94,6 +94,17 @@ struct HaltonTab {
         for (int k = 0; k < 33; ++k) { v = v * invB; f[k] = v; }
     }
 };
+template <uint32_t B>
+struct HaltonRcpPow {
+    float f[24];  // f[k] = fl(1 / b^k) for the powers b^k <= 2^22 (b^k is exact in fp32), 0 beyond
+    constexpr HaltonRcpPow() : f{} {
+        uint64_t v = 1;
+        for (int k = 0; k < 24; ++k) {
+            f[k] = v <= (1ull << 22) ? 1.0f / (float)v : 0.0f;
+            v = v * B > (1ull << 40) ? (1ull << 40) : v * B;
+        }
+    }
+};
 // Device evaluation of one dimension, bit-identical to the reference loop (validated exhaustively on the
 // CPU by tests/helpers/halton_identities.c):
 //  * base 2: closed form.  The running sum keeps the exponent of its first (largest) term, so every later
@@ -140,27 +151,38 @@ TRG_DEV float halton_c(uint32_t i) {
         constexpr int K1 = halton_lo_digits(B);
         constexpr uint32_t B1 = halton_pow(B, K1);
         constexpr HaltonTab<B> tab{};
-        constexpr float bf = (float)B, rcp = 1.0f / (float)B;
+        constexpr HaltonRcpPow<B> rp{};
+        constexpr float bf = (float)B;
         const uint32_t hi = i / B1;
         const uint32_t lo = i - hi * B1;
         float r = 0.0f;
-        float n = (float)lo;
+        // Every quotient comes straight from n -- q_k = floor((n + 0.5) * fl(1 / b^k)) = n div b^k exactly for n < 2^22
+        // (same error bound as for k = 1; checked exhaustively in tests/helpers/halton_identities.c) -- instead of from
+        // the previous quotient, so the digits d_k = q_k - b * q_{k+1} are independent of one another: no serial
+        // add -> mul -> floor chain per digit, and one instruction less.  The sum still runs in digit order.
+        {
+            const float n = (float)lo, nh = n + 0.5f;
+            float q0 = n;
 #pragma unroll
-        for (int k = 0; k < K1; ++k) {
-            const float q = __builtin_floorf((n + 0.5f) * rcp);
-            const float dig = __builtin_fmaf(q, -bf, n);
-            const float t = tab.f[k] * dig;
-            r = r + t;
-            n = q;
+            for (int k = 0; k < K1; ++k) {
+                const float q1 = (k + 1 < K1) ? __builtin_floorf(nh * rp.f[k + 1]) : 0.0f;  // lo < b^K1
+                const float dig = __builtin_fmaf(q1, -bf, q0);
+                const float t = tab.f[k] * dig;
+                r = r + t;
+                q0 = q1;
+            }
         }
-        n = (float)hi;
+        {
+            const float n = (float)hi, nh = n + 0.5f;
+            float q0 = n;
 #pragma unroll
-        for (int k = K1; k < N; ++k) {
-            const float q = __builtin_floorf((n + 0.5f) * rcp);
-            const float dig = __builtin_fmaf(q, -bf, n);
-            const float t = tab.f[k] * dig;
-            r = r + t;
-            n = q;
+            for (int k = 0; k < N - K1; ++k) {
+                const float q1 = (k + 1 < N - K1) ? __builtin_floorf(nh * rp.f[k + 1]) : 0.0f;  // hi < b^(N-K1)
+                const float dig = __builtin_fmaf(q1, -bf, q0);
+                const float t = tab.f[K1 + k] * dig;
+                r = r + t;
+                q0 = q1;
+            }
         }
         return r;
     }
