@@ -347,9 +347,17 @@ TRG_DEV void trg_sincos(float phi, float &s_out, float &c_out) {
 // common.h:80-91
 TRG_DEV V3 sample_cosine_hemisphere(float ux, float uy) {
     const float PI_F = 3.1415926535898f;
-    const float phi = 2.0f * PI_F * ux;
     float sin_phi, cos_phi;
+#if TRG_STRICT
+    const float phi = 2.0f * PI_F * ux;
     trg_sincos(phi, sin_phi, cos_phi);
+#else
+    // shipped build: v_sin_f32 / v_cos_f32 take their argument in revolutions, which is exactly ux -- two
+    // transcendental instructions instead of the range reduction and two polynomials
+    (void)PI_F;
+    sin_phi = __builtin_amdgcn_sinf(ux);
+    cos_phi = __builtin_amdgcn_cosf(ux);
+#endif
     const float cos_theta = sqrt_fast(uy);
     const float sin_theta = sqrt_fast(1.0f - cos_theta * cos_theta);
     return mk(sin_theta * cos_phi, cos_theta, sin_theta * sin_phi);
