@@ -619,10 +619,14 @@ TRG_DEV void trav_leaf_step(const SceneView &sc, Trav &tv, bool any, STK stk, Co
     const uint32_t code = (uint32_t)~tv.node;
     const uint32_t first = code >> 3, count = (code & 7u) + 1u;
     bool stop = false;
-    for (uint32_t k = 0; k < count; ++k) {
-        const v4f *tr = sc.tris + (first + k) * 3;
-        const v4f a = tr[0], b = tr[1], c = tr[2];
-        if (trav_tri_math<COUNT>(a, b, c, tv, any, cnt)) { stop = true; break; }
+    {   // leaves of the host builder hold one or two triangles: those without a loop (-2 %); more only from other builders
+        const v4f *tr = sc.tris + first * 3;
+        stop = trav_tri_math<COUNT>(tr[0], tr[1], tr[2], tv, any, cnt);
+        if (!stop && count > 1u) stop = trav_tri_math<COUNT>(tr[3], tr[4], tr[5], tv, any, cnt);
+        for (uint32_t k = 2; k < count && !stop; ++k) {
+            const v4f *t2 = sc.tris + (first + k) * 3;
+            stop = trav_tri_math<COUNT>(t2[0], t2[1], t2[2], tv, any, cnt);
+        }
     }
     const bool empty = stk.empty(tv.sp);
     int sp = tv.sp - ((stop || empty) ? 0 : STK::unit);
