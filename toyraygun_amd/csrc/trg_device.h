@@ -434,7 +434,11 @@ TRG_DEV bool tri_test(const v4f a, const v4f b, const v4f c, V3 o, V3 d, float t
     const V3 q = cross(tv, e1);
     v = dot(d, q) * inv;
     t = dot(e2, q) * inv;
+#ifdef TRG_EXP_BITTRI
+    return (u >= 0.0f) & (v >= 0.0f) & ((u + v) <= 1.0f) & (t >= 0.0f) & (t <= tmax_ray);
+#else
     return (u >= 0.0f) && (v >= 0.0f) && ((u + v) <= 1.0f) && (t >= 0.0f) && (t <= tmax_ray);
+#endif
 }
 
 // Per-lane traversal stack, laid out [level][thread] so lane i always hits LDS bank i%32 (no conflicts).
@@ -575,7 +579,9 @@ TRG_DEV void trav_node_step_signed(const SceneView &sc, Trav &tv, STK stk, Count
     const bool both = ha && hb, none = !(ha || hb);
     const bool first1 = hb && (!ha || bmin < amin);
     const int nearc = first1 ? c1 : c0, farc = first1 ? c0 : c1;
-    if (both) stk.push(tv.sp, farc);
+    // the slot above the top is scratch (the stack holds depth + 2 levels, a near-first BVH2 walk keeps at most one
+    // pending entry per level): write the far child always and keep it only if both children are entered -- no branch (-1 %)
+    stk.push(tv.sp, farc);
     int sp = tv.sp + (both ? STK::unit : 0);
     int next = nearc;
     if (none) {
@@ -603,7 +609,11 @@ TRG_DEV bool trav_tri_math(const v4f a, const v4f b, const v4f c, Trav &tv, bool
     float t, u, v;
     const bool ok = tri_test(a, b, c, tv.o, tv.d, tv.tmax, t, u, v) && masked_in;
     const int prim = __float_as_int(a.w);
+#ifdef TRG_EXP_BITTAKE
+    const bool take = ok & (any | !tv.found | (t < tv.best) | ((t == tv.best) & (prim < tv.hit.prim)));
+#else
     const bool take = ok && (any || !tv.found || t < tv.best || (t == tv.best && prim < tv.hit.prim));
+#endif
     tv.found = tv.found || ok;
     tv.best = (take && !any) ? t : tv.best;
     tv.hit.t = take ? t : tv.hit.t;
