@@ -434,11 +434,7 @@ TRG_DEV bool tri_test(const v4f a, const v4f b, const v4f c, V3 o, V3 d, float t
     const V3 q = cross(tv, e1);
     v = dot(d, q) * inv;
     t = dot(e2, q) * inv;
-#ifdef TRG_EXP_BITTRI
-    return (u >= 0.0f) & (v >= 0.0f) & ((u + v) <= 1.0f) & (t >= 0.0f) & (t <= tmax_ray);
-#else
     return (u >= 0.0f) && (v >= 0.0f) && ((u + v) <= 1.0f) && (t >= 0.0f) && (t <= tmax_ray);
-#endif
 }
 
 // Per-lane traversal stack, laid out [level][thread] so lane i always hits LDS bank i%32 (no conflicts).
@@ -609,11 +605,7 @@ TRG_DEV bool trav_tri_math(const v4f a, const v4f b, const v4f c, Trav &tv, bool
     float t, u, v;
     const bool ok = tri_test(a, b, c, tv.o, tv.d, tv.tmax, t, u, v) && masked_in;
     const int prim = __float_as_int(a.w);
-#ifdef TRG_EXP_BITTAKE
-    const bool take = ok & (any | !tv.found | (t < tv.best) | ((t == tv.best) & (prim < tv.hit.prim)));
-#else
     const bool take = ok && (any || !tv.found || t < tv.best || (t == tv.best && prim < tv.hit.prim));
-#endif
     tv.found = tv.found || ok;
     tv.best = (take && !any) ? t : tv.best;
     tv.hit.t = take ? t : tv.hit.t;
