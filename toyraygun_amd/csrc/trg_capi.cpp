@@ -282,7 +282,7 @@ int trg_load_scene(trg_ctx *c, const float *pos, const float *nrm, const float *
     // [ BVH2 nodes | triangle records | normals | colours | material ids ] [ quantised 4-wide nodes | 128 B pad ]
     // The first bracket is what a workgroup stages into LDS when it is small enough; scenes that can only be
     // traversed from HBM skip the BVH2 nodes when the HBM kernels use the 4-wide tree.
-    const uint64_t small_bytes = (uint64_t)bvh.n_nodes * kLdsNodeBytes + (uint64_t)nt_rec * 48u + (uint64_t)attr_tris * 76u + 64u;
+    const uint64_t small_bytes = (uint64_t)bvh.n_nodes * kLdsNodeBytes + (uint64_t)nt_rec * 48u + (uint64_t)attr_tris * 76u + 64u + kHtabBytes;
     const bool lds_candidate = small_bytes <= kMaxLdsScene;
     const bool keep_bvh2 = lds_candidate || !kWideHbm;
     SceneDesc sc{};
@@ -293,10 +293,11 @@ int trg_load_scene(trg_ctx *c, const float *pos, const float *nrm, const float *
     sc.off_normals = align16(sc.off_tris + nt_rec * 48u);
     sc.off_colors = align16(sc.off_normals + attr_tris * 36u);
     sc.off_mats = align16(sc.off_colors + attr_tris * 36u);
-    sc.off_nodes4 = align16(sc.off_mats + attr_tris * 4u);
+    sc.off_htab = align16(sc.off_mats + attr_tris * 4u);
+    sc.off_nodes4 = align16(sc.off_htab + (lds_candidate ? kHtabBytes : 0u));
     sc.off_nodes4 = (sc.off_nodes4 + 127u) & ~127u;  // 64-byte nodes, two per 128-byte line
     sc.n_nodes4 = kWideHbm ? bvh.n_nodes4 : 0u;
-    sc.lds_stage_bytes = lds_candidate ? align16(sc.off_mats + attr_tris * 4u) : 0u;
+    sc.lds_stage_bytes = lds_candidate ? align16(sc.off_htab + kHtabBytes) : 0u;
     const uint64_t total = (uint64_t)sc.off_nodes4 + (uint64_t)sc.n_nodes4 * kQ4NodeBytes + 128u;
     if (total > 0xFFFFFFF0ull) return fail(c, TRG_ERR_RANGE, "trg_load_scene: scene needs %llu B on the device (limit 4 GiB)", (unsigned long long)total);
     sc.blob_bytes = (uint32_t)total;
@@ -335,6 +336,16 @@ int trg_load_scene(trg_ctx *c, const float *pos, const float *nrm, const float *
         memcpy(hn, nrm, (size_t)n_tris * 36);
         memcpy(hc, col, (size_t)n_tris * 36);
         memcpy(&host[sc.off_mats], mat, (size_t)n_tris * 4);
+    }
+    if (lds_candidate) {  // Halton group tables (trg_kernels.h kHtab)
+        float *T = reinterpret_cast<float *>(&host[sc.off_htab]);
+        for (const HtabSpec &h : kHtab)
+            for (uint32_t r = 0; r < h.radix; ++r) {
+                double v = 0.0, f = 1.0;
+                uint32_t x = r;
+                for (uint32_t j = 0; j < h.digits; ++j) { f /= (double)h.base; v += f * (double)(x % h.base); x /= h.base; }
+                T[h.offset + r] = (float)v;
+            }
     }
     if (sc.n_nodes4) memcpy(&host[sc.off_nodes4], bvh.nodes4q.data(), (size_t)sc.n_nodes4 * kQ4NodeBytes);
 

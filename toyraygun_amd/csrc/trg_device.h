@@ -105,6 +105,14 @@ struct HaltonRcpPow {
         }
     }
 };
+template <uint32_t B>
+struct HaltonWeight {
+    float f[33];  // f[k] = b^-k, correctly rounded (weight of a digit group that starts at digit k)
+    constexpr HaltonWeight() : f{} {
+        double v = 1.0;
+        for (int k = 0; k < 33; ++k) { f[k] = (float)v; v /= (double)B; }
+    }
+};
 // Device evaluation of one dimension, bit-identical to the reference loop (validated exhaustively on the
 // CPU by tests/helpers/halton_identities.c):
 //  * base 2: closed form.  The running sum keeps the exponent of its first (largest) term, so every later
@@ -187,27 +195,80 @@ TRG_DEV float halton_c(uint32_t i) {
         return r;
     }
 }
+// Table form of dimensions 1..5 (bases 3, 5, 7, 11, 13) for the shipped megakernel on an LDS-resident scene: the same
+// hi / lo split and the same direct quotients, but in radix R = b^K -- one LDS lookup of the radical inverse of a whole
+// K-digit group (trg_kernels.h kHtab) instead of K digits.  Not bit-identical to the digit loop (the groups are summed
+// with correctly rounded weights), within an ulp or two of it; the strict build never uses it.
+template <uint32_t D>
+TRG_DEV float halton_t(uint32_t i, const float *htab) {
+    constexpr uint32_t B = halton_prime(D);
+    constexpr trg::HtabSpec spec = trg::kHtab[D - 1];
+    static_assert(D >= 1 && D <= 5 && spec.base == B, "table dimensions are 1..5");
+    constexpr int K = (int)spec.digits;
+    constexpr int N = halton_digits(B);
+    constexpr int K1 = halton_lo_digits(B);
+    constexpr uint32_t B1 = halton_pow(B, K1);
+    constexpr HaltonRcpPow<B> rp{};
+    constexpr HaltonWeight<B> wt{};
+    constexpr float Rf = (float)spec.radix;
+    const float *T = htab + spec.offset;
+    const uint32_t hi = i / B1;
+    const uint32_t lo = i - hi * B1;
+    float r = 0.0f;
+    {
+        constexpr int G = (K1 + K - 1) / K;
+        const float n = (float)lo, nh = n + 0.5f;
+        float q0 = n;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float q1 = (g + 1 < G) ? __builtin_floorf(nh * rp.f[(g + 1) * K]) : 0.0f;
+            const float rem = __builtin_fmaf(q1, -Rf, q0);
+            r = __builtin_fmaf(T[(int)rem], wt.f[g * K], r);
+            q0 = q1;
+        }
+    }
+    {
+        constexpr int G = (N - K1 + K - 1) / K;
+        const float n = (float)hi, nh = n + 0.5f;
+        float q0 = n;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float q1 = (g + 1 < G) ? __builtin_floorf(nh * rp.f[(g + 1) * K]) : 0.0f;
+            const float rem = __builtin_fmaf(q1, -Rf, q0);
+            r = __builtin_fmaf(T[(int)rem], wt.f[K1 + g * K], r);
+            q0 = q1;
+        }
+    }
+    return r;
+}
+template <uint32_t D, bool TAB>
+TRG_DEV float halton_d(uint32_t i, const float *htab) {
+    if constexpr (TAB && D >= 1 && D <= 5) return halton_t<D>(i, htab);
+    else return halton_c<D>(i);
+}
 // the two raygen dimensions (Raytracing.metal:67-68)
-TRG_DEV void halton_pixel(uint32_t i, float &r0, float &r1) { r0 = halton_c<0>(i); r1 = halton_c<1>(i); }
+template <bool TAB = false>
+TRG_DEV void halton_pixel(uint32_t i, float &r0, float &r1, const float *htab = nullptr) { r0 = halton_c<0>(i); r1 = halton_d<1, TAB>(i, htab); }
 // the four dimensions 2 + 4*bounce + {0,1,2,3} of one shading event (Raytracing.metal:165-166,188-189);
 // `bounce` is wave-uniform so this is a scalar branch.
-template <int BNC>
-TRG_DEV void halton4_c(uint32_t i, float r[4]) {
-    r[0] = halton_c<2 + 4 * BNC + 0>(i);
-    r[1] = halton_c<2 + 4 * BNC + 1>(i);
-    r[2] = halton_c<2 + 4 * BNC + 2>(i);
-    r[3] = halton_c<2 + 4 * BNC + 3>(i);
+template <int BNC, bool TAB = false>
+TRG_DEV void halton4_c(uint32_t i, float r[4], const float *htab = nullptr) {
+    r[0] = halton_d<2 + 4 * BNC + 0, TAB>(i, htab);
+    r[1] = halton_d<2 + 4 * BNC + 1, TAB>(i, htab);
+    r[2] = halton_d<2 + 4 * BNC + 2, TAB>(i, htab);
+    r[3] = halton_d<2 + 4 * BNC + 3, TAB>(i, htab);
 }
 // only the two light-sample dimensions 2 + 4*bounce + {0,1}: on the last bounce the continuation ray is never
 // traced, so its two dimensions (and the hemisphere sample built from them) are not evaluated at all
-template <int BNC>
-TRG_DEV void halton2_c(uint32_t i, float r[4]) {
-    r[0] = halton_c<2 + 4 * BNC + 0>(i);
-    r[1] = halton_c<2 + 4 * BNC + 1>(i);
+template <int BNC, bool TAB = false>
+TRG_DEV void halton2_c(uint32_t i, float r[4], const float *htab = nullptr) {
+    r[0] = halton_d<2 + 4 * BNC + 0, TAB>(i, htab);
+    r[1] = halton_d<2 + 4 * BNC + 1, TAB>(i, htab);
 }
-TRG_DEV void halton2(uint32_t i, uint32_t bounce, float r[4]) {
+template <bool TAB = false>
+TRG_DEV void halton2(uint32_t i, uint32_t bounce, float r[4], const float *htab = nullptr) {
     switch (bounce) {
-    case 0: halton2_c<0>(i, r); break;
+    case 0: halton2_c<0, TAB>(i, r, htab); break;
     case 1: halton2_c<1>(i, r); break;
     case 2: halton2_c<2>(i, r); break;
     case 3: halton2_c<3>(i, r); break;
@@ -224,9 +285,10 @@ TRG_DEV void halton2(uint32_t i, uint32_t bounce, float r[4]) {
     default: halton2_c<14>(i, r); break;
     }
 }
-TRG_DEV void halton4(uint32_t i, uint32_t bounce, float r[4]) {
+template <bool TAB = false>
+TRG_DEV void halton4(uint32_t i, uint32_t bounce, float r[4], const float *htab = nullptr) {
     switch (bounce) {
-    case 0: halton4_c<0>(i, r); break;
+    case 0: halton4_c<0, TAB>(i, r, htab); break;
     case 1: halton4_c<1>(i, r); break;
     case 2: halton4_c<2>(i, r); break;
     case 3: halton4_c<3>(i, r); break;
@@ -392,9 +454,10 @@ TRG_DEV LightSample sample_area_light(const trg_uniforms &u, float r0, float r1,
 }
 
 // Raytracing.metal:41-91 (a6)
-TRG_DEV void raygen(const trg_uniforms &u, uint32_t x, uint32_t y, uint32_t hidx, V3 &org, V3 &dir) {
+template <bool TAB = false>
+TRG_DEV void raygen(const trg_uniforms &u, uint32_t x, uint32_t y, uint32_t hidx, V3 &org, V3 &dir, const float *htab = nullptr) {
     float r0, r1;
-    halton_pixel(hidx, r0, r1);
+    halton_pixel<TAB>(hidx, r0, r1, htab);
     const float px = (float)x + r0, py = (float)y + r1;
     float uvx = div_fast(px, (float)u.width), uvy = div_fast(py, (float)u.height);
     uvx = uvx * 2.0f - 1.0f;
@@ -419,6 +482,7 @@ struct SceneView {
     const float *normals;   // 9 per triangle, ORIGINAL order (reference vertexNormals buffer)
     const float *colors;    // 9 per triangle, ORIGINAL order (reference vertexColors buffer)
     const uint32_t *mats;   // 1 per triangle, ORIGINAL order (reference triangleMasks buffer)
+    const float *htab;      // Halton group tables in LDS (trg_kernels.h kHtab), or nullptr
 };
 struct Hit { float t; int prim; float u, v; };  // u, v = Moeller-Trumbore weights of vertex 1 and 2
 struct Counters { uint32_t nodes, tris, wnodes, wtris; };  // per-lane work and wave-level iterations (first active lane counts)

@@ -34,6 +34,7 @@ struct SceneDesc {
     uint32_t n_nodes, n_tris;
     uint32_t off_nodes4, n_nodes4;  // 4-wide nodes (HBM traversal); they sit after the LDS-staged part of the blob
     uint32_t lds_stage_bytes;       // bytes a workgroup stages into LDS (everything before the 4-wide nodes)
+    uint32_t off_htab;              // Halton group tables (kHtabFloats floats), inside the staged region
 };
 
 // traversal stack: the first `klds` levels live in LDS, deeper ones in a global scratch column per thread
@@ -65,6 +66,17 @@ struct TraceParams {
     uint32_t stack_off;
     StackDesc stack;
 };
+
+// Radical-inverse tables for the five smallest odd bases (Halton dimensions 1..5: the pixel y offset and the four
+// samples of bounce 0), staged in LDS with the scene: T_b[r] = radical inverse of r read as a K-digit base-b number.
+// The shipped megakernel on an LDS-resident scene takes K digits per lookup instead of one digit per five VALU
+// instructions (trg_device.h halton_c); everything else (strict build, HBM scenes, other dimensions) keeps the digits.
+#ifndef TRG_HALTON_TABLES
+#define TRG_HALTON_TABLES 1
+#endif
+struct HtabSpec { uint32_t base, digits, radix, offset; };
+constexpr HtabSpec kHtab[5] = { { 3, 4, 81, 0 }, { 5, 3, 125, 81 }, { 7, 2, 49, 206 }, { 11, 2, 121, 255 }, { 13, 2, 169, 376 } };
+constexpr uint32_t kHtabFloats = 545, kHtabBytes = 2192;  // 545 * 4 rounded up to 16
 
 // which BVH flavour the HBM (non-LDS) kernels traverse; must match TRG_TRAV_HBM in trg_device.h
 #ifndef TRG_TRAV_HBM

@@ -7,8 +7,8 @@
 // 4-byte Halton offset read and one 16-byte float4 write (+16 B read when continuing an average).
 //
 // Built twice: TRG_STRICT=0 -> *_fast symbols, TRG_STRICT=1 (-ffp-contract=off) -> *_strict symbols.
-#include "trg_device.h"
 #include "trg_kernels.h"
+#include "trg_device.h"
 
 using namespace trgdev;
 
@@ -35,12 +35,14 @@ TRG_DEV SceneView scene_view(const trg::SceneDesc &sc, unsigned char *smem) {
         v.normals = reinterpret_cast<const float *>(smem + sc.off_normals);
         v.colors = reinterpret_cast<const float *>(smem + sc.off_colors);
         v.mats = reinterpret_cast<const uint32_t *>(smem + sc.off_mats);
+        v.htab = reinterpret_cast<const float *>(smem + sc.off_htab);
     } else {
         v.nodes = reinterpret_cast<const v4f *>(sc.blob + (trg::kWideHbm ? sc.off_nodes4 : sc.off_nodes));
         v.tris = reinterpret_cast<const v4f *>(sc.blob + sc.off_tris);
         v.normals = reinterpret_cast<const float *>(sc.blob + sc.off_normals);
         v.colors = reinterpret_cast<const float *>(sc.blob + sc.off_colors);
         v.mats = reinterpret_cast<const uint32_t *>(sc.blob + sc.off_mats);
+        v.htab = nullptr;
     }
     return v;
 }
@@ -55,6 +57,7 @@ TRG_DEV uint32_t wave_sum(uint32_t v) {
 // nearest-hit record: updates throughput / radiance / path state, moves the ray to the continuation ray and
 // returns the shadow ray to trace.  Shared by both loop shapes of render_kernel.
 struct ShadeOut { bool want_shadow, want_next; V3 sdir, scol; float smax; };
+template <bool TAB = false>
 TRG_DEV ShadeOut shade_event(const trg_uniforms &u, const SceneView &sc, const Hit &h, bool found, uint32_t b, bool last, uint32_t hidx,
                              V3 &o, V3 &d, V3 &thr, V3 &rad, uint32_t &rmask, bool &active, V3 light_color, uint32_t &n_shaded) {
     ShadeOut out;
@@ -77,7 +80,7 @@ TRG_DEV ShadeOut shade_event(const trg_uniforms &u, const SceneView &sc, const H
         uint32_t hi = hidx;
         asm volatile("" : "+v"(hi));
         r[2] = 0.0f; r[3] = 0.0f;
-        if (last) halton2(hi, b, r); else halton4(hi, b, r);
+        if (last) halton2<TAB>(hi, b, r, sc.htab); else halton4<TAB>(hi, b, r, sc.htab);
         const LightSample ls = sample_area_light(u, r[0], r[1], P, nrm);
         thr = thr * vcol;
         o = P + nrm * 1e-3f;  // origin of both the shadow ray and the continuation ray
@@ -109,7 +112,8 @@ TRG_DEV V3 path_radiance(const trg::RenderParams &p, const SceneView &sc, STK st
                          V3 light_color, PathCounters &pc, Counters &cnt) {
     uint32_t &n_primary = pc.primary, &n_bounce = pc.bounce, &n_shadow = pc.shadow, &n_shaded = pc.shaded;
     V3 o, d;
-    raygen(p.u, x, y, hidx, o, d);
+    constexpr bool TAB = LDS_SCENE && !TRG_STRICT && TRG_HALTON_TABLES;  // Halton group tables staged with the scene
+    raygen<TAB>(p.u, x, y, hidx, o, d, sc.htab);
     V3 thr = mk(1.0f, 1.0f, 1.0f);  // ray.color
     V3 rad = mk(0.0f, 0.0f, 0.0f);  // the render target texel of this frame
     uint32_t rmask = 3u;            // RAY_MASK_PRIMARY
@@ -126,7 +130,7 @@ TRG_DEV V3 path_radiance(const trg::RenderParams &p, const SceneView &sc, STK st
                 if (b > 0) n_bounce++;
                 Hit h;
                 const bool found = traverse<false, COUNT, trg::kBlock, false>(sc, o, d, INFINITY, rmask, h, stk, cnt);
-                const ShadeOut so = shade_event(p.u, sc, h, found, b, last, hidx, o, d, thr, rad, rmask, active, light_color, n_shaded);
+                const ShadeOut so = shade_event<TAB>(p.u, sc, h, found, b, last, hidx, o, d, thr, rad, rmask, active, light_color, n_shaded);
                 if (so.want_shadow) {
                     n_shadow++;
                     Hit sh;
@@ -147,7 +151,7 @@ TRG_DEV V3 path_radiance(const trg::RenderParams &p, const SceneView &sc, STK st
             if (__ballot(active) == 0ull) break;
             const bool last = (b + 1u == p.bounces);
             ShadeOut so; so.want_shadow = false; so.want_next = false; so.sdir = mk(0.0f, 0.0f, 1.0f); so.scol = mk(0.0f, 0.0f, 0.0f); so.smax = -1.0f;
-            if (active) so = shade_event(p.u, sc, h, found, b, last, hidx, o, d, thr, rad, rmask, active, light_color, n_shaded);
+            if (active) so = shade_event<TAB>(p.u, sc, h, found, b, last, hidx, o, d, thr, rad, rmask, active, light_color, n_shaded);
             if (__ballot(so.want_shadow || so.want_next) != 0ull) {
                 bool occluded = false;
                 traverse_pair<COUNT, trg::kBlock, true>(sc, o, so.want_shadow, so.sdir, so.smax, so.want_next, d, rmask, occluded, h, found, stk, cnt);
