@@ -86,7 +86,8 @@ static int plan_lds(trg_ctx *c, LdsPlan &p, bool pool = false, uint32_t fp_slots
         p.klds = std::min(levels, kStackLdsLevels);
     }
     p.overflow_levels = levels - p.klds;
-    p.stack_off = p.lds_scene ? align16(c->sc.lds_stage_bytes) : 0u;
+    // the pool kernel does not use the Halton group tables at the end of the staged region: it stages (and pays for) less
+    p.stack_off = p.lds_scene ? align16(pool ? c->sc.off_htab : c->sc.lds_stage_bytes) : 0u;
     p.red_off = p.stack_off + p.klds * kBlock * 4u;
     p.pool_off = align16(p.red_off + 4u * 8u * 4u);
     p.total = p.pool_off;
@@ -410,6 +411,7 @@ int trg_render(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces,
     RenderParams p{};
     p.u = c->u;
     p.sc = c->sc;
+    if (pool && plan.lds_scene) p.sc.lds_stage_bytes = c->sc.off_htab;
     p.offsets = c->offsets;
     p.accum = c->accum;
     p.counters = c->counters;
