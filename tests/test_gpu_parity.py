@@ -646,6 +646,59 @@ def test_full_size_c2_properties(capi, O, cornell):
         c.close()
 
 
+def test_full_size_c3_and_c5_properties(capi, O, cornell):
+    """Configs C3 (1920x1080, 256 spp, 8 bounces) and C5 (3840x2160, 64 spp, 3 bounces; here on one GPU, sharded into the
+    eight row bands of the 8-GPU job) at BASELINE's full sizes, through size-independent properties: a launch split in
+    two continues bit for bit, the union of the bands is the unsharded frame bit for bit, ray-count identities hold,
+    and sampled rows agree with the oracle within the stated tolerance."""
+    from toyraygun_amd.dist import band_rows
+    # ---- C3
+    w, h, spp, bnc = 1920, 1080, 256, 8
+    c = make_ctx(O, cornell, w, h)
+    try:
+        c.reset_stats()
+        c.render(0, spp, bnc)
+        img, st = c.read_accum(), c.stats()
+        assert np.isfinite(img).all() and (img[..., 3] == 1.0).all() and (img[..., :3] >= 0).all()
+        assert st.primary_rays == w * h * spp and st.shadow_rays == st.shaded_hits and st.bounce_rays <= st.shaded_hits
+        assert st.rays <= 2 * bnc * w * h * spp and st.bounce_rays > st.primary_rays   # deep bounces really happen
+        c.render(0, 100, bnc)
+        c.render(100, spp - 100, bnc)
+        assert np.array_equal(_bits(c.read_accum()), _bits(img))
+        off = O.pixel_offsets(w, h)
+        acc = np.zeros((h, w, 4), np.float32)
+        rows = [(300, 2), (700, 2)]
+        for r0, n in rows:
+            O.render(cornell, w, h, spp, bnc, row0=r0, rows=n, accum=acc, offsets=off)
+        got = np.concatenate([img[r0:r0 + n] for r0, n in rows])
+        ref = np.concatenate([acc[r0:r0 + n] for r0, n in rows])
+        rmse, frac_ok, worst = image_metrics(got, ref)
+        assert rmse <= TOL_RMSE and frac_ok >= TOL_FRAC, (rmse, frac_ok, worst)
+    finally:
+        c.close()
+    # ---- C5
+    w, h, spp, bnc = 3840, 2160, 64, 3
+    c = make_ctx(O, cornell, w, h)
+    try:
+        c.reset_stats()
+        c.render(0, spp, bnc)
+        full, st = c.read_accum(), c.stats()
+        assert st.primary_rays == w * h * spp and st.shadow_rays == st.shaded_hits
+        c.render(0, 1, bnc)                                   # clobber, then the eight bands of the 8-GPU job
+        c.reset_stats()
+        for r in range(8):
+            row0, rows = band_rows(h, 8, r)
+            c.render(0, spp, bnc, row0, rows)
+        assert np.array_equal(_bits(c.read_accum()), _bits(full)) and c.stats().rays == st.rays
+        off = O.pixel_offsets(w, h)
+        acc = np.zeros((h, w, 4), np.float32)
+        O.render(cornell, w, h, spp, bnc, row0=1079, rows=2, accum=acc, offsets=off)   # straddles the band 3 / band 4 boundary
+        rmse, frac_ok, worst = image_metrics(full[1079:1081], acc[1079:1081])
+        assert rmse <= TOL_RMSE and frac_ok >= TOL_FRAC, (rmse, frac_ok, worst)
+    finally:
+        c.close()
+
+
 def test_kernels_agree(capi, O, cornell):
     c = make_ctx(O, cornell, 200, 120)
     try:
