@@ -737,22 +737,23 @@ TRG_DEV void trav_node4_math(const v4f q0, const v4f q1, const v4f q2, const v4f
         const float tnz = (float)((nz >> (8 * k)) & 255u) * az + bz, tfz = (float)((fz >> (8 * k)) & 255u) * az + bz;
         const float tmin = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
         const float tmax = fminf(fminf(tfx, tfy), fminf(tfz, tv.best));
-        const int c = k == 0 ? c0 : (k == 1 ? c1 : (k == 2 ? c2 : c3));
-        t[k] = (tmin <= tmax && c != kNodeDone) ? tmin : INFINITY;  // +inf = not entered (miss or unused slot)
+        // +inf = not entered.  An unused slot decodes to the inverted box (255, 0) and can never pass, so the child word
+        // needs no check of its own (-4 % on C4)
+        t[k] = (tmin <= tmax) ? tmin : INFINITY;
     }
     float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
-    const int n_hit = (t0 < INFINITY ? 1 : 0) + (t1 < INFINITY ? 1 : 0) + (t2 < INFINITY ? 1 : 0) + (t3 < INFINITY ? 1 : 0);
     // sort the four (entry distance, child) pairs, nearest first (5-comparator network); misses sink to the end
     TRG_CSWAP(t0, c0, t1, c1) TRG_CSWAP(t2, c2, t3, c3) TRG_CSWAP(t0, c0, t2, c2) TRG_CSWAP(t1, c1, t3, c3) TRG_CSWAP(t1, c1, t2, c2)
+    const bool h4 = t3 < INFINITY, h3 = t2 < INFINITY, h2 = t1 < INFINITY, h0 = !(t0 < INFINITY);  // sorted: t_k finite <=> more than k hits
     int sp = tv.sp;
-    if (n_hit >= 4) stk.push(sp, c3);
-    sp += n_hit >= 4 ? STK::unit : 0;
-    if (n_hit >= 3) stk.push(sp, c2);
-    sp += n_hit >= 3 ? STK::unit : 0;
-    if (n_hit >= 2) stk.push(sp, c1);
-    sp += n_hit >= 2 ? STK::unit : 0;
+    if (h4) stk.push(sp, c3);
+    sp += h4 ? STK::unit : 0;
+    if (h3) stk.push(sp, c2);
+    sp += h3 ? STK::unit : 0;
+    if (h2) stk.push(sp, c1);
+    sp += h2 ? STK::unit : 0;
     int next = c0;
-    if (n_hit == 0) {
+    if (h0) {
         const bool empty = stk.empty(sp);
         sp -= empty ? 0 : STK::unit;
         const int popped = stk.pop(sp);
