@@ -25,6 +25,9 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 
+_INPLACE_OK = True
+
+
 def band_rows(height, world, rank):
     """Rows [row0, row0+rows) of rank `rank` (the last bands absorb the remainder)."""
     row0 = (height * rank) // world
@@ -41,8 +44,16 @@ def gather_bands(full, world, rank, group=None):
     equal = len({b[1] for b in bands}) == 1
     mine = full[bands[rank][0]:bands[rank][0] + bands[rank][1]]
     if equal and hasattr(dist, "all_gather_into_tensor"):
-        # in place: the output IS the frame, the input is this rank's slice of it
-        dist.all_gather_into_tensor(full, mine, group=group)
+        # in place: the output IS the frame, the input is this rank's slice of it (NCCL's in-place all-gather layout:
+        # sendbuff == recvbuff + rank * count).  Should a backend refuse the aliasing, send a copy of the band instead.
+        global _INPLACE_OK
+        if _INPLACE_OK:
+            try:
+                dist.all_gather_into_tensor(full, mine, group=group)
+                return full
+            except (RuntimeError, ValueError):
+                _INPLACE_OK = False
+        dist.all_gather_into_tensor(full, mine.clone(), group=group)
         return full
     rows_max = max(b[1] for b in bands)
     pad = torch.zeros((rows_max,) + tuple(full.shape[1:]), dtype=full.dtype, device=full.device)
