@@ -5,6 +5,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -263,18 +264,36 @@ def test_quantised_wide_nodes_are_conservative(built, O):
 
 
 def test_host_builder_under_sanitizers():
-    """The host BVH builder, the 4-wide collapse and the node quantiser compiled with -fsanitize=address,undefined
-    (g++, CPU only: GPU sanitizers are not available) on empty, tiny, degenerate-heavy and 200 k-triangle inputs."""
+    """The host BVH builder (threaded above 65,536 triangles), the 4-wide collapse and the node quantiser compiled with
+    -fsanitize=address,undefined and again with -fsanitize=thread (g++, CPU only: GPU sanitizers are not available) on
+    empty, tiny, degenerate-heavy and 200 k-triangle inputs."""
     import tempfile
     csrc = os.path.join(ROOT, "toyraygun_amd", "csrc")
-    with tempfile.TemporaryDirectory() as td:
-        exe = os.path.join(td, "san")
-        subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
-                               "-fno-omit-frame-pointer", "-I" + csrc, os.path.join(ROOT, "tests", "helpers", "bvh_sanitize.cpp"),
-                               os.path.join(csrc, "bvh_build.cpp"), "-o", exe])
-        r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    assert "n=200000" in r.stdout and "ERROR" not in r.stderr and "runtime error" not in r.stderr
+    for san in ("address,undefined", "thread"):
+        with tempfile.TemporaryDirectory() as td:
+            exe = os.path.join(td, "san")
+            subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=" + san, "-fno-sanitize-recover=all", "-pthread",
+                                   "-fno-omit-frame-pointer", "-I" + csrc, os.path.join(ROOT, "tests", "helpers", "bvh_sanitize.cpp"),
+                                   os.path.join(csrc, "bvh_build.cpp"), "-o", exe])
+            r = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=dict(os.environ, TRG_BVH_THREADS="4"))
+        assert r.returncode == 0, (san, r.stderr[-2000:])
+        assert "n=200000" in r.stdout and "ERROR" not in r.stderr and "runtime error" not in r.stderr and "WARNING: ThreadSanitizer" not in r.stderr
+
+
+def test_threaded_host_build_is_identical_to_the_single_threaded_one(built):
+    """Worker threads build disjoint subtrees of the same tree: node arrays, triangle order and quantised nodes are the
+    same bits for 1 and 5 threads (run in child processes: the thread count is read from the environment at build time)."""
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from toyraygun_amd import capi; from oracle import pyoracle as O;"
+            "b = O.OracleScene.cornell_lattice(19).buffers();"          # 82,344 triangles: above the threading threshold
+            "n, t, d = capi.debug_build_bvh(b['positions'], b['indices'], b['material_ids']);"
+            "q = capi.debug_build_bvh4q(b['positions'], b['indices'], b['material_ids']);"
+            "import hashlib; print(hashlib.sha256(n.tobytes() + t.tobytes() + q.tobytes()).hexdigest(), n.shape[0], d)") % ROOT
+    outs = []
+    for thr in ("1", "5"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, TRG_BVH_THREADS=thr))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip())
+    assert outs[0] == outs[1] and len(outs[0].split()[0]) == 64
 
 
 def test_halton_device_identities():

@@ -7,7 +7,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <limits>
+#include <thread>
 
 namespace trg {
 namespace {
@@ -38,10 +40,15 @@ struct BuildNode {
     bool leaf = false;
 };
 
+// A subtree handed to a worker thread: its triangle range, its depth, and the child slot of the top tree it hangs from.
+struct Task { uint32_t first, count, depth; int32_t parent, slot; };
+
 struct Builder {
-    std::vector<Prim> prims;
+    Prim *prims = nullptr;             // the builder sorts sub-ranges of ONE shared array in place (disjoint per subtree)
     std::vector<BuildNode> nodes;
     uint32_t depth = 0, leaves = 0, max_leaf = 0;
+    uint32_t cutoff = 0;               // top tree only: ranges at most this long become tasks instead of being built
+    std::vector<Task> *tasks = nullptr;
 
     int32_t make_leaf(const Box &box, uint32_t first, uint32_t count, uint32_t d) {
         BuildNode n; n.box = box; n.first = first; n.count = count; n.leaf = true;
@@ -92,11 +99,11 @@ struct Builder {
                 if (count <= kMaxLeaf && leaf_cost <= split_cost) return make_leaf(box, first, count, d);
                 const float scale = (float)kBins / ext[best_axis];
                 const float lo = cbox.lo[best_axis];
-                auto it = std::partition(prims.begin() + first, prims.begin() + first + count, [&](const Prim &p) {
+                auto it = std::partition(prims + first, prims + first + count, [&](const Prim &p) {
                     int b = std::min(kBins - 1, std::max(0, (int)((p.c[best_axis] - lo) * scale)));
                     return b <= best_bin;
                 });
-                mid = (uint32_t)(it - (prims.begin() + first));
+                mid = (uint32_t)(it - (prims + first));
                 have_split = mid > 0 && mid < count;
             }
         }
@@ -104,7 +111,7 @@ struct Builder {
             if (count <= kMaxLeaf && (ext[axis] <= 0.f || d >= kSahDepthCap)) return make_leaf(box, first, count, d);
             // balanced median split (also the fallback for coincident centroids)
             mid = count / 2;
-            std::nth_element(prims.begin() + first, prims.begin() + first + mid, prims.begin() + first + count,
+            std::nth_element(prims + first, prims + first + mid, prims + first + count,
                              [axis](const Prim &a, const Prim &b) {
                                  if (a.c[axis] != b.c[axis]) return a.c[axis] < b.c[axis];
                                  return a.id < b.id;
@@ -113,10 +120,16 @@ struct Builder {
         const int32_t me = (int32_t)nodes.size();
         nodes.emplace_back();
         nodes[me].box = box;
-        const int32_t l = build(first, mid, d + 1);
-        const int32_t r = build(first + mid, count - mid, d + 1);
+        const int32_t l = child(first, mid, d + 1, me, 0);
+        const int32_t r = child(first + mid, count - mid, d + 1, me, 1);
         nodes[me].child[0] = l; nodes[me].child[1] = r;
         return me;
+    }
+
+    // build the child now, or (top tree of a threaded build) leave it to a worker: -1 until the subtree is spliced in
+    int32_t child(uint32_t first, uint32_t count, uint32_t d, int32_t parent, int32_t slot) {
+        if (tasks && count <= cutoff) { tasks->push_back(Task{ first, count, d, parent, slot }); return -1; }
+        return build(first, count, d);
     }
 };
 
@@ -128,7 +141,8 @@ void build_bvh(const float *pos, const uint32_t *idx, const uint32_t *masks, uin
     if (const char *e = getenv("TRG_BVH_MAXLEAF")) kMaxLeaf = (uint32_t)std::min(8, std::max(1, atoi(e)));
     if (const char *e = getenv("TRG_BVH_TRAVCOST")) kTravCost = (float)atof(e);
     Builder B;
-    B.prims.resize(ntris);
+    std::vector<Prim> prim_store(ntris);
+    B.prims = prim_store.data();
     Box scene;
     for (uint32_t k = 0; k < ntris; ++k) {
         Prim &p = B.prims[k];
@@ -138,7 +152,45 @@ void build_bvh(const float *pos, const uint32_t *idx, const uint32_t *masks, uin
         scene.grow(p.b);
     }
     B.nodes.reserve((size_t)ntris * 2 + 2);
+    // Large scenes: the top of the tree is built here, subtrees of at most `cutoff` triangles by worker threads (each sorts
+    // its own range of the shared array and fills its own node vector), then spliced in.  Every split decision depends on
+    // the triangles of its range only, so the tree -- and, after the depth-first flatten below, the device layout -- is the
+    // same as the single-threaded one, whatever the thread count or timing.
+    unsigned n_threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char *e = getenv("TRG_BVH_THREADS")) n_threads = (unsigned)std::min(64, std::max(1, atoi(e)));
+    std::vector<Task> tasks;
+    if (ntris >= 65536u && n_threads > 1) {
+        B.cutoff = std::max(4096u, ntris / (n_threads * 8u));
+        B.tasks = &tasks;
+    }
     int32_t root = ntris ? B.build(0, ntris, 0) : -1;
+    if (!tasks.empty()) {
+        B.tasks = nullptr;
+        std::vector<Builder> sub(tasks.size());
+        std::vector<int32_t> sub_root(tasks.size(), -1);
+        std::atomic<size_t> next{ 0 };
+        auto work = [&]() {
+            for (size_t t = next.fetch_add(1); t < tasks.size(); t = next.fetch_add(1)) {
+                sub[t].prims = B.prims;
+                sub[t].nodes.reserve((size_t)tasks[t].count * 2 + 2);
+                sub_root[t] = sub[t].build(tasks[t].first, tasks[t].count, tasks[t].depth);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned k = 1; k < n_threads; ++k) pool.emplace_back(work);
+        work();
+        for (std::thread &th : pool) th.join();
+        for (size_t t = 0; t < tasks.size(); ++t) {   // splice, in task order
+            const int32_t off = (int32_t)B.nodes.size();
+            for (BuildNode n : sub[t].nodes) {
+                for (int k = 0; k < 2; ++k)
+                    if (n.child[k] >= 0) n.child[k] += off;
+                B.nodes.push_back(n);
+            }
+            B.nodes[tasks[t].parent].child[tasks[t].slot] = off + sub_root[t];
+            B.depth = std::max(B.depth, sub[t].depth); B.leaves += sub[t].leaves; B.max_leaf = std::max(B.max_leaf, sub[t].max_leaf);
+        }
+    }
 
     // Conservative padding: the slab test and the triangle test round differently; every box is
     // widened by far more than that so a triangle the Moeller-Trumbore test accepts is always reached.
