@@ -75,8 +75,8 @@ static inline uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
 constexpr uint32_t kStackLdsLevels = 16;  // HBM scenes: stack levels kept in LDS (deeper ones spill to global scratch)
 
 struct LdsPlan { bool lds_scene; uint32_t stack_off, red_off, pool_off, total, klds, overflow_levels; };
-static int plan_lds(trg_ctx *c, LdsPlan &p, bool pool = false, uint32_t fp_slots = 0) {
-    p.lds_scene = !c->opt_force_global && c->sc.lds_stage_bytes != 0 && c->sc.lds_stage_bytes <= kMaxLdsScene;
+static bool plan_lds_as(const trg_ctx *c, LdsPlan &p, bool lds_scene, bool pool, uint32_t fp_slots, uint32_t &limit) {
+    p.lds_scene = lds_scene;
     uint32_t levels;
     if (p.lds_scene) {
         levels = c->bvh_depth + 2;      // BVH2, near child first: at most one pending entry per level
@@ -96,10 +96,16 @@ static int plan_lds(trg_ctx *c, LdsPlan &p, bool pool = false, uint32_t fp_slots
         p.total = p.pool_off + slots * kPoolSlotBytes + 4u * slots * 2u + 16u;  // slots, two lists of 2P u16, counters
     }
     if (fp_slots) p.total = p.pool_off + fp_slots * (uint32_t)kBlock * 12u;  // render_fp_kernel: parked radiances, 3 floats x 256 pixel-frames per slot group
-    const uint32_t limit = (pool || fp_slots) ? 160u * 1024u : 64u * 1024u;  // above 64 KB the launcher opts in per kernel
-    if (p.total > limit)
-        return fail(c, TRG_ERR_RANGE, "BVH depth %u needs %u B of LDS per workgroup (limit %u)", c->bvh_depth, p.total, limit);
-    return TRG_OK;
+    limit = (pool || fp_slots) ? 160u * 1024u : 64u * 1024u;  // above 64 KB the launcher opts in per kernel
+    return p.total <= limit;
+}
+static int plan_lds(trg_ctx *c, LdsPlan &p, bool pool = false, uint32_t fp_slots = 0) {
+    const bool want_lds = !c->opt_force_global && c->sc.lds_stage_bytes != 0 && c->sc.lds_stage_bytes <= kMaxLdsScene;
+    uint32_t limit = 0;
+    if (want_lds && plan_lds_as(c, p, true, pool, fp_slots, limit)) return TRG_OK;
+    // the scene stays in HBM -- also a small one whose tree is too deep for its traversal stacks to fit in LDS next to it
+    if (plan_lds_as(c, p, false, pool, fp_slots, limit)) return TRG_OK;
+    return fail(c, TRG_ERR_RANGE, "BVH depth %u needs %u B of LDS per workgroup (limit %u)", c->bvh_depth, p.total, limit);
 }
 
 // How many wavefronts share a pixel's frames (render_fp_kernel) for a launch of `rows` rows and `spp` frames.
