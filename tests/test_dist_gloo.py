@@ -24,7 +24,7 @@ def test_band_rows_partition():
     assert band_rows(1080, 8, 3) == (405, 135) and band_rows(2160, 8, 7) == (1890, 270)
 
 
-def _worker(rank, world, port, h, w, out_dir):
+def _worker(rank, world, port, h, w, out_dir, root=None):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -35,7 +35,7 @@ def _worker(rank, world, port, h, w, out_dir):
     acc = np.zeros((h, w, 4), np.float32)
     O.render(scene, w, h, 2, 3, row0=row0, rows=rows, accum=acc, nthreads=2)
     full = torch.from_numpy(acc)
-    gather_bands(full, world, rank)
+    gather_bands(full, world, rank, root=root)
     np.save(os.path.join(out_dir, "rank%d.npy" % rank), full.numpy())
     dist.barrier()
     dist.destroy_process_group()
@@ -53,3 +53,22 @@ def test_sharded_render_equals_single(tmp_path, world, h, O):
     for r in range(world):
         got = np.load(os.path.join(str(tmp_path), "rank%d.npy" % r))
         assert np.array_equal(got, ref), "rank %d frame differs from the unsharded render" % r
+
+
+@pytest.mark.parametrize("world,h", [(2, 32), (3, 34)])
+def test_gather_to_root_only(tmp_path, world, h, O):
+    """gather_bands(root=0): rank 0 ends up with the unsharded frame bit for bit; the others keep their own band only."""
+    from toyraygun_amd.dist import band_rows
+    w = 48
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(world, port, h, w, str(tmp_path), 0), nprocs=world, join=True)
+    ref, _ = O.render(O.OracleScene.cornell_box(), w, h, 2, 3)
+    assert np.array_equal(np.load(os.path.join(str(tmp_path), "rank0.npy")), ref)
+    for r in range(1, world):
+        got = np.load(os.path.join(str(tmp_path), "rank%d.npy" % r))
+        r0, n = band_rows(h, world, r)
+        assert np.array_equal(got[r0:r0 + n], ref[r0:r0 + n])
+        assert (np.delete(got, np.s_[r0:r0 + n], axis=0) == 0).all()

@@ -35,9 +35,31 @@ def band_rows(height, world, rank):
     return row0, row1 - row0
 
 
-def gather_bands(full, world, rank, group=None):
-    """All-gather the row bands of `full` ([h, w, 4] float32, this rank's band already filled) in place."""
+def gather_bands(full, world, rank, group=None, root=None):
+    """All-gather the row bands of `full` ([h, w, 4] float32, this rank's band already filled) in place.
+    root = r: gather to rank r only (the other ranks keep just their own band) -- one eighth of the traffic when only
+    one rank presents or stores the frame; also selected by TRG_GATHER=root (rank 0)."""
     if world == 1 and not os.environ.get("TRG_FORCE_GATHER"):
+        return full
+    if root is None and os.environ.get("TRG_GATHER") == "root":
+        root = 0
+    if root is not None:
+        h = full.shape[0]
+        bands = [band_rows(h, world, r) for r in range(world)]
+        mine = full[bands[rank][0]:bands[rank][0] + bands[rank][1]]
+        if len({b[1] for b in bands}) == 1:
+            # the receive list ARE the row bands of the frame: every band lands in place
+            dist.gather(mine, [full[b0:b0 + n] for b0, n in bands] if rank == root else None, dst=root, group=group)
+        else:
+            rows_max = max(b[1] for b in bands)
+            pad = torch.zeros((rows_max,) + tuple(full.shape[1:]), dtype=full.dtype, device=full.device)
+            pad[:bands[rank][1]] = mine
+            out = [torch.empty_like(pad) for _ in range(world)] if rank == root else None
+            dist.gather(pad, out, dst=root, group=group)
+            if rank == root:
+                for r, (r0, n) in enumerate(bands):
+                    if r != rank:
+                        full[r0:r0 + n] = out[r][:n]
         return full
     h = full.shape[0]
     bands = [band_rows(h, world, r) for r in range(world)]
