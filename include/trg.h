@@ -141,6 +141,8 @@ TRG_API int trg_render(trg_ctx *ctx, uint32_t frameIndexBegin, uint32_t spp, uin
  *     MetalRenderer.mm:538): width*height*4 floats, host memory. */
 TRG_API int trg_read_accum(trg_ctx *ctx, float *rgba);
 
+/* ray counters are read after synchronising the context's CURRENT stream: with launches in flight on other streams
+ * (TRG_OPT_LAUNCHES_IN_FLIGHT), synchronise those yourself first. */
 TRG_API int trg_get_stats(trg_ctx *ctx, trg_stats *out);
 TRG_API int trg_reset_stats(trg_ctx *ctx);
 TRG_API int trg_set_option(trg_ctx *ctx, int option, int64_t value);
