@@ -7,6 +7,7 @@
 // (intersection contract: minimum t, ties to the lower primitive index), so images stay bit-identical.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -132,42 +133,75 @@ __global__ void refit_kernel(const Box3 *prim_boxes, const unsigned long long *k
 // leaves hold up to two triangles as well).  The root is exempt.
 __device__ __forceinline__ bool is_pair(const int *left, const int *right, int i) { return i > 0 && left[i] < 0 && right[i] < 0; }
 
-__global__ void depth_kernel(const int *parent_int, const int *left, const int *right, int n_int, uint32_t *kept, int *max_depth) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_int) return;
-    int d = 0;
-    for (int p = parent_int[i]; p >= 0; p = parent_int[p]) ++d;
-    kept[i] = ((d & 1) == 0 && !is_pair(left, right, i)) ? 1u : 0u;
-    atomicMax(max_depth, d);
+// ---- greedy top-down collapse: level by level, every BVH2 node that becomes a 4-wide node
+// starts from its two children and keeps opening the child with the largest surface area until four slots are full
+// (pairs and leaves cannot be opened).  Inner slots become the wide nodes of the next level; their indices come from an
+// exclusive scan, so the layout is deterministic, breadth-first, siblings adjacent, and every child index is larger than
+// its parent's (which validate_wide_kernel checks: a tree that passes cannot send the traversal in a circle).
+__device__ __forceinline__ float box_half_area(const Box3 &b) {
+    const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    return dx * dy + dy * dz + dz * dx;
 }
-
-// one 4-wide node per kept BVH2 node: its children's children (or the children themselves when they are leaves)
-__global__ void emit_wide_kernel(const Box3 *prim_boxes, const unsigned long long *keys, const Box3 *node_boxes, const int *left,
-                                 const int *right, const uint32_t *kept, const uint32_t *wide_index, int n_int, float4 *nodes4) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_int || !kept[i]) return;
-    int child[4]; int n = 0;
-    const int c2[2] = { left[i], right[i] };
-    for (int k = 0; k < 2; ++k) {
-        if (c2[k] >= 0 && !is_pair(left, right, c2[k])) { child[n++] = left[c2[k]]; child[n++] = right[c2[k]]; }
-        else child[n++] = c2[k];
+__global__ void collapse_plan_kernel(const int *frontier, int n_cur, const int *left, const int *right, const Box3 *node_boxes,
+                                     int *slots4, uint32_t *cnt) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_cur) return;
+    const int i = frontier[j];
+    int sl[4] = { left[i], right[i], kEmptyChild, kEmptyChild };
+    int n = 2;
+    while (n < 4) {
+        int best = -1; float best_area = -1.0f;
+        for (int k = 0; k < n; ++k)
+            if (sl[k] >= 0 && !is_pair(left, right, sl[k])) {
+                const float a = box_half_area(node_boxes[sl[k]]);
+                if (a > best_area) { best_area = a; best = k; }
+            }
+        if (best < 0) break;
+        const int c = sl[best];
+        sl[best] = left[c];
+        sl[n++] = right[c];
     }
+    uint32_t m = 0;
+    for (int k = 0; k < 4; ++k) {
+        slots4[j * 4 + k] = sl[k];
+        if (sl[k] >= 0 && !is_pair(left, right, sl[k])) ++m;
+    }
+    cnt[j] = m;
+}
+__global__ void collapse_emit_kernel(const int *frontier, int n_cur, const int *slots4, const uint32_t *off, uint32_t wide_base_cur,
+                                     uint32_t wide_base_next, const int *left, const int *right, const Box3 *node_boxes,
+                                     const Box3 *prim_boxes, const unsigned long long *keys, int *next_frontier, float4 *nodes4) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_cur) return;
     float v[6][4]; int ref[4];
+    uint32_t inner = 0;
     for (int k = 0; k < 4; ++k) {
         ref[k] = kEmptyChild;
         for (int a = 0; a < 6; ++a) v[a][k] = 0.0f;
-        if (k >= n) continue;
-        const int c = child[k];
+        const int c = slots4[j * 4 + k];
+        if (c == kEmptyChild) continue;
         const Box3 *b;
-        if (c >= 0 && is_pair(left, right, c)) { b = &node_boxes[c]; ref[k] = ~(int)((((uint32_t)~left[c]) << 3) | 1u); }  // two-triangle leaf
-        else if (c >= 0) { b = &node_boxes[c]; ref[k] = (int)wide_index[c]; }          // grandchild: kept (depth + 2)
-        else { const uint32_t r = (uint32_t)~c; b = &prim_boxes[(uint32_t)(keys[r] & 0xFFFFFFFFull)]; ref[k] = ~(int)(r << 3); }  // leaf of one triangle
+        if (c >= 0 && is_pair(left, right, c)) { b = &node_boxes[c]; ref[k] = ~(int)((((uint32_t)~left[c]) << 3) | 1u); }
+        else if (c >= 0) { b = &node_boxes[c]; const uint32_t w = off[j] + inner++; ref[k] = (int)(wide_base_next + w); next_frontier[w] = c; }
+        else { const uint32_t r = (uint32_t)~c; b = &prim_boxes[(uint32_t)(keys[r] & 0xFFFFFFFFull)]; ref[k] = ~(int)(r << 3); }
         for (int a = 0; a < 3; ++a) { v[a * 2][k] = b->lo[a]; v[a * 2 + 1][k] = b->hi[a]; }
     }
-    float4 *o = nodes4 + (size_t)wide_index[i] * 8;
+    float4 *o = nodes4 + (size_t)(wide_base_cur + (uint32_t)j) * 8;
     for (int a = 0; a < 6; ++a) o[a] = make_float4(v[a][0], v[a][1], v[a][2], v[a][3]);
     o[6] = make_float4(__int_as_float(ref[0]), __int_as_float(ref[1]), __int_as_float(ref[2]), __int_as_float(ref[3]));
     o[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+// structural check of a finished wide tree: inner children point forward and in range, leaves stay inside the records
+__global__ void validate_wide_kernel(const float4 *nodes4, uint32_t n4, uint32_t ntris, int *bad) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float4 c = nodes4[(size_t)i * 8 + 6];
+    const int ref[4] = { __float_as_int(c.x), __float_as_int(c.y), __float_as_int(c.z), __float_as_int(c.w) };
+    for (int k = 0; k < 4; ++k) {
+        if (ref[k] == kEmptyChild) continue;
+        if (ref[k] >= 0) { if ((uint32_t)ref[k] <= i || (uint32_t)ref[k] >= n4) atomicExch(bad, 1); }
+        else { const uint32_t code = (uint32_t)~ref[k]; if ((code >> 3) + (code & 7u) + 1u > ntris) atomicExch(bad, 1); }
+    }
 }
 
 // float 4-wide nodes -> the 64-byte quantised nodes the kernels traverse (same encoder as the host build)
@@ -225,22 +259,50 @@ hipError_t gpu_build_lbvh(const float *d_pos, const uint32_t *d_idx, const uint3
                        par_l.as<int>());
     hipLaunchKernelGGL(refit_kernel, dim3((n + T - 1) / T), dim3(T), 0, s, boxes.as<Box3>(), keys, n, left.as<int>(), right.as<int>(),
                        par_i.as<int>(), par_l.as<int>(), nboxes.as<Box3>(), arrive.as<int>());
-    hipLaunchKernelGGL(depth_kernel, dim3((n_int + T - 1) / T), dim3(T), 0, s, par_i.as<int>(), left.as<int>(), right.as<int>(), n_int,
-                       kept.as<uint32_t>(), maxd.as<int>());
-    tmp_bytes = 0;
-    BCHK(rocprim::exclusive_scan(nullptr, tmp_bytes, kept.as<uint32_t>(), widx.as<uint32_t>(), 0u, (size_t)n_int, rocprim::plus<uint32_t>(), s));
-    BCHK(scan_tmp.alloc(tmp_bytes));
-    BCHK(rocprim::exclusive_scan(scan_tmp.p, tmp_bytes, kept.as<uint32_t>(), widx.as<uint32_t>(), 0u, (size_t)n_int, rocprim::plus<uint32_t>(), s));
-    hipLaunchKernelGGL(emit_wide_kernel, dim3((n_int + T - 1) / T), dim3(T), 0, s, boxes.as<Box3>(), keys, nboxes.as<Box3>(), left.as<int>(),
-                       right.as<int>(), kept.as<uint32_t>(), widx.as<uint32_t>(), n_int, d_nodes4);
-    BCHK(hipGetLastError());
-    uint32_t last_kept = 0, last_idx = 0; int md = 0;
-    BCHK(hipMemcpyAsync(&last_kept, kept.as<uint32_t>() + (n_int - 1), 4, hipMemcpyDeviceToHost, s));
-    BCHK(hipMemcpyAsync(&last_idx, widx.as<uint32_t>() + (n_int - 1), 4, hipMemcpyDeviceToHost, s));
-    BCHK(hipMemcpyAsync(&md, maxd.p, 4, hipMemcpyDeviceToHost, s));
+    uint32_t n4 = 0, d4 = 0;
+    {
+        // greedy level-by-level collapse (kept / widx double as the two frontier buffers)
+        Tmp slots, cnt, off;
+        BCHK(slots.alloc(16 * (size_t)n)); BCHK(cnt.alloc(4 * (size_t)n)); BCHK(off.alloc(4 * (size_t)n));
+        tmp_bytes = 0;
+        BCHK(rocprim::exclusive_scan(nullptr, tmp_bytes, cnt.as<uint32_t>(), off.as<uint32_t>(), 0u, (size_t)n_int, rocprim::plus<uint32_t>(), s));
+        BCHK(scan_tmp.alloc(tmp_bytes));
+        int *front[2] = { kept.as<int>(), widx.as<int>() };
+        BCHK(hipMemsetAsync(front[0], 0, 4, s));  // level 0: the root, BVH2 node 0
+        uint32_t n_cur = 1, wide_base = 0;
+        int cur = 0;
+        while (n_cur > 0) {
+            if (wide_base + n_cur > (uint32_t)n_int || d4 > 4096u) return hipErrorUnknown;  // cannot happen for a tree; never loop forever
+            const dim3 g((n_cur + T - 1) / T);
+            hipLaunchKernelGGL(collapse_plan_kernel, g, dim3(T), 0, s, front[cur], (int)n_cur, left.as<int>(), right.as<int>(), nboxes.as<Box3>(),
+                               slots.as<int>(), cnt.as<uint32_t>());
+            size_t tb = tmp_bytes;
+            BCHK(rocprim::exclusive_scan(scan_tmp.p, tb, cnt.as<uint32_t>(), off.as<uint32_t>(), 0u, (size_t)n_cur, rocprim::plus<uint32_t>(), s));
+            uint32_t last_cnt = 0, last_off = 0;
+            BCHK(hipMemcpyAsync(&last_cnt, cnt.as<uint32_t>() + (n_cur - 1), 4, hipMemcpyDeviceToHost, s));
+            BCHK(hipMemcpyAsync(&last_off, off.as<uint32_t>() + (n_cur - 1), 4, hipMemcpyDeviceToHost, s));
+            BCHK(hipStreamSynchronize(s));
+            const uint32_t n_next = last_off + last_cnt;
+            hipLaunchKernelGGL(collapse_emit_kernel, g, dim3(T), 0, s, front[cur], (int)n_cur, slots.as<int>(), off.as<uint32_t>(), wide_base,
+                               wide_base + n_cur, left.as<int>(), right.as<int>(), nboxes.as<Box3>(), boxes.as<Box3>(), keys, front[cur ^ 1],
+                               d_nodes4);
+            BCHK(hipGetLastError());
+            wide_base += n_cur;
+            n_cur = n_next;
+            cur ^= 1;
+            ++d4;
+        }
+        n4 = wide_base;
+    }
+    // a malformed tree could send a traversal kernel in a circle: check the structure before anybody walks it
+    BCHK(hipMemsetAsync(maxd.p, 0, 4, s));
+    hipLaunchKernelGGL(validate_wide_kernel, dim3((n4 + T - 1) / T), dim3(T), 0, s, d_nodes4, n4, ntris, maxd.as<int>());
+    int bad = 0;
+    BCHK(hipMemcpyAsync(&bad, maxd.p, 4, hipMemcpyDeviceToHost, s));
     BCHK(hipStreamSynchronize(s));
-    *n_nodes4 = last_idx + last_kept;
-    *depth4 = (uint32_t)(md / 2 + 1);
+    if (bad) return hipErrorUnknown;
+    *n_nodes4 = n4;
+    *depth4 = d4;
     return hipSuccess;
 }
 
