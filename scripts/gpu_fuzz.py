@@ -1,0 +1,62 @@
+"""Extended randomised parity fuzz (not part of the test suite: minutes, not seconds): random soups, image sizes, spp,
+bounces and option combinations; the strict build must match the oracle bit for bit, ray counts included.
+python scripts/gpu_fuzz.py [cases] [seed]"""
+import sys, time; sys.path.insert(0, ".")
+import numpy as np
+from toyraygun_amd import capi
+from oracle import pyoracle as O
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+eye = np.eye(4, dtype=np.float32)
+bad = 0
+t_start = time.time()
+for case in range(cases):
+    kind = rng.choice(["box", "small", "large"], p=[0.2, 0.45, 0.35])
+    s = O.OracleScene.cornell_box() if kind != "large" or rng.random() < 0.5 else O.OracleScene()
+    n = 0 if kind == "box" else int(rng.integers(1, 150)) if kind == "small" else int(rng.integers(400, 6000))
+    if n:
+        ctr = rng.uniform([-0.9, 0.1, -0.9], [0.9, 1.9, 0.9], (n, 3)).astype(np.float32)
+        tri = ctr[:, None, :] + rng.normal(0, rng.choice([0.02, 0.1, 0.4]), (n, 3, 3)).astype(np.float32)
+        if n > 10:
+            tri[n // 2: n // 2 + n // 10] = tri[: n // 10]
+        mats = rng.choice([1, 1, 1, 2, 3], n)
+        for k in range(n):
+            s.add_geometry(tri[k], [0, 1, 2], eye, rng.uniform(0.2, 0.9, 3), int(mats[k]))
+    w, h = int(rng.integers(1, 90)), int(rng.integers(1, 70))
+    spp, bnc = int(rng.integers(1, 9)), int(rng.integers(0, 7))
+    opts = dict(force_global=int(rng.integers(0, 2)), fsplit=int(rng.choice([0, 1, 2, 4])), gpu_build=int(rng.integers(0, 2)) if s.ntris >= 2 else 0,
+                kernel=int(rng.choice([0, 0, 0, 1])), in_flight=int(rng.choice([1, 4])), counters=int(rng.integers(0, 2)))
+    off = O.pixel_offsets(w, h, seed=int(rng.integers(1, 2 ** 31)))
+    O.set_trig_mode(O.TRIG_PORTABLE)
+    ref, rst = O.render(s, w, h, spp, bnc, offsets=off)
+    O.set_trig_mode(O.TRIG_LIBM)
+    b = s.buffers()
+    c = capi.Context(w, h)
+    try:
+        c.set_option(capi.OPT_GPU_BUILD, opts["gpu_build"])
+        c.load_scene(b["positions"], b["normals"], b["colors"], b["indices"], b["material_ids"])
+        c.set_uniforms(O.uniforms_bytes(O.make_uniforms(w, h)))
+        c.set_pixel_offsets(off)
+        c.set_option(capi.OPT_STRICT, 1)
+        c.set_option(capi.OPT_FORCE_GLOBAL, opts["force_global"])
+        c.set_option(capi.OPT_FRAME_SPLIT, opts["fsplit"])
+        c.set_option(capi.OPT_KERNEL, opts["kernel"])
+        c.set_option(capi.OPT_LAUNCHES_IN_FLIGHT, opts["in_flight"])
+        c.set_option(capi.OPT_COUNTERS, opts["counters"])
+        split = int(rng.integers(0, spp + 1))
+        if split:
+            c.render(0, split, bnc)
+        if spp - split:
+            c.render(split, spp - split, bnc)
+        img, st = c.read_accum(), c.stats()
+        ok = np.array_equal(img.view(np.uint32), ref.view(np.uint32)) and st.rays == rst.rays
+    finally:
+        c.close()
+    if not ok:
+        bad += 1
+        print("MISMATCH case %d: tris %d %dx%d spp %d (split %d) bounces %d %s rays %d vs %d" % (case, s.ntris, w, h, spp, split, bnc, opts, st.rays, rst.rays), flush=True)
+    if case % 20 == 19:
+        print("case %d, %d mismatches, %.0f s" % (case + 1, bad, time.time() - t_start), flush=True)
+print("done: %d cases, %d mismatches" % (cases, bad))
+sys.exit(1 if bad else 0)
