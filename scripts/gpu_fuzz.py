@@ -1,6 +1,7 @@
 """Extended randomised parity fuzz (not part of the test suite: minutes, not seconds): random soups, image sizes, spp,
 bounces and option combinations; the strict build must match the oracle bit for bit, ray counts included.
-python scripts/gpu_fuzz.py [cases] [seed]"""
+python scripts/gpu_fuzz.py [cases] [seed] [fast]   (fast: the shipped build against the libm oracle within the stated tolerance,
+images of at least 32x32 pixels)"""
 import sys, time; sys.path.insert(0, ".")
 import numpy as np
 from toyraygun_amd import capi
@@ -8,6 +9,7 @@ from oracle import pyoracle as O
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+FAST = len(sys.argv) > 3 and sys.argv[3] == "fast"
 eye = np.eye(4, dtype=np.float32)
 bad = 0
 t_start = time.time()
@@ -24,11 +26,13 @@ for case in range(cases):
         for k in range(n):
             s.add_geometry(tri[k], [0, 1, 2], eye, rng.uniform(0.2, 0.9, 3), int(mats[k]))
     w, h = int(rng.integers(1, 90)), int(rng.integers(1, 70))
+    if FAST:
+        w, h = max(w, 32), max(h, 32)
     spp, bnc = int(rng.integers(1, 9)), int(rng.integers(0, 7))
     opts = dict(force_global=int(rng.integers(0, 2)), fsplit=int(rng.choice([0, 1, 2, 4])), gpu_build=int(rng.integers(0, 2)) if s.ntris >= 2 else 0,
                 kernel=int(rng.choice([0, 0, 0, 1])), in_flight=int(rng.choice([1, 4])), counters=int(rng.integers(0, 2)))
     off = O.pixel_offsets(w, h, seed=int(rng.integers(1, 2 ** 31)))
-    O.set_trig_mode(O.TRIG_PORTABLE)
+    O.set_trig_mode(O.TRIG_LIBM if FAST else O.TRIG_PORTABLE)
     ref, rst = O.render(s, w, h, spp, bnc, offsets=off)
     O.set_trig_mode(O.TRIG_LIBM)
     b = s.buffers()
@@ -38,7 +42,7 @@ for case in range(cases):
         c.load_scene(b["positions"], b["normals"], b["colors"], b["indices"], b["material_ids"])
         c.set_uniforms(O.uniforms_bytes(O.make_uniforms(w, h)))
         c.set_pixel_offsets(off)
-        c.set_option(capi.OPT_STRICT, 1)
+        c.set_option(capi.OPT_STRICT, 0 if FAST else 1)
         c.set_option(capi.OPT_FORCE_GLOBAL, opts["force_global"])
         c.set_option(capi.OPT_FRAME_SPLIT, opts["fsplit"])
         c.set_option(capi.OPT_KERNEL, opts["kernel"])
@@ -50,7 +54,20 @@ for case in range(cases):
         if spp - split:
             c.render(split, spp - split, bnc)
         img, st = c.read_accum(), c.stats()
-        ok = np.array_equal(img.view(np.uint32), ref.view(np.uint32)) and st.rays == rst.rays
+        if FAST:
+            d = np.linalg.norm(img[..., :3].astype(np.float64) - ref[..., :3], axis=-1)
+            nr = np.linalg.norm(ref[..., :3].astype(np.float64), axis=-1)
+            inl = d <= 1e-4 * np.maximum(1.0, nr)
+            frac = float(np.mean(inl))
+            # on these small images ONE edge-flip pixel (a ray that picks the other of two duplicate / coplanar triangles
+            # under FMA rounding) already exceeds the 1e-3 RMSE meant for megapixel frames: RMSE over the inliers, and at
+            # most 0.1 % outliers ("the <= 0.1 % outliers allowed are edge-flip pixels")
+            rmse = float(np.sqrt(np.mean((d * d)[inl]))) if inl.any() else 0.0
+            ok = rmse <= 1e-3 and frac >= 0.999
+            if not ok:
+                print("  rmse %.3g frac_ok %.5f (%d of %d pixels off)" % (rmse, frac, int((d > 1e-4 * np.maximum(1.0, nr)).sum()), w * h))
+        else:
+            ok = np.array_equal(img.view(np.uint32), ref.view(np.uint32)) and st.rays == rst.rays
     finally:
         c.close()
     if not ok:
