@@ -864,6 +864,33 @@ def test_overlapped_launches_are_independent(capi, O, cornell, force_global):
         r.close()
 
 
+def test_overlapped_launches_on_a_deep_hbm_scene(capi, O):
+    """Four launches in flight on a 96 k-triangle lattice: the 4-wide tree is deep enough (3 x depth + 2 > 16 levels) for
+    traversal stacks to spill into the per-launch global scratch, which overlapping launches must not share."""
+    from toyraygun_amd.dist import DistributedRenderer
+    from toyraygun_amd import host
+    w, h, spp, bounces = 160, 96, 2, 3
+    b = host.Scene.cornell_lattice(20).buffers()
+    r = DistributedRenderer(w, h, 0, pipelined=True)
+    try:
+        r.load_scene(b)
+        st = r.ctx.stats()
+        assert st.scene_in_lds == 0 and 3 * st.bvh_depth4 + 2 > 16
+        r.ctx.set_uniforms(host.uniforms(w, h)[0])
+        r.ctx.set_pixel_offsets_seed()
+        r.ctx.set_option(capi.OPT_STRICT, 1)
+        r.ctx.render(0, spp, bounces)                      # one launch alone, timing on (synchronous)
+        alone = r.ctx.read_accum().copy()
+        r.ctx.set_option(capi.OPT_TIMING, 0)
+        for _ in range(12):
+            r.render(0, spp, bounces, gather=False)
+        r.synchronize()
+        for fr in r.frames:
+            assert np.array_equal(_bits(fr.cpu().numpy()), _bits(alone))
+    finally:
+        r.close()
+
+
 def test_single_rank_distributed_renderer(capi, O, cornell):
     from toyraygun_amd.dist import DistributedRenderer
     r = DistributedRenderer(64, 32, 0)
