@@ -39,6 +39,20 @@ def test_no_gpu_means_loud_failure(built):
         capi.Context(0, 16)
 
 
+def test_plain_c_consumer(built, tmp_path):
+    """include/trg.h compiles as C (gcc -std=c99 -pedantic -Werror), the library links from a C program, and on a box
+    without a GPU that program gets TRG_ERR_NODEV with the "no CPU fallback" message from trg_create."""
+    from toyraygun_amd import capi
+    exe = str(tmp_path / "c_consumer")
+    lib_dir = os.path.dirname(capi.HIP_SO)
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "helpers", "c_consumer.c"), "-o", exe,
+                           "-L" + lib_dir, "-ltoyraygun_hip", "-Wl,-rpath," + lib_dir])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert "no CPU fallback" in r.stdout or "gpu path ok" in r.stdout
+
+
 def test_struct_layouts(built):
     from toyraygun_amd import capi
     assert C.sizeof(capi.Uniforms) == 176                     # Uniforms.h:19-41 / MetalRenderer.mm:34-36
