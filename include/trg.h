@@ -182,6 +182,12 @@ TRG_API int trg_debug_build_bvh4(const float *positions3, const uint32_t *indice
 TRG_API int trg_debug_build_bvh4q(const float *positions3, const uint32_t *indices, const uint32_t *material_ids, uint32_t n_verts,
                                   uint32_t n_tris, uint32_t *nodes4q_out, uint32_t nodes4_cap, uint32_t *n_nodes4);
 
+/* host-only: byte layout of the device blob of an HBM-resident scene of n_tris triangles and n_nodes4 wide nodes, computed
+ * exactly as trg_load_scene does (64-bit arithmetic).  TRG_ERR_RANGE when it does not fit the 32-bit offsets the kernels
+ * use (4 GiB) -- trg_load_scene refuses such a scene before it allocates or copies anything.  offsets7 (may be NULL) =
+ * nodes, records, normals, colours, material ids, wide nodes, total. */
+TRG_API int trg_debug_scene_layout(uint64_t n_tris, uint64_t n_nodes4, uint64_t *total_bytes, uint32_t *offsets7);
+
 /* --- N1: ACES tonemap + sRGB of the accumulation buffer to RGBA8 (PostProcessing.metal:44-57;
  *     common.h:36-43,163-171).  flip_y != 0 writes the top image row first (PNG order). */
 TRG_API int trg_postprocess(trg_ctx *ctx, uint8_t *rgba8, int flip_y);

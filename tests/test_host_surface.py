@@ -27,6 +27,27 @@ def test_capi_exports_every_declared_symbol(built):
         assert re.search(r"\bT %s\b" % name, out), name
 
 
+def test_scene_blob_layout_is_64_bit_and_refuses_what_cannot_fit(built):
+    """the blob offsets used to be summed in uint32 and wrapped from ~30 M triangles on, so the 4 GiB check
+    passed on a wrapped total.  The layout is now planned in 64 bits and refused before any allocation."""
+    import ctypes as C
+    from toyraygun_amd import capi
+    L = capi.load()
+    total = C.c_uint64()
+    off = (C.c_uint32 * 7)()
+    assert L.trg_debug_scene_layout(1_022_244, 246_000, C.byref(total), off) == capi.OK
+    o = list(off)
+    assert o[0] == 0 and o[1] == 0 and o == sorted(o) and o[6] == total.value
+    assert o[2] >= 1_022_244 * 48 and o[3] - o[2] >= 1_022_244 * 36 and o[5] % 128 == 0
+    # 30 M triangles still fit (124 B per triangle + nodes = 4.2e9 is just over; 25 M fits)
+    assert L.trg_debug_scene_layout(25_000_000, 6_000_000, C.byref(total), None) == capi.OK
+    assert total.value > 25_000_000 * 124
+    # 50 M triangles: the old uint32 sums wrapped to ~2.9e9 and passed; now refused with the true size
+    assert L.trg_debug_scene_layout(50_000_000, 12_000_000, C.byref(total), None) == capi.ERR_RANGE
+    assert total.value > 2**32
+    assert L.trg_debug_scene_layout(40_000_000, 0, C.byref(total), None) == capi.ERR_RANGE  # even without a single node
+
+
 def test_no_gpu_means_loud_failure(built):
     import torch
     from toyraygun_amd import capi

@@ -56,7 +56,7 @@ def build(force=False, verbose=False):
     dev = ["--offload-arch=" + ARCH]
     # -fno-slp-vectorize: the SLP vectoriser pairs the Halton digit chains of two dimensions into v_pk_mul_f32 /
     # v_pk_fma_f32, which are not faster than two scalar ops on gfx950 and cost 10 VGPRs + scratch spills
-    # (80 VGPRs + 48 B scratch -> 70 VGPRs, none): +9 % on C2, +2.5 % on C4 (profiles/r01/experiments.md)
+    # (80 VGPRs + 48 B scratch -> 70 VGPRs, none): +9 % on C2, +2.5 % on C4 ('registers')
     kern = dev + ["-fno-slp-vectorize"]
 
     objs = []

@@ -71,6 +71,32 @@ static int fail(trg_ctx *c, int code, const char *fmt, ...) {
     } while (0)
 
 static inline uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
+static inline uint64_t align16_64(uint64_t v) { return (v + 15ull) & ~15ull; }
+
+// Byte layout of the scene blob (DESIGN.md "Data layout in HBM"), computed in 64 bits: SceneDesc keeps 32-bit offsets, so a
+// scene whose blob would not fit below 4 GiB is refused BEFORE anything is allocated or copied (the sums used to be
+// 32-bit and wrapped from about 30 M triangles on).  n_nodes = BVH2 / sign-ordered nodes kept in the blob (0 for HBM-only
+// scenes), nt_rec = triangle records, attr_tris = triangles with attributes.
+constexpr uint64_t kBlobLimit = 0xFFFFFFF0ull;
+static bool plan_scene_layout(uint64_t n_nodes, uint32_t node_bytes, uint64_t nt_rec, uint64_t attr_tris, bool with_htab, uint64_t n_nodes4,
+                              SceneDesc &sc, uint64_t &total) {
+    const uint64_t off_nodes = 0;
+    const uint64_t off_tris = align16_64(off_nodes + n_nodes * node_bytes);
+    const uint64_t off_normals = align16_64(off_tris + nt_rec * 48ull);
+    const uint64_t off_colors = align16_64(off_normals + attr_tris * 36ull);
+    const uint64_t off_mats = align16_64(off_colors + attr_tris * 36ull);
+    const uint64_t off_htab = align16_64(off_mats + attr_tris * 4ull);
+    const uint64_t stage_end = align16_64(off_htab + (with_htab ? kHtabBytes : 0u));
+    const uint64_t off_nodes4 = (stage_end + 127ull) & ~127ull;  // 64-byte nodes, two per 128-byte line
+    total = off_nodes4 + n_nodes4 * kQ4NodeBytes + 128ull;
+    if (total > kBlobLimit) return false;
+    sc.off_nodes = (uint32_t)off_nodes; sc.off_tris = (uint32_t)off_tris; sc.off_normals = (uint32_t)off_normals;
+    sc.off_colors = (uint32_t)off_colors; sc.off_mats = (uint32_t)off_mats; sc.off_htab = (uint32_t)off_htab;
+    sc.off_nodes4 = (uint32_t)off_nodes4;
+    sc.lds_stage_bytes = with_htab ? (uint32_t)stage_end : 0u;
+    sc.blob_bytes = (uint32_t)total;
+    return true;
+}
 
 constexpr uint32_t kStackLdsLevels = 16;  // HBM scenes: stack levels kept in LDS (deeper ones spill to global scratch)
 
@@ -179,16 +205,10 @@ static int load_scene_gpu_build(trg_ctx *c, const float *pos, const float *nrm, 
 
     SceneDesc sc{};
     sc.n_nodes = 0; sc.n_tris = n_tris;
-    sc.off_nodes = 0; sc.off_tris = 0;
-    sc.off_normals = align16(n_tris * 48u);
-    sc.off_colors = align16(sc.off_normals + n_tris * 36u);
-    sc.off_mats = align16(sc.off_colors + n_tris * 36u);
-    sc.off_nodes4 = (align16(sc.off_mats + n_tris * 4u) + 127u) & ~127u;
     sc.n_nodes4 = n4;
-    sc.lds_stage_bytes = 0;
-    const uint64_t total = (uint64_t)sc.off_nodes4 + (uint64_t)n4 * kQ4NodeBytes + 128u;
-    if (total > 0xFFFFFFF0ull) return fail(c, TRG_ERR_RANGE, "trg_load_scene: scene needs %llu B on the device (limit 4 GiB)", (unsigned long long)total);
-    sc.blob_bytes = (uint32_t)total;
+    uint64_t total = 0;
+    if (!plan_scene_layout(0, 64u, n_tris, n_tris, false, n4, sc, total))
+        return fail(c, TRG_ERR_RANGE, "trg_load_scene: scene needs %llu B on the device (limit 4 GiB)", (unsigned long long)total);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->blob) { (void)hipFree(c->blob); c->blob = nullptr; c->scene_loaded = false; }
     e = hipMalloc((void **)&c->blob, sc.blob_bytes);
@@ -272,6 +292,12 @@ int trg_load_scene(trg_ctx *c, const float *pos, const float *nrm, const float *
     if (n_tris >= (1u << 28)) return fail(c, TRG_ERR_RANGE, "trg_load_scene: too many triangles (%u)", n_tris);
     for (size_t i = 0; i < (size_t)n_tris * 3; ++i)
         if (idx[i] >= n_verts) return fail(c, TRG_ERR_INVALID, "trg_load_scene: index %u out of range (%u vertices) at %zu", idx[i], n_verts, i);
+    {   // refuse a scene that cannot fit the 32-bit blob offsets before anything is built, allocated or copied
+        SceneDesc probe{};
+        uint64_t least = 0;
+        if (!plan_scene_layout(0, 64u, n_tris, n_tris, false, 0, probe, least))
+            return fail(c, TRG_ERR_RANGE, "trg_load_scene: %u triangles need at least %llu B on the device (limit 4 GiB)", n_tris, (unsigned long long)least);
+    }
     HIPCHK(c, hipSetDevice(c->device));
     if (c->opt_gpu_build && n_tris >= 2) return load_scene_gpu_build(c, pos, nrm, col, idx, mat, n_verts, n_tris);
 
@@ -294,20 +320,11 @@ int trg_load_scene(trg_ctx *c, const float *pos, const float *nrm, const float *
     const bool keep_bvh2 = lds_candidate || !kWideHbm;
     SceneDesc sc{};
     sc.n_nodes = keep_bvh2 ? bvh.n_nodes : 0u; sc.n_tris = n_tris;
-    sc.off_nodes = 0;
     const uint32_t node_bytes = lds_candidate ? kLdsNodeBytes : 64u;
-    sc.off_tris = align16(sc.off_nodes + sc.n_nodes * node_bytes);
-    sc.off_normals = align16(sc.off_tris + nt_rec * 48u);
-    sc.off_colors = align16(sc.off_normals + attr_tris * 36u);
-    sc.off_mats = align16(sc.off_colors + attr_tris * 36u);
-    sc.off_htab = align16(sc.off_mats + attr_tris * 4u);
-    sc.off_nodes4 = align16(sc.off_htab + (lds_candidate ? kHtabBytes : 0u));
-    sc.off_nodes4 = (sc.off_nodes4 + 127u) & ~127u;  // 64-byte nodes, two per 128-byte line
     sc.n_nodes4 = kWideHbm ? bvh.n_nodes4 : 0u;
-    sc.lds_stage_bytes = lds_candidate ? align16(sc.off_htab + kHtabBytes) : 0u;
-    const uint64_t total = (uint64_t)sc.off_nodes4 + (uint64_t)sc.n_nodes4 * kQ4NodeBytes + 128u;
-    if (total > 0xFFFFFFF0ull) return fail(c, TRG_ERR_RANGE, "trg_load_scene: scene needs %llu B on the device (limit 4 GiB)", (unsigned long long)total);
-    sc.blob_bytes = (uint32_t)total;
+    uint64_t total = 0;
+    if (!plan_scene_layout(sc.n_nodes, node_bytes, nt_rec, attr_tris, lds_candidate, sc.n_nodes4, sc, total))
+        return fail(c, TRG_ERR_RANGE, "trg_load_scene: scene needs %llu B on the device (limit 4 GiB)", (unsigned long long)total);
     std::vector<unsigned char> host(sc.blob_bytes, 0);
     if (sc.n_nodes && lds_candidate && kSignedLds) {
         // sign-ordered LDS nodes (trav_node_step_signed): per axis the slab planes of both children as
@@ -605,6 +622,19 @@ int trg_debug_build_bvh4q(const float *positions3, const uint32_t *indices, cons
     if (nodes4q_out) {
         if (nodes4_cap < bvh.n_nodes4) return TRG_ERR_RANGE;
         memcpy(nodes4q_out, bvh.nodes4q.data(), (size_t)bvh.n_nodes4 * kQ4NodeBytes);
+    }
+    return TRG_OK;
+}
+
+int trg_debug_scene_layout(uint64_t n_tris, uint64_t n_nodes4, uint64_t *total_bytes, uint32_t *offsets7) {
+    SceneDesc sc{};
+    uint64_t total = 0;
+    const bool ok = plan_scene_layout(0, 64u, n_tris, n_tris ? n_tris : 1u, false, n_nodes4, sc, total);
+    if (total_bytes) *total_bytes = total;
+    if (!ok) return TRG_ERR_RANGE;
+    if (offsets7) {
+        const uint32_t o[7] = { sc.off_nodes, sc.off_tris, sc.off_normals, sc.off_colors, sc.off_mats, sc.off_nodes4, sc.blob_bytes };
+        memcpy(offsets7, o, sizeof(o));
     }
     return TRG_OK;
 }

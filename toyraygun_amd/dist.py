@@ -130,6 +130,11 @@ class DistributedRenderer:
         # tell the library how many launches overlap: each gets its own traversal-stack scratch, and the frame split adapts
         self._overlap = len(self.render_streams) > 1
         self.ctx.set_option(self.capi.OPT_LAUNCHES_IN_FLIGHT, len(self.render_streams) if self._overlap else 1)
+        if self._overlap:
+            # trg_render's default timing brackets every launch with events and WAITS for the second one (a host sync
+            # per launch): nothing would ever be in flight.  Pipelined rendering is asynchronous; per-launch times come
+            # from events on the launch's own stream (time_launches / launch_ms()).
+            self.ctx.set_option(self.capi.OPT_TIMING, 0)
 
     def render(self, frame_begin, spp, bounces, gather=True):
         """Render this rank's band; with gather=True every rank ends up with the whole frame.
