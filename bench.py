@@ -1,20 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: Mrays/s (primary + bounce + shadow rays) on the Cornell box.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus 1 --steps K --warmup W [--config c2|c3|c4|c5]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-Workload = BASELINE.json configs[1] ("C2"): Cornell box (src/cornellBox.h), 1920x1080, 16 spp, 3 bounces,
-synthetic inputs of SURVEY 8d (seeded per-pixel Halton offsets).  One STEP = one pass of the hot path
-over the whole frame: ONE megakernel launch per GPU (raygen -> 3 x [nearest, shade, shadow] ->
-accumulate for all 16 samples) and, for N > 1, one RCCL all-gather of the row bands.  The frame is
-fixed, so N > 1 is STRONG scaling: rank g renders rows [g*h/N, (g+1)*h/N).
+Default workload = BASELINE.json configs[1] ("C2"): Cornell box (src/cornellBox.h), 1920x1080, 16 spp, 3 bounces,
+synthetic inputs of SURVEY 8d (seeded per-pixel Halton offsets).  `--config c4` = configs[3]: the same settings on the
+1,022,244-triangle replicated-mesh scene (the only configuration whose working set lives in HBM); c3 / c5 = configs[2] /
+configs[4] on one GPU.  One STEP = one pass of the hot path over the whole frame: ONE megakernel launch per GPU (raygen ->
+bounces x [nearest, shade, shadow] -> accumulate for all samples) and, for N > 1, one RCCL all-gather of the row bands.
+The frame is fixed, so N > 1 is STRONG scaling: rank g renders rows [g*h/N, (g+1)*h/N).
 
-Rank 0 prints one JSON line.  `value` counts rays actually traversed (in-kernel counters), inputs
-resident in HBM before the timed region.  `roofline` prices the megakernel with SURVEY 8(d)'s
-algorithmic bytes per ray; `cpu_baseline` times the CPU oracle (a port: the reference has no CPU path)
-on the host cores, rank 0, N = 1 only.
+Rank 0 prints one JSON line.  `value` counts rays actually traversed (in-kernel counters), inputs resident in HBM
+before the timed region.
+
+`roofline` names the resource that BINDS the dominant kernel and never prints a fraction above 1:
+  * scene staged in LDS (C2/C3/C5): the kernel is bound by VALU issue -- `bound: "valu_issue"`, wave-level VALU
+    instructions per launch (rocprofv3 SQ_INSTS_VALU of this build, imported from profiles/, labelled so) x 2 cycles
+    / (1024 SIMDs x 2.4 GHz) against the launch duration measured live with HIP events; beside it `lds` (algorithmic
+    bytes of SURVEY 8(d) -- here they are LDS reads -- from this run's in-kernel counters against the ~150 TB/s
+    ds_read_b128 aggregate) and `hbm` (measured FETCH_SIZE + WRITE_SIZE against 8 TB/s).  Without an imported counter
+    file the primary bound falls back to "lds", which is measured entirely in this run.
+  * scene in HBM (C4): `bound: "hbm"`, algorithmic bytes per launch / launch duration against 8 TB/s, with the measured
+    memory-side traffic (`traffic`, `hbm_measured`) side by side.
+`cpu_baseline` times the CPU oracle (a port: the reference has no CPU path) on the host cores, rank 0, N = 1 only:
+the headline leg is the benched configuration on all cores; the other legs are bounded samples (single thread,
+reduced spp) of the BASELINE configurations with the extrapolation factor stated.
 """
 import argparse
 import json
@@ -31,31 +43,81 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-W, H, SPP, BOUNCES = 1920, 1080, 16, 3
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+LDS_PEAK_GBS = 150000.0     # aggregate ds_read_b64/b128 rate with every CU streaming (MI355X_MICROARCH.md, LDS)
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0  # wave-level VALU instructions per ns: 1024 SIMDs, 2 cycles per wave64 instruction, 2.4 GHz
+PROFILE_ROUND = "r02"
+
+CONFIGS = {
+    "c2": dict(w=1920, h=1080, spp=16, bounces=3, scene="cornell",
+               workload="Cornell box (36 triangles) 1920x1080, 16 spp, 3 bounces (BASELINE configs[1])"),
+    "c3": dict(w=1920, h=1080, spp=256, bounces=8, scene="cornell",
+               workload="Cornell box (36 triangles) 1920x1080, 256 spp, 8 bounces (BASELINE configs[2], deep-bounce divergence stress)"),
+    "c4": dict(w=1920, h=1080, spp=16, bounces=3, scene="lattice44",
+               workload="Cornell box + 44x44x44 replicated cubes = 1,022,244 triangles, 1920x1080, 16 spp, 3 bounces (BASELINE configs[3], BVH/HBM stress)"),
+    "c5": dict(w=3840, h=2160, spp=64, bounces=3, scene="cornell",
+               workload="Cornell box (36 triangles) 3840x2160, 64 spp, 3 bounces (BASELINE configs[4]; row bands over the GPUs)"),
+}
 
 
-def cornell_buffers():
+def scene_buffers(cfg):
     """Scene + uniforms from the PRODUCT's host library (libtoyraygun.so), not from the oracle."""
     from toyraygun_amd import host
-    return host.Scene.cornell_box().buffers(), host.uniforms(W, H)[0]
+    sc = host.Scene.cornell_lattice(44) if cfg["scene"] == "lattice44" else host.Scene.cornell_box()
+    return sc.buffers(), host.uniforms(cfg["w"], cfg["h"])[0]
 
 
 from toyraygun_amd.roofline import algorithmic_bytes_per_ray  # SURVEY 8(d) figure from the kernel's counters
 
 
-def cpu_baseline(buffers_unused):
-    """The CPU oracle (project restatement of the Metal semantics, brute-force intersector over the 36
-    triangles, OpenMP over row bands) on the same C2 workload, all host cores."""
+def _oracle_leg(O, scene, name, w, h, spp, bounces, full_spp, threads):
+    t0 = time.perf_counter()
+    _, st = O.render(scene, w, h, spp, bounces, nthreads=threads)
+    dt = time.perf_counter() - t0
+    return {"config": name, "value": st.rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "rays": int(st.rays), "seconds": round(dt, 3),
+            "sample": "%dx%d, %d of %d spp, %d bounces" % (w, h, spp, full_spp, bounces),
+            "extrapolation": "x%g in spp to the full configuration (cost is linear in spp: frames are independent)" % (full_spp / spp),
+            "full_config_seconds_estimate": round(dt * full_spp / spp, 2)}
+
+
+def cpu_baseline(config_name):
+    """The CPU oracle (project restatement of the Metal semantics; OpenMP over row bands; brute force over the 36
+    triangles of the Cornell box, its own BVH on the lattice) on the GPU box's host cores.  Headline leg = the benched
+    configuration on all cores; the other legs are the bounded samples SURVEY 8(d) / BASELINE.md ask for."""
     from oracle import pyoracle as O
-    scene = O.OracleScene.cornell_box()
+    box = O.OracleScene.cornell_box()
     # the GPU box gives one GPU a CPU share of 16 cores even though it shows more hardware threads
     threads = max(1, min(O.num_threads(), len(os.sched_getaffinity(0)), 16))
-    t0 = time.perf_counter()
-    _, st = O.render(scene, W, H, SPP, BOUNCES, nthreads=threads)
-    dt = time.perf_counter() - t0
-    return {"value": st.rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": "the whole C2 frame (1920x1080, 16 spp, 3 bounces), %d rays in %.1f s" % (st.rays, dt)}
+    legs = []
+    lattice = None
+    if config_name == "c4" or not os.environ.get("TRG_BENCH_FEW_CPU_LEGS"):
+        lattice = O.OracleScene.cornell_lattice(44)
+        O.render(lattice, 16, 16, 1, 1, nthreads=threads)   # builds the oracle's BVH (not part of the timed sample)
+    legs.append(_oracle_leg(O, box, "C1", 256, 256, 1, 1, 1, 1))
+    legs.append(_oracle_leg(O, box, "C2", 1920, 1080, 16, 3, 16, threads))
+    legs.append(_oracle_leg(O, box, "C2", 1920, 1080, 1, 3, 16, 1))
+    legs.append(_oracle_leg(O, box, "C3", 1920, 1080, 2, 8, 256, threads))
+    if lattice is not None:
+        legs.append(_oracle_leg(O, lattice, "C4", 1920, 1080, 1, 3, 16, threads))
+    legs.append(_oracle_leg(O, box, "C5", 3840, 2160, 1, 3, 64, threads))
+    want = config_name.upper()
+    head = next(l for l in legs if l["config"] == want and l["cores"] == threads)
+    return {"value": head["value"], "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": "%s: %s, %d rays in %.1f s; %s" % (head["config"], head["sample"], head["rays"], head["seconds"], head["extrapolation"]),
+            "note": "project CPU restatement of ToyRaygun's Metal semantics (oracle/trg_oracle.c), never a reference CPU path: the reference has none",
+            "legs": legs}
+
+
+def imported_counters(config_name):
+    """Per-launch PMC counters of THIS build's megakernel from the committed rocprofv3 passes (scripts/profile_round.sh ->
+    profiles/<round>/<config>_counters.json).  bench.py cannot run the profiler on itself; the numbers are labelled imported."""
+    path = os.path.join(ROOT, "profiles", PROFILE_ROUND, "%s_counters.json" % config_name)
+    if not os.path.exists(path):
+        return None, None
+    try:
+        return json.load(open(path)), os.path.relpath(path, ROOT)
+    except Exception:
+        return None, None
 
 
 def main():
@@ -63,8 +125,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    W, H, SPP, BOUNCES = cfg["w"], cfg["h"], cfg["spp"], cfg["bounces"]
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -83,7 +148,7 @@ def main():
     from toyraygun_amd import capi
     from toyraygun_amd.dist import DistributedRenderer
 
-    buffers, uniforms = cornell_buffers()
+    buffers, uniforms = scene_buffers(cfg)
     # four frame buffers on four alternating render streams (+ a communication stream): consecutive steps are independent
     # images, so the next steps fill the CUs that the tail of step k leaves idle (or that a small row band never fills),
     # and the gather of k overlaps the renders that follow
@@ -101,26 +166,28 @@ def main():
             torch.cuda.synchronize(dev)
 
     # counters pass (untimed): algorithmic bytes per ray for the roofline object
+    r.ctx.set_option(capi.OPT_TIMING, 1)
     r.ctx.set_option(capi.OPT_COUNTERS, 1)
     r.ctx.reset_stats()
     r.ctx.render(0, SPP, BOUNCES, r.row0, r.rows)
     cst = r.ctx.stats()
     bytes_per_ray, mix = algorithmic_bytes_per_ray(cst, r.rows * W * SPP)
     rays_per_launch = cst.rays
+    lane_util_nodes = cst.node_fetches / (64.0 * cst.wave_node_iters * (1 if cst.scene_in_lds else 2)) if cst.wave_node_iters else None
     r.ctx.set_option(capi.OPT_COUNTERS, 0)
 
     gather = distributed or bool(os.environ.get("TRG_FORCE_GATHER"))
     for _ in range(args.warmup):
         r.render(0, SPP, BOUNCES, gather=gather)
     sync_all()
-    # average launch duration of the megakernel: HIP events on the stream it runs on (trg_render brackets the launch with
-    # hipEventRecord on the context's stream), measured here on 3 launches that run alone -- the event wait is a host
-    # sync, which would serialise the pipeline inside the timed region (and there two launches overlap on purpose).
+    # launch duration of the megakernel when it runs ALONE: HIP events on the stream it runs on (trg_render brackets the
+    # launch with hipEventRecord on the context's stream), 3 launches -- the event wait is a host sync, which would
+    # serialise the pipeline inside the timed region (and there several launches overlap on purpose).
     r.ctx.reset_stats()
     for _ in range(3):
         r.ctx.render(0, SPP, BOUNCES, r.row0, r.rows)
     pst = r.ctx.stats()
-    kernel_ms_pre = pst.total_render_ms / max(pst.renders, 1)
+    kernel_ms_alone = pst.total_render_ms / max(pst.renders, 1)
     r.ctx.set_option(capi.OPT_TIMING, 0)
     sync_all()
     r.ctx.reset_stats()
@@ -153,33 +220,60 @@ def main():
 
     if rank == 0:
         value = rays_total / dt / 1e6
-        achieved = rays_per_launch * bytes_per_ray / (kernel_eff_ms * 1e-3) / 1e9  # GB/s, dominant kernel (slowest rank)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_c2.json")
-        if world == 1 and os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        in_lds = bool(cst.scene_in_lds)
+        sec = kernel_eff_ms * 1e-3                       # GPU time per launch in the timed region (slowest rank)
+        bytes_per_launch = rays_per_launch * bytes_per_ray
+        algorithmic_gbs = bytes_per_launch / sec / 1e9
+        imp, imp_path = imported_counters(args.config) if world == 1 else (None, None)
+        traffic = imp.get("hbm_bytes_per_launch") if imp else None
+        rf = {"kernel_ms": kernel_ms, "launches_in_flight": concurrency, "kernel_ms_per_launch_effective": kernel_eff_ms,
+              "kernel_alone_ms": kernel_ms_alone, "kernel_alone_mrays_per_s": rays_per_launch / (kernel_ms_alone * 1e-3) / 1e6,
+              "algorithmic_bytes_per_ray": bytes_per_ray, "bytes_per_launch": bytes_per_launch, **mix,
+              "lane_utilisation_node_loop": lane_util_nodes,
+              "traffic": traffic,
+              "imported": ("%s (rocprofv3 --pmc passes of this build: %s)" % (imp_path, imp.get("source", "")) if imp else None)}
+        hbm_measured = None
+        if traffic:
+            hbm_measured = {"achieved": traffic / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": traffic / sec / 1e9 / HBM_PEAK_GBS,
+                            "bytes_per_launch": traffic, "source": "imported: FETCH_SIZE + WRITE_SIZE per launch"}
+        valu = None
+        if imp and imp.get("valu_insts_per_launch"):
+            g = imp["valu_insts_per_launch"] / sec / 1e9
+            valu = {"achieved": g, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s", "frac": g / VALU_PEAK_GINST,
+                    "valu_insts_per_launch": imp["valu_insts_per_launch"],
+                    "lanes_active_per_instruction": imp.get("lanes_active_per_valu_inst"),
+                    "source": "imported: SQ_INSTS_VALU per launch; peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction"}
+        if in_lds:
+            lds = {"achieved": algorithmic_gbs, "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": algorithmic_gbs / LDS_PEAK_GBS,
+                   "note": "SURVEY 8(d)'s algorithmic bytes are LDS reads here (the %.1f KB scene is staged per workgroup); measured live" % (cst.scene_bytes / 1024.0)}
+            if valu:
+                rf = {"bound": "valu_issue", "achieved": valu["achieved"], "peak": valu["peak"], "unit": valu["unit"], "frac": valu["frac"], **rf,
+                      "valu_issue": valu, "lds": lds, "hbm": hbm_measured}
+            else:
+                rf = {"bound": "lds", "achieved": lds["achieved"], "peak": lds["peak"], "unit": lds["unit"], "frac": lds["frac"], **rf,
+                      "lds": lds, "hbm": hbm_measured}
+            rf["note"] = ("LDS-resident scene: the kernel is VALU-issue bound at partial lane utilisation; the HBM side only sees the "
+                          "4-byte offset read and the 16-byte accumulation write per pixel (SURVEY 8d caveat)")
+        else:
+            rf = {"bound": "hbm", "achieved": algorithmic_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algorithmic_gbs / HBM_PEAK_GBS, **rf,
+                  "hbm_measured": hbm_measured, "valu_issue": valu,
+                  "note": "algorithmic bytes (SURVEY 8d: 16 B per box of the 64-byte 4-wide node + 48 B per triangle test + 76 B per shaded hit) "
+                          "against the HBM peak; `traffic` / hbm_measured = what left L2 towards Infinity Cache / HBM"}
         out = {
-            "metric": "Mrays/s (primary+shadow+bounce) at 1920x1080",
+            "metric": "Mrays/s (primary+shadow+bounce) at %dx%d" % (W, H),
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Cornell box (36 triangles) 1920x1080, 16 spp, 3 bounces (BASELINE configs[1])",
+            "config": {"workload": cfg["workload"], "name": args.config,
                        "rays_per_step": rays_total / args.steps, "sharding": "row bands + RCCL all-gather (gather of step k overlaps the renders that follow)" if distributed else "none",
                        "pipeline": ("%d frames in flight on alternating streams: later steps fill the CUs the tail of step k leaves idle "
                                     "(roofline.kernel_ms = average launch duration while they overlap; kernel_alone_ms = one launch by itself)" % len(r.render_streams)) if getattr(r, "_overlap", False) else "serial launches",
-                       "kernel": ("render_kernel" if st.last_frame_split <= 1 else "render_fp_kernel, %d frame lanes" % st.last_frame_split) + "<LDS scene> (fast build)"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel_ms": kernel_ms, "launches_in_flight": concurrency, "kernel_ms_per_launch_effective": kernel_eff_ms,
-                         "kernel_alone_ms": kernel_ms_pre, "kernel_alone_mrays_per_s": rays_per_launch / (kernel_ms_pre * 1e-3) / 1e6,
-                         "algorithmic_bytes_per_ray": bytes_per_ray,
-                         "bytes_per_launch": rays_per_launch * bytes_per_ray, **mix,
-                         "note": "the scene (%.1f KB on the device) is LDS-resident:" % (cst.scene_bytes / 1024.0) + " the algorithmic bytes are served from LDS, so frac > 1 is expected; real HBM traffic (`traffic`, rocprofv3 FETCH_SIZE+WRITE_SIZE) is the offset read, the float4 write and spill scratch (SURVEY 8d caveat)"},
+                       "kernel": ("render_kernel" if st.last_frame_split <= 1 else "render_fp_kernel, %d frame lanes" % st.last_frame_split) + ("<LDS scene>" if in_lds else "<HBM scene, quantised 4-wide BVH>") + " (fast build)",
+                       "triangles": int(len(buffers["material_ids"])), "scene_bytes": int(cst.scene_bytes)},
+            "roofline": rf,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(buffers)
+            out["cpu_baseline"] = cpu_baseline(args.config)
         print(json.dumps(out), flush=True)
     r.close()
     if distributed or launched:

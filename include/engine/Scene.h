@@ -24,6 +24,9 @@ public:
     // beyond the reference: an arbitrary indexed mesh with per-vertex normals
     void addMesh(const bx::Vec3 *vertices, const bx::Vec3 *normals, const uint32_t *indices, int triangleCount,
                  float *transformMtx, bx::Vec3 color, unsigned int materialID);
+    // the same with a colour per vertex (interpolated like the normals, Raytracing.metal:95-112)
+    void addMesh(const bx::Vec3 *vertices, const bx::Vec3 *normals, const bx::Vec3 *colors, const uint32_t *indices,
+                 int triangleCount, float *transformMtx, unsigned int materialID);
 
     // Wavefront OBJ (v / vn / f with v, v/vt, v//vn or v/vt/vn corners, negative indices, polygons as fans).
     // Faces without normals get the flat face normal addGeometry would give them.  Returns the number of

@@ -158,6 +158,10 @@ TRG_API int trg_sync(trg_ctx *ctx);
 TRG_API int trg_trace(trg_ctx *ctx, const trg_ray *rays, size_t n, int any_hit, void *out);
 /* a5: halton(i[k], d[k]) */
 TRG_API int trg_halton(trg_ctx *ctx, const uint32_t *i, const uint32_t *d, size_t n, float *out);
+/* a5 as the SHIPPED megakernel evaluates it on an LDS-resident scene: dimensions 1..5 through the digit-group tables that are
+ * staged into LDS with the scene (not bit-identical to the digit loop: within 2 ulp), every other dimension through the digit
+ * code.  A table index outside [0, radix) yields NaN.  Needs a loaded LDS-sized scene; always runs the fast build. */
+TRG_API int trg_halton_table(trg_ctx *ctx, const uint32_t *i, const uint32_t *d, size_t n, float *out);
 /* a6: primary rays of one frame for the whole image (width*height trg_ray) */
 TRG_API int trg_raygen(trg_ctx *ctx, uint32_t frameIndex, trg_ray *out);
 /* a10/a11: out[k] = {dir.xyz, dist, color.xyz, 0, bounce_dir.xyz, 0} for hit point p[k], unit normal n[k],

@@ -158,6 +158,17 @@ class OracleScene:
         self.L.orc_scene_add_geometry(self.p, _fp(v), t.ctypes.data_as(C.POINTER(C.c_uint32)), t.size // 3,
                                       _fp(m), _fp(c), material_id)
 
+    def add_raw(self, positions, normals, colors, material_ids):
+        """Append unindexed triangles exactly as given (the five Scene.h vectors are public): per-corner positions,
+        normals and colours [3*n, 3], material ids [n]."""
+        p = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+        n = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+        c = np.ascontiguousarray(colors, np.float32).reshape(-1, 3)
+        m = np.ascontiguousarray(material_ids, np.uint32).reshape(-1)
+        assert p.shape[0] == 3 * m.shape[0] == n.shape[0] == c.shape[0]
+        self.L.orc_scene_add_raw.argtypes = [C.POINTER(Scene), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        self.L.orc_scene_add_raw(self.p, p.ctypes.data, n.ctypes.data, c.ctypes.data, m.ctypes.data, m.shape[0])
+
     @property
     def ntris(self):
         return int(self.p.contents.ntris)

@@ -247,6 +247,26 @@ void orc_scene_add_geometry(orc_scene *s, const float *verts3, const uint32_t *t
         s->material_ids[s->ntris++] = material_id;
     }
 }
+/* The five vectors of src/engine/Scene.h:25-29 are PUBLIC members: an application may fill them with anything (the
+ * per-corner normals and colours need not be equal).  This appends tri_count unindexed triangles exactly as given --
+ * it is how the tests feed smooth-normal / per-vertex-colour meshes, which Raytracing.metal:95-112 interpolates. */
+void orc_scene_add_raw(orc_scene *s, const float *pos9, const float *nrm9, const float *col9, const uint32_t *material_ids,
+                       int tri_count)
+{
+    scene_reserve(s, (uint32_t)tri_count);
+    if (s->accel) { accel_free(s->accel); s->accel = NULL; }
+    for (int i = 0; i < tri_count; ++i) {
+        for (int j = 0; j < 3; ++j) {
+            uint32_t v = s->nverts;
+            memcpy(&s->positions[v * 3], &pos9[(i * 3 + j) * 3], 12);
+            memcpy(&s->normals[v * 3], &nrm9[(i * 3 + j) * 3], 12);
+            memcpy(&s->colors[v * 3], &col9[(i * 3 + j) * 3], 12);
+            s->indices[v] = v;
+            s->nverts++;
+        }
+        s->material_ids[s->ntris++] = material_ids[i];
+    }
+}
 /* src/engine/Scene.cpp:13-22 cubeVertices */
 static const float k_cube_verts[8 * 3] = {
     -0.5f, -0.5f, -0.5f, 0.5f, -0.5f, -0.5f, -0.5f, 0.5f, -0.5f, 0.5f, 0.5f, -0.5f,

@@ -97,6 +97,8 @@ orc_scene *orc_scene_new(void);
 void orc_scene_free(orc_scene *s);
 void orc_scene_add_geometry(orc_scene *s, const float *verts3, const uint32_t *tri_idx, int tri_count,
                             const float *mtx, const float color[3], uint32_t material_id);
+void orc_scene_add_raw(orc_scene *s, const float *pos9, const float *nrm9, const float *col9, const uint32_t *material_ids,
+                       int tri_count); /* Scene.h:25-29 public vectors, appended as given */
 void orc_scene_add_cube(orc_scene *s, const float color[3], const float *mtx);
 void orc_scene_add_plane(orc_scene *s, const float color[3], const float *mtx);
 void orc_scene_add_area_light(orc_scene *s, const float color[3], const float *mtx);

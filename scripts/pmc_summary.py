@@ -1,0 +1,70 @@
+"""Condenses the rocprofv3 passes of scripts/profile_round.sh:  python3 scripts/pmc_summary.py <dir> c2 [c4]
+-> <dir>/summary.json (everything), <dir>/<cfg>_kernel_stats.csv (the --stats table) and <dir>/<cfg>_counters.json, the
+per-launch counters of the benched megakernel that bench.py imports into its roofline object."""
+import collections
+import csv
+import glob
+import json
+import subprocess
+import sys
+
+out = sys.argv[1]
+cfgs = sys.argv[2:] or ["c2", "c4"]
+try:
+    commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+except Exception:
+    commit = ""
+summary = {}
+for cfg in cfgs:
+    counters = {}
+    for f in glob.glob(f"{out}/{cfg}_*/*/*_counter_collection.csv"):
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            if "render" in k and "_kernel<" in k:
+                agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+        for (k, c), v in agg.items():
+            counters.setdefault(k, {})[c] = {"launches": len(v), "mean": sum(v) / len(v)}
+    stats = []
+    for f in glob.glob(f"{out}/{cfg}_trace/*/*_kernel_stats.csv"):
+        stats = [r for r in csv.DictReader(open(f))][:4]
+        open(f"{out}/{cfg}_kernel_stats.csv", "w").write(open(f).read())
+    summary[cfg] = {"kernel_stats_top": stats, "pmc_per_launch": counters}
+    # per-launch view of the trace: bench.py runs a few launches alone (HIP-event timed) and then keeps 4 in flight, so the
+    # kernel_stats average mixes two populations; list them apart (overlap = launches whose interval intersects another's)
+    by_kernel = collections.defaultdict(list)
+    for f in glob.glob(f"{out}/{cfg}_trace/*/*_kernel_trace.csv"):
+        for r in csv.DictReader(open(f)):
+            if "render" in r["Kernel_Name"] and "_kernel<" in r["Kernel_Name"]:
+                by_kernel[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+    launches = sorted(max(by_kernel.values(), key=len)) if by_kernel else []  # the timed instantiation (the COUNT one runs once)
+    alone, shared = [], []
+    for i, (a, b) in enumerate(launches):
+        over = any(j != i and launches[j][0] < b and launches[j][1] > a for j in range(len(launches)))
+        (shared if over else alone).append((b - a) / 1e6)
+    if launches:
+        summary[cfg]["launches"] = {"alone_ms": alone, "overlapped_ms": shared,
+                                    "overlapped_mean_ms": sum(shared) / max(len(shared), 1), "alone_mean_ms": sum(alone) / max(len(alone), 1),
+                                    "pipeline_ms_per_launch": (launches[-1][1] - launches[len(alone)][0]) / 1e6 / max(len(shared), 1) if shared else None}
+        print(cfg, "launches alone:", [round(x, 3) for x in alone], "overlapped:", [round(x, 3) for x in shared])
+    # the kernel bench.py times = the one with the most launches
+    if counters:
+        kname = max(counters, key=lambda k: max(v["launches"] for v in counters[k].values()))
+        c = {n: v["mean"] for n, v in counters[kname].items()}
+        fetch = c.get("FETCH_SIZE", 0.0) * 1024.0   # rocprofv3 reports KiB
+        write = c.get("WRITE_SIZE", 0.0) * 1024.0
+        rec = {"kernel": kname, "commit": commit,
+               "valu_insts_per_launch": c.get("SQ_INSTS_VALU"), "salu_insts_per_launch": c.get("SQ_INSTS_SALU"), "lds_insts_per_launch": c.get("SQ_INSTS_LDS"),
+               "lanes_active_per_valu_inst": (c["SQ_THREAD_CYCLES_VALU"] / c["SQ_INSTS_VALU"]) if c.get("SQ_THREAD_CYCLES_VALU") and c.get("SQ_INSTS_VALU") else None,
+               "fetch_bytes": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
+               "wave_cycles": c.get("SQ_WAVE_CYCLES"), "wait_any_cycles": c.get("SQ_WAIT_ANY"), "busy_cycles": c.get("SQ_BUSY_CYCLES"),
+               "lds_idx_active": c.get("SQ_LDS_IDX_ACTIVE"), "lds_bank_conflict": c.get("SQ_LDS_BANK_CONFLICT"),
+               "tcc_hit": c.get("TCC_HIT_sum"), "tcc_miss": c.get("TCC_MISS_sum"), "ta_busy_avr": c.get("TA_BUSY_avr"), "gui_active": c.get("GRBM_GUI_ACTIVE"),
+               "alone_mean_ms": summary[cfg].get("launches", {}).get("alone_mean_ms"),
+               "source": "scripts/profile_round.sh at commit %s: one rocprofv3 --pmc pass per counter group of `python3 bench.py%s`, per-launch means; "
+                         "FETCH_SIZE/WRITE_SIZE in KiB x 1024, no width correction applied (profiles/%s: fetch_calibration)" % (commit, "" if cfg == "c2" else " --config " + cfg, "r02")}
+        json.dump(rec, open(f"{out}/{cfg}_counters.json", "w"), indent=1)
+        print(cfg, json.dumps({k: (round(v) if isinstance(v, float) and v > 100 else v) for k, v in rec.items() if k not in ("source",)}))
+    for r in stats[:2]:
+        print(cfg, r["Name"][:70], "calls", r["Calls"], "avg ns", r["AverageNs"])
+json.dump(summary, open(f"{out}/summary.json", "w"), indent=1)

@@ -16,6 +16,12 @@ def image_metrics(img, ref):
 # RMSE <= 1e-3 and >= 99.9 % of pixels with L2 <= 1e-4 * max(1, |ref|).
 TOL_RMSE = 1e-3
 TOL_FRAC = 0.999
+# C4 exception ("C4 tolerance"): the replicated-mesh scene has 85,184 small cubes, i.e. ~1 M silhouette
+# and crease edges where the Cornell box has ~50.  A ray that grazes an edge may resolve to the other face under FMA
+# contraction (an "edge flip": a whole different path, not a rounding difference), and the share of such pixels scales
+# with the edge length in the picture: measured 0.15 % at 1 spp, against 0.002 % on the Cornell box.  The RMSE bar is
+# unchanged; the pixel share for C4 is 99.7 %.
+TOL_FRAC_C4 = 0.997
 
 
 def make_ctx(O, scene, w, h, offsets=None, uniforms=None):

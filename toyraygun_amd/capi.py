@@ -79,6 +79,7 @@ _SYMBOLS = [
     ("trg_sync", C.c_int, [_P]),
     ("trg_trace", C.c_int, [_P, _P, C.c_size_t, C.c_int, _P]),
     ("trg_halton", C.c_int, [_P, _P, _P, C.c_size_t, _P]),
+    ("trg_halton_table", C.c_int, [_P, _P, _P, C.c_size_t, _P]),
     ("trg_raygen", C.c_int, [_P, C.c_uint32, _P]),
     ("trg_sample", C.c_int, [_P, _P, _P, _P, C.c_size_t, _P]),
     ("trg_postprocess", C.c_int, [_P, _P, C.c_int]),
@@ -221,6 +222,14 @@ class Context:
         d = np.ascontiguousarray(d, np.uint32).reshape(-1)
         out = np.zeros(i.shape[0], np.float32)
         self._chk(self.L.trg_halton(self.h_ctx, _ptr(i), _ptr(d), i.shape[0], _ptr(out)))
+        return out
+
+    def halton_table(self, i, d):
+        """a5 through the shipped megakernel's own path (digit-group tables in LDS for dimensions 1..5)."""
+        i = np.ascontiguousarray(i, np.uint32).reshape(-1)
+        d = np.ascontiguousarray(d, np.uint32).reshape(-1)
+        out = np.zeros(i.shape[0], np.float32)
+        self._chk(self.L.trg_halton_table(self.h_ctx, _ptr(i), _ptr(d), i.shape[0], _ptr(out)))
         return out
 
     def raygen(self, frame_index):

@@ -85,6 +85,20 @@ void Scene::addMesh(const bx::Vec3 *vertices, const bx::Vec3 *normals, const uin
     }
 }
 
+void Scene::addMesh(const bx::Vec3 *vertices, const bx::Vec3 *normals, const bx::Vec3 *colors, const uint32_t *indices,
+                    int triangleCount, float *transformMtx, unsigned int materialID) {
+    for (int t = 0; t < triangleCount; ++t) {
+        const uint32_t *tri = &indices[t * 3];
+        for (int c = 0; c < 3; ++c) {
+            m_vertexBuffer.push_back(transformed(vertices[tri[c]], transformMtx, 1.0f));
+            m_indexBuffer.push_back((uint32_t)(m_vertexBuffer.size() - 1));
+            m_normalBuffer.push_back(bx::normalize(transformed(normals[tri[c]], transformMtx, 0.0f)));
+            m_colorBuffer.push_back(colors[tri[c]]);
+        }
+        m_materialIDBuffer.push_back(materialID);
+    }
+}
+
 int Scene::addObj(const char *path, float *transformMtx, bx::Vec3 color, unsigned int materialID) {
     FILE *f = fopen(path, "r");
     if (!f) return -1;

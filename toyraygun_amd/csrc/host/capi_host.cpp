@@ -35,6 +35,13 @@ void trh_scene_add_mesh(void *s, const float *verts3, const float *normals3, con
     static_cast<Scene *>(s)->addMesh(reinterpret_cast<const bx::Vec3 *>(verts3), reinterpret_cast<const bx::Vec3 *>(normals3),
                                      indices, triCount, m, bx::Vec3(color3[0], color3[1], color3[2]), materialID);
 }
+void trh_scene_add_mesh_colors(void *s, const float *verts3, const float *normals3, const float *colors3, const uint32_t *indices,
+                               int triCount, const float *mtx16, unsigned int materialID) {
+    float m[16];
+    memcpy(m, mtx16, sizeof(m));
+    static_cast<Scene *>(s)->addMesh(reinterpret_cast<const bx::Vec3 *>(verts3), reinterpret_cast<const bx::Vec3 *>(normals3),
+                                     reinterpret_cast<const bx::Vec3 *>(colors3), indices, triCount, m, materialID);
+}
 int trh_scene_add_obj(void *s, const char *path, const float *mtx16, const float *color3, unsigned int materialID) {
     float m[16];
     memcpy(m, mtx16, sizeof(m));

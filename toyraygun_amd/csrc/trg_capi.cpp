@@ -690,6 +690,27 @@ int trg_halton(trg_ctx *c, const uint32_t *i, const uint32_t *d, size_t n, float
     return TRG_OK;
 }
 
+int trg_halton_table(trg_ctx *c, const uint32_t *i, const uint32_t *d, size_t n, float *out) {
+    if (!c || (n && (!i || !d || !out)) || n > 0x7FFFFFFFull) return TRG_ERR_INVALID;
+    if (!c->scene_loaded || c->sc.lds_stage_bytes == 0)
+        return fail(c, TRG_ERR_INVALID, "trg_halton_table: needs a loaded scene small enough for LDS (the group tables are staged with it)");
+    if (n == 0) return TRG_OK;
+    for (size_t k = 0; k < n; ++k)
+        if (d[k] >= 64) return fail(c, TRG_ERR_RANGE, "trg_halton_table: dimension %u >= 64", d[k]);
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf di, dd, dout;
+    HIPCHK(c, di.alloc(n * 4)); HIPCHK(c, dd.alloc(n * 4)); HIPCHK(c, dout.alloc(n * 4));
+    HIPCHK(c, hipMemcpyAsync(di.p, i, n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dd.p, d, n * 4, hipMemcpyHostToDevice, c->stream));
+    // always the shipped (fast) build: the strict build never uses the tables
+    hipError_t e = launch_halton_tab_fast(reinterpret_cast<const float *>(c->blob + c->sc.off_htab), (const uint32_t *)di.p, (const uint32_t *)dd.p,
+                                          (uint32_t)n, (float *)dout.p, c->stream);
+    if (e != hipSuccess) return fail(c, TRG_ERR_DEVICE, "trg_halton_table: launch failed: %s", hipGetErrorString(e));
+    HIPCHK(c, hipMemcpyAsync(out, dout.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return TRG_OK;
+}
+
 int trg_raygen(trg_ctx *c, uint32_t frameIndex, trg_ray *out) {
     if (!c || !out) return TRG_ERR_INVALID;
     if (!c->have_uniforms || !c->have_offsets) return fail(c, TRG_ERR_INVALID, "trg_raygen: uniforms / pixel offsets not set");

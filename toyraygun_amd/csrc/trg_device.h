@@ -199,7 +199,9 @@ TRG_DEV float halton_c(uint32_t i) {
 // hi / lo split and the same direct quotients, but in radix R = b^K -- one LDS lookup of the radical inverse of a whole
 // K-digit group (trg_kernels.h kHtab) instead of K digits.  Not bit-identical to the digit loop (the groups are summed
 // with correctly rounded weights), within an ulp or two of it; the strict build never uses it.
-template <uint32_t D>
+// CHECK (test entry trg_halton_table only): a group remainder outside [0, radix) -- an out-of-range table index -- poisons the
+// result with NaN; the arithmetic is otherwise the megakernel's, instruction for instruction.
+template <uint32_t D, bool CHECK = false>
 TRG_DEV float halton_t(uint32_t i, const float *htab) {
     constexpr uint32_t B = halton_prime(D);
     constexpr trg::HtabSpec spec = trg::kHtab[D - 1];
@@ -215,6 +217,7 @@ TRG_DEV float halton_t(uint32_t i, const float *htab) {
     const uint32_t hi = i / B1;
     const uint32_t lo = i - hi * B1;
     float r = 0.0f;
+    bool bad = false;
     {
         constexpr int G = (K1 + K - 1) / K;
         const float n = (float)lo, nh = n + 0.5f;
@@ -223,7 +226,8 @@ TRG_DEV float halton_t(uint32_t i, const float *htab) {
         for (int g = 0; g < G; ++g) {
             const float q1 = (g + 1 < G) ? __builtin_floorf(nh * rp.f[(g + 1) * K]) : 0.0f;
             const float rem = __builtin_fmaf(q1, -Rf, q0);
-            r = __builtin_fmaf(T[(int)rem], wt.f[g * K], r);
+            if (CHECK && !(rem >= 0.0f && rem < Rf)) bad = true;
+            else r = __builtin_fmaf(T[(int)rem], wt.f[g * K], r);
             q0 = q1;
         }
     }
@@ -235,11 +239,24 @@ TRG_DEV float halton_t(uint32_t i, const float *htab) {
         for (int g = 0; g < G; ++g) {
             const float q1 = (g + 1 < G) ? __builtin_floorf(nh * rp.f[(g + 1) * K]) : 0.0f;
             const float rem = __builtin_fmaf(q1, -Rf, q0);
-            r = __builtin_fmaf(T[(int)rem], wt.f[K1 + g * K], r);
+            if (CHECK && !(rem >= 0.0f && rem < Rf)) bad = true;
+            else r = __builtin_fmaf(T[(int)rem], wt.f[K1 + g * K], r);
             q0 = q1;
         }
     }
-    return r;
+    return (CHECK && bad) ? __builtin_nanf("") : r;
+}
+// any dimension the way the shipped megakernel evaluates it on an LDS-resident scene: group tables for 1..5, digits otherwise
+TRG_DEV float halton_any(uint32_t i, uint32_t d);
+TRG_DEV float halton_any_tab(uint32_t i, uint32_t d, const float *htab) {
+    switch (d & 63u) {
+    case 1: return halton_t<1, true>(i, htab);
+    case 2: return halton_t<2, true>(i, htab);
+    case 3: return halton_t<3, true>(i, htab);
+    case 4: return halton_t<4, true>(i, htab);
+    case 5: return halton_t<5, true>(i, htab);
+    default: return halton_any(i, d);
+    }
 }
 template <uint32_t D, bool TAB>
 TRG_DEV float halton_d(uint32_t i, const float *htab) {

@@ -101,6 +101,8 @@ static_assert(!kSignedLds || kWideHbm, "sign-ordered LDS nodes replace the BVH2 
     hipError_t launch_trace_##SFX(const TraceParams &p, bool lds_scene, bool any_hit, size_t lds_bytes,          \
                                   hipStream_t s);                                                                \
     hipError_t launch_halton_##SFX(const uint32_t *i, const uint32_t *d, uint32_t n, float *out, hipStream_t s); \
+    hipError_t launch_halton_tab_##SFX(const float *htab, const uint32_t *i, const uint32_t *d, uint32_t n, float *out,   \
+                                       hipStream_t s);                                                           \
     hipError_t launch_raygen_##SFX(const trg_uniforms &u, const uint32_t *offsets, trg_ray *out, hipStream_t s); \
     hipError_t launch_sample_##SFX(const trg_uniforms &u, const float *p3, const float *n3, const float *r4,     \
                                    uint32_t n, float *out12, hipStream_t s);                                     \

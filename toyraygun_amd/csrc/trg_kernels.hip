@@ -568,6 +568,16 @@ __global__ void halton_kernel(const uint32_t *i, const uint32_t *d, uint32_t n, 
     if (k < n) out[k] = halton_any(i[k], d[k]);
 }
 
+// a5 as the SHIPPED megakernel evaluates it on an LDS-resident scene: the group tables staged into LDS exactly like
+// scene_view does, dimensions 1..5 through halton_t (checked), the others through the digit code
+__global__ void halton_tab_kernel(const float *htab_global, const uint32_t *i, const uint32_t *d, uint32_t n, float *out) {
+    __shared__ float T[trg::kHtabBytes / 4];
+    for (uint32_t k = threadIdx.x; k < trg::kHtabBytes / 4; k += blockDim.x) T[k] = htab_global[k];
+    __syncthreads();
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = halton_any_tab(i[k], d[k], T);
+}
+
 __global__ void raygen_kernel(const trg_uniforms u, const uint32_t *offsets, trg_ray *out) {
     const uint32_t x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (x >= u.width || y >= u.height) return;
@@ -680,6 +690,12 @@ hipError_t SFX(launch_trace)(const TraceParams &p, bool lds_scene, bool any_hit,
 hipError_t SFX(launch_halton)(const uint32_t *i, const uint32_t *d, uint32_t n, float *out, hipStream_t s) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(halton_kernel, dim3((n + 255) / 256), dim3(256), 0, s, i, d, n, out);
+    return hipGetLastError();
+}
+
+hipError_t SFX(launch_halton_tab)(const float *htab, const uint32_t *i, const uint32_t *d, uint32_t n, float *out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(halton_tab_kernel, dim3((n + 255) / 256), dim3(256), 0, s, htab, i, d, n, out);
     return hipGetLastError();
 }
 

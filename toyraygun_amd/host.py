@@ -13,7 +13,7 @@ from . import capi
 HOST_SO = os.path.join(capi.LIB_DIR, "libtoyraygun.so")
 _lib = None
 
-SYMBOL_NAMES = ["trh_scene_new", "trh_scene_cornell", "trh_scene_lattice", "trh_scene_free", "trh_scene_add", "trh_scene_add_mesh", "trh_scene_add_obj",
+SYMBOL_NAMES = ["trh_scene_new", "trh_scene_cornell", "trh_scene_lattice", "trh_scene_free", "trh_scene_add", "trh_scene_add_mesh", "trh_scene_add_mesh_colors", "trh_scene_add_obj",
                 "trh_scene_counts", "trh_scene_copy", "trh_mtx_srt", "trh_mtx_inverse", "trh_uniforms",
                 "trh_random_texture", "trh_run_app"]
 
@@ -33,6 +33,7 @@ def load():
         L.trh_scene_free.argtypes = [P]
         L.trh_scene_add.argtypes = [P, C.c_int, F, F]
         L.trh_scene_add_mesh.argtypes = [P, F, F, F, C.c_int, F, F, C.c_uint]
+        L.trh_scene_add_mesh_colors.argtypes = [P, F, F, F, F, C.c_int, F, C.c_uint]
         L.trh_scene_add_obj.argtypes = [P, C.c_char_p, F, F, C.c_uint]
         L.trh_scene_add_obj.restype = C.c_int
         L.trh_scene_counts.argtypes = [P, C.POINTER(C.c_uint)]
@@ -81,8 +82,14 @@ class Scene:
         self.L.trh_scene_add(self.h, self.KINDS[kind], c.ctypes.data, m.ctypes.data)
 
     def add_mesh(self, verts, normals, tri_idx, mtx, color, material_id):
+        """Scene::addMesh.  color: one RGB for the whole mesh, or an [n_verts, 3] array of per-vertex colours."""
         v, n, m, c = _f32(verts), _f32(normals), _f32(mtx).reshape(16), _f32(color)
         t = np.ascontiguousarray(tri_idx, np.uint32)
+        if c.ndim == 2:
+            assert c.shape == v.reshape(-1, 3).shape
+            self.L.trh_scene_add_mesh_colors(self.h, v.ctypes.data, n.ctypes.data, c.ctypes.data, t.ctypes.data, t.size // 3,
+                                             m.ctypes.data, material_id)
+            return
         self.L.trh_scene_add_mesh(self.h, v.ctypes.data, n.ctypes.data, t.ctypes.data, t.size // 3, m.ctypes.data,
                                   c.ctypes.data, material_id)
 
