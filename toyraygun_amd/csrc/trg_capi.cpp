@@ -105,10 +105,10 @@ static bool plan_lds_as(const trg_ctx *c, LdsPlan &p, bool lds_scene, bool pool,
     p.lds_scene = lds_scene;
     uint32_t levels;
     if (p.lds_scene) {
-        levels = c->bvh_depth + 2;      // BVH2, near child first: at most one pending entry per level
+        levels = c->bvh_depth + 3;      // the sentinel at level 0 + BVH2, near child first: at most one pending entry per level + the scratch slot above the top
         p.klds = levels;
     } else {
-        levels = kWideHbm ? 3 * c->bvh_depth4 + 2 : c->bvh_depth + 2;  // 4-wide: up to three pending entries per level
+        levels = kWideHbm ? 3 * c->bvh_depth4 + 3 : c->bvh_depth + 3;  // the sentinel at level 0; 4-wide: up to three pending entries per level
         p.klds = std::min(levels, kStackLdsLevels);
     }
     p.overflow_levels = levels - p.klds;

@@ -476,13 +476,19 @@ TRG_DEV void raygen(const trg_uniforms &u, uint32_t x, uint32_t y, uint32_t hidx
     float r0, r1;
     halton_pixel<TAB>(hidx, r0, r1, htab);
     const float px = (float)x + r0, py = (float)y + r1;
-    float uvx = div_fast(px, (float)u.width), uvy = div_fast(py, (float)u.height);
+    // Opaque copies: 1/width, 1/height and the four 0*m products below are wave-uniform and loop-invariant, so LICM hoists them
+    // out of the megakernel's frame loop -- as VALU results they then sit in six VGPRs across every traversal and were
+    // spilled to scratch at 8 waves/SIMD.  Recomputing them per frame is eight instructions.  Same arithmetic, same bits.
+    uint32_t wv = u.width, hv = u.height;
+    float zero = 0.0f;
+    asm volatile("" : "+v"(wv), "+v"(hv), "+v"(zero));
+    float uvx = div_fast(px, (float)wv), uvy = div_fast(py, (float)hv);
     uvx = uvx * 2.0f - 1.0f;
     uvy = uvy * 2.0f - 1.0f;
     const float *m = u.inv_view_proj;
     float w[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) w[j] = uvx * m[j * 4 + 0] + uvy * m[j * 4 + 1] + 0.0f * m[j * 4 + 2] + 1.0f * m[j * 4 + 3];
+    for (int j = 0; j < 4; ++j) w[j] = uvx * m[j * 4 + 0] + uvy * m[j * 4 + 1] + zero * m[j * 4 + 2] + 1.0f * m[j * 4 + 3];
     const V3 cam = mk(u.cam_pos[0], u.cam_pos[1], u.cam_pos[2]);
     const V3 world = mk(div_fast(w[0], w[3]), div_fast(w[1], w[3]), div_fast(w[2], w[3]));
     org = cam;
@@ -527,15 +533,19 @@ TRG_DEV bool tri_test(const v4f a, const v4f b, const v4f c, V3 o, V3 d, float t
 // Without overflow it IS the LDS byte address of the next free entry (unit = BLOCK ints), so push and pop are a bare
 // ds_write_b32 / ds_read_b32 with no address arithmetic; with overflow it is the level index.
 typedef __attribute__((address_space(3))) int lds_int_t;
+constexpr int kNodeDone = (int)0x80000000;  // "traversal finished" marker in the node register (never a valid leaf code)
+// Level 0 of every stack holds a permanent SENTINEL (kNodeDone, written once per thread by init()): a traversal starts with its
+// stack pointer at level 1, and the pop that would underflow returns the sentinel, which ends the traversal -- so pop never tests
+// for an empty stack (two instructions less per pop, and neither the marker nor the stack base has to stay in a VGPR).
 template <int BLOCK, bool OVERFLOW = false>
 struct LdsStackT {
     int *base;         // LDS, already offset by the thread index
     int *gbase;        // global overflow column of this thread (nullptr when unused)
     uint32_t gstride;  // elements between consecutive overflow levels
-    int klds;          // levels held in LDS
+    int klds;          // levels held in LDS (level 0 = the sentinel)
     static constexpr int unit = OVERFLOW ? 1 : BLOCK * 4;
-    TRG_DEV int first() const { return OVERFLOW ? 0 : (int)(uint32_t)(uintptr_t)(lds_int_t *)base; }
-    TRG_DEV bool empty(int sp) const { return sp == first(); }
+    TRG_DEV void init() const { *(lds_int_t *)base = kNodeDone; }
+    TRG_DEV int first() const { return OVERFLOW ? 1 : (int)(uint32_t)(uintptr_t)(lds_int_t *)base + BLOCK * 4; }
     TRG_DEV void push(int sp, int v) {
         if (!OVERFLOW) *(lds_int_t *)(uintptr_t)(uint32_t)sp = v;
         else if (sp < klds) base[sp * BLOCK] = v;
@@ -547,8 +557,6 @@ struct LdsStackT {
         return gbase[(size_t)(sp - klds) * gstride];
     }
 };
-
-constexpr int kNodeDone = (int)0x80000000;  // "traversal finished" marker in the node register (never a valid leaf code)
 
 TRG_DEV uint32_t mbcnt64(uint64_t m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -566,13 +574,18 @@ struct Trav {
     int sx, sy, sz;  // sign-ordered LDS nodes (TRG_TRAV_LDS == 4): byte offset of the slab pair to read per axis
 };
 
+TRG_DEV float clamp_away_from_zero(float v) {
+    const uint32_t b = __float_as_uint(v);
+    const uint32_t mag = b & 0x7fffffffu, tiny = 0x0da24260u;  // 1e-30f
+    return __uint_as_float((b & 0x80000000u) | (mag < tiny ? tiny : mag));
+}
 TRG_DEV void trav_begin(Trav &tv, V3 o, V3 d, float tmax, uint32_t rmask, int sp0, uint32_t node_base = 0u) {
     // Reciprocal direction with zero components pushed to +-1e-30: the slab products stay finite (no
     // inf - inf = NaN whose fmin/fmax would pick the wrong endpoint), and a ray that moves 1e-30 per
     // unit t along an axis is parallel to the slab for every practical purpose.
-    const float dx = fabsf(d.x) < 1e-30f ? copysignf(1e-30f, d.x) : d.x;
-    const float dy = fabsf(d.y) < 1e-30f ? copysignf(1e-30f, d.y) : d.y;
-    const float dz = fabsf(d.z) < 1e-30f ? copysignf(1e-30f, d.z) : d.z;
+    // |d| < 1e-30 ? copysign(1e-30, d) : d, written on the bit patterns (the magnitudes of non-negative floats order like
+    // unsigned integers) so that every constant is a VOP2 literal instead of a VGPR the inner loops would have to carry
+    const float dx = clamp_away_from_zero(d.x), dy = clamp_away_from_zero(d.y), dz = clamp_away_from_zero(d.z);
     tv.o = o; tv.d = d;
     tv.idx = rcp_fast(dx); tv.idy = rcp_fast(dy); tv.idz = rcp_fast(dz);
     tv.oix = o.x * tv.idx; tv.oiy = o.y * tv.idy; tv.oiz = o.z * tv.idz;
@@ -612,10 +625,8 @@ TRG_DEV void trav_node_math(const v4f n0, const v4f n1, const v4f n2, const v4f 
     int sp = tv.sp + (both ? STK::unit : 0);
     int next = nearc;
     if (none) {
-        const bool empty = stk.empty(sp);
-        sp -= empty ? 0 : STK::unit;
-        const int popped = stk.pop(sp);  // when empty this reads level 0 (in bounds) and is discarded
-        next = empty ? kNodeDone : popped;
+        sp -= STK::unit;
+        next = stk.pop(sp);  // the sentinel at level 0 when nothing is pending
     }
     tv.node = next; tv.sp = sp;
 }
@@ -662,10 +673,8 @@ TRG_DEV void trav_node_step_signed(const SceneView &sc, Trav &tv, STK stk, Count
     int sp = tv.sp + (both ? STK::unit : 0);
     int next = nearc;
     if (none) {
-        const bool empty = stk.empty(sp);
-        sp -= empty ? 0 : STK::unit;
-        const int popped = stk.pop(sp);
-        next = empty ? kNodeDone : popped;
+        sp -= STK::unit;
+        next = stk.pop(sp);  // the sentinel at level 0 when nothing is pending
     }
     tv.node = next; tv.sp = sp;
 }
@@ -696,9 +705,10 @@ TRG_DEV bool trav_tri_math(const v4f a, const v4f b, const v4f c, Trav &tv, bool
     return any && ok;
 }
 
-// One leaf: test its 1..8 triangles.  ~node = (first << 3) | (count - 1).  Returns with tv.node = next node or kNodeDone.
+// One leaf: test its 1..8 triangles.  ~node = (first << 3) | (count - 1).  Pops the next node (the sentinel kNodeDone when
+// nothing is pending) and returns true when an any-hit query is satisfied -- the caller then stops whatever was popped.
 template <bool COUNT, int BLOCK, typename STK>
-TRG_DEV void trav_leaf_step(const SceneView &sc, Trav &tv, bool any, STK stk, Counters &cnt) {
+TRG_DEV bool trav_leaf_step(const SceneView &sc, Trav &tv, bool any, STK stk, Counters &cnt) {
     const uint32_t code = (uint32_t)~tv.node;
     const uint32_t first = code >> 3, count = (code & 7u) + 1u;
     bool stop = false;
@@ -711,11 +721,10 @@ TRG_DEV void trav_leaf_step(const SceneView &sc, Trav &tv, bool any, STK stk, Co
             stop = trav_tri_math<COUNT>(t2[0], t2[1], t2[2], tv, any, cnt);
         }
     }
-    const bool empty = stk.empty(tv.sp);
-    int sp = tv.sp - ((stop || empty) ? 0 : STK::unit);
-    const int popped = stk.pop(sp);
-    tv.node = (stop || empty) ? kNodeDone : popped;
+    const int sp = tv.sp - STK::unit;
+    tv.node = stk.pop(sp);
     tv.sp = sp;
+    return stop;
 }
 
 // ---- 4-wide nodes (scenes in HBM): 128-byte node, four child boxes in SoA form (bvh_build.h) ----
@@ -771,10 +780,8 @@ TRG_DEV void trav_node4_math(const v4f q0, const v4f q1, const v4f q2, const v4f
     sp += h2 ? STK::unit : 0;
     int next = c0;
     if (h0) {
-        const bool empty = stk.empty(sp);
-        sp -= empty ? 0 : STK::unit;
-        const int popped = stk.pop(sp);
-        next = empty ? kNodeDone : popped;
+        sp -= STK::unit;
+        next = stk.pop(sp);  // the sentinel at level 0 when nothing is pending
     }
     tv.node = next; tv.sp = sp;
 }
@@ -794,12 +801,11 @@ TRG_DEV void trav_step_wide(const SceneView &sc, Trav &tv, bool any, STK stk, Co
     } else {
         const bool stop = trav_tri_math<COUNT>(q0, q1, q2, tv, any, cnt);
         const bool more = left != 0u;
-        const bool empty = stk.empty(tv.sp);
-        const bool do_pop = !stop && !more && !empty;
+        const bool do_pop = !stop && !more;
         const int sp = tv.sp - (do_pop ? STK::unit : 0);
-        const int popped = stk.pop(sp);
+        const int popped = stk.pop(sp);  // the sentinel at level 0 when nothing is pending
         const int advanced = ~(int)(((first + 1u) << 3) | (left - 1u));
-        tv.node = stop ? kNodeDone : (more ? advanced : (empty ? kNodeDone : popped));
+        tv.node = stop ? kNodeDone : (more ? advanced : popped);
         tv.sp = sp;
     }
 }
@@ -822,12 +828,11 @@ TRG_DEV void trav_step_unified(const SceneView &sc, Trav &tv, bool any, STK stk,
     } else {
         const bool stop = trav_tri_math<COUNT>(q0, q1, q2, tv, any, cnt);
         const bool more = left != 0u;
-        const bool empty = stk.empty(tv.sp);
-        const bool do_pop = !stop && !more && !empty;
+        const bool do_pop = !stop && !more;
         const int sp = tv.sp - (do_pop ? STK::unit : 0);
-        const int popped = stk.pop(sp);
+        const int popped = stk.pop(sp);  // the sentinel at level 0 when nothing is pending
         const int advanced = ~(int)(((first + 1u) << 3) | (left - 1u));
-        tv.node = stop ? kNodeDone : (more ? advanced : (empty ? kNodeDone : popped));
+        tv.node = stop ? kNodeDone : (more ? advanced : popped);
         tv.sp = sp;
     }
 }
@@ -868,7 +873,7 @@ TRG_DEV bool traverse(const SceneView &sc, V3 o, V3 d, float tmax_ray, uint32_t 
         for (;;) {
             while (tv.node >= 0) trav_node_step<COUNT, BLOCK, mode == 4>(sc, tv, stk, cnt);
             if (tv.node == kNodeDone) break;
-            trav_leaf_step<COUNT, BLOCK>(sc, tv, ANY, stk, cnt);
+            if (trav_leaf_step<COUNT, BLOCK>(sc, tv, ANY, stk, cnt)) break;   // any-hit satisfied
             if (tv.node == kNodeDone) break;
         }
     }
@@ -899,7 +904,7 @@ TRG_DEV void traverse_pair(const SceneView &sc, V3 org, bool has_shadow, V3 sdir
             trav_step_unified<COUNT, BLOCK>(sc, tv, any, stk, cnt);
         } else {
             while (tv.node >= 0) trav_node_step<COUNT, BLOCK, mode == 4>(sc, tv, stk, cnt);
-            if (tv.node != kNodeDone) trav_leaf_step<COUNT, BLOCK>(sc, tv, any, stk, cnt);
+            if (tv.node != kNodeDone && trav_leaf_step<COUNT, BLOCK>(sc, tv, any, stk, cnt)) tv.node = kNodeDone;
         }
         if (tv.node == kNodeDone) {
             if (phase == 0) {
@@ -983,7 +988,7 @@ TRG_DEV void trace_queue(const SceneView &sc, const PoolView pv, const unsigned 
                 } else {
                     while (tv.node >= 0) trav_node_step<COUNT, BLOCK, mode == 4>(sc, tv, stk, cnt);
                     if (tv.node == kNodeDone) break;
-                    trav_leaf_step<COUNT, BLOCK>(sc, tv, any, stk, cnt);
+                    if (trav_leaf_step<COUNT, BLOCK>(sc, tv, any, stk, cnt)) tv.node = kNodeDone;
                 }
                 if (tv.node == kNodeDone) break;
                 // enough lanes of this wavefront have run dry: let them refill (state stays in registers)

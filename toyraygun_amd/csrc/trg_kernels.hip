@@ -47,6 +47,13 @@ TRG_DEV SceneView scene_view(const trg::SceneDesc &sc, unsigned char *smem) {
     return v;
 }
 
+// lane index without touching threadIdx: v_mbcnt of an all-ones mask.  The opaque form is not hoisted or CSE'd.
+TRG_DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+TRG_DEV uint32_t lane_id_opaque() {
+    uint32_t l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 TRG_DEV uint32_t wave_sum(uint32_t v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -56,19 +63,19 @@ TRG_DEV uint32_t wave_sum(uint32_t v) {
 // The shading event of one bounce (primaryHit, Raytracing.metal:115-215) for the lane's current ray and its
 // nearest-hit record: updates throughput / radiance / path state, moves the ray to the continuation ray and
 // returns the shadow ray to trace.  Shared by both loop shapes of render_kernel.
-struct ShadeOut { bool want_shadow, want_next; V3 sdir, scol; float smax; };
+struct ShadeOut { bool want_shadow, want_next, shaded; V3 sdir, scol; float smax; };
 template <bool TAB = false>
 TRG_DEV ShadeOut shade_event(const trg_uniforms &u, const SceneView &sc, const Hit &h, bool found, uint32_t b, bool last, uint32_t hidx,
-                             V3 &o, V3 &d, V3 &thr, V3 &rad, uint32_t &rmask, bool &active, V3 light_color, uint32_t &n_shaded) {
+                             V3 &o, V3 &d, V3 &thr, V3 &rad, uint32_t &rmask, bool &active, V3 light_color) {
     ShadeOut out;
-    out.want_shadow = false; out.want_next = false; out.sdir = mk(0.0f, 0.0f, 1.0f); out.scol = mk(0.0f, 0.0f, 0.0f); out.smax = -1.0f;
+    out.want_shadow = false; out.want_next = false; out.shaded = false; out.sdir = mk(0.0f, 0.0f, 1.0f); out.scol = mk(0.0f, 0.0f, 0.0f); out.smax = -1.0f;
     if (!found) {
         active = false;  // Raytracing.metal:139-144
         return out;
     }
     const uint32_t mat = sc.mats[h.prim];
     if (mat == TRG_MATERIAL_DEFAULT) {
-        n_shaded++;
+        out.shaded = true;
         // Raytracing.metal:150-199
         const V3 P = o + d * h.t;
         const float cx = 1.0f - h.u - h.v, cy = h.u;  // weights of vertex 0, 1
@@ -106,11 +113,13 @@ TRG_DEV ShadeOut shade_event(const trg_uniforms &u, const SceneView &sc, const H
 // One path: raygen, then `bounces` x [nearest hit, shading event, shadow ray] -- the radiance this frame adds to the
 // pixel's texel (what the reference's render target holds before accumulate).  Shared by the frame-serial and the
 // frame-parallel megakernels.
+// Ray counters are WAVE-level scalars: every count is taken at a wave-uniform point as popcount(ballot(predicate)), so the four
+// counters live in SGPRs instead of four VGPRs per lane (the per-lane form cost 4 of the 64 registers of the 8-waves/SIMD build).
 struct PathCounters { uint32_t primary, bounce, shadow, shaded; };
+TRG_DEV uint32_t wave_count(bool pred) { return (uint32_t)__popcll(__ballot(pred)); }
 template <bool LDS_SCENE, bool COUNT, typename STK>
 TRG_DEV V3 path_radiance(const trg::RenderParams &p, const SceneView &sc, STK stk, uint32_t x, uint32_t y, uint32_t hidx, bool valid,
                          V3 light_color, PathCounters &pc, Counters &cnt) {
-    uint32_t &n_primary = pc.primary, &n_bounce = pc.bounce, &n_shadow = pc.shadow, &n_shaded = pc.shaded;
     V3 o, d;
     constexpr bool TAB = LDS_SCENE && !TRG_STRICT && TRG_HALTON_TABLES;  // Halton group tables staged with the scene
     raygen<TAB>(p.u, x, y, hidx, o, d, sc.htab);
@@ -118,7 +127,7 @@ TRG_DEV V3 path_radiance(const trg::RenderParams &p, const SceneView &sc, STK st
     V3 rad = mk(0.0f, 0.0f, 0.0f);  // the render target texel of this frame
     uint32_t rmask = 3u;            // RAY_MASK_PRIMARY
     bool active = valid;
-    if (active) n_primary++;
+    pc.primary += wave_count(active);
 
     if (LDS_SCENE) {
         // LDS-resident scene: per bounce, a wave-synchronous nearest-hit trace, the shading event, a
@@ -126,18 +135,20 @@ TRG_DEV V3 path_radiance(const trg::RenderParams &p, const SceneView &sc, STK st
         for (uint32_t b = 0; b < p.bounces; ++b) {
             if (__ballot(active) == 0ull) break;  // whole wavefront terminated
             const bool last = (b + 1u == p.bounces);  // wave-uniform
+            if (b > 0) pc.bounce += wave_count(active);
+            ShadeOut so; so.want_shadow = false; so.shaded = false;
             if (active) {
-                if (b > 0) n_bounce++;
                 Hit h;
                 const bool found = traverse<false, COUNT, trg::kBlock, false>(sc, o, d, INFINITY, rmask, h, stk, cnt);
-                const ShadeOut so = shade_event<TAB>(p.u, sc, h, found, b, last, hidx, o, d, thr, rad, rmask, active, light_color, n_shaded);
+                so = shade_event<TAB>(p.u, sc, h, found, b, last, hidx, o, d, thr, rad, rmask, active, light_color);
                 if (so.want_shadow) {
-                    n_shadow++;
                     Hit sh;
                     const bool occluded = traverse<true, COUNT, trg::kBlock, false>(sc, o, so.sdir, so.smax, 1u, sh, stk, cnt);
                     if (!occluded) rad = rad + so.scol;  // Raytracing.metal:240-241
                 }
             }
+            pc.shaded += wave_count(so.shaded);
+            pc.shadow += wave_count(so.want_shadow);
         }
     } else {
         // HBM-resident scene: the primary ray alone; afterwards every shading event yields a (shadow ray,
@@ -150,16 +161,15 @@ TRG_DEV V3 path_radiance(const trg::RenderParams &p, const SceneView &sc, STK st
         for (uint32_t b = 0; b < p.bounces; ++b) {
             if (__ballot(active) == 0ull) break;
             const bool last = (b + 1u == p.bounces);
-            ShadeOut so; so.want_shadow = false; so.want_next = false; so.sdir = mk(0.0f, 0.0f, 1.0f); so.scol = mk(0.0f, 0.0f, 0.0f); so.smax = -1.0f;
-            if (active) so = shade_event<TAB>(p.u, sc, h, found, b, last, hidx, o, d, thr, rad, rmask, active, light_color, n_shaded);
+            ShadeOut so; so.want_shadow = false; so.want_next = false; so.shaded = false; so.sdir = mk(0.0f, 0.0f, 1.0f); so.scol = mk(0.0f, 0.0f, 0.0f); so.smax = -1.0f;
+            if (active) so = shade_event<TAB>(p.u, sc, h, found, b, last, hidx, o, d, thr, rad, rmask, active, light_color);
+            pc.shaded += wave_count(so.shaded);
+            pc.shadow += wave_count(so.want_shadow);
+            pc.bounce += wave_count(so.want_next);
             if (__ballot(so.want_shadow || so.want_next) != 0ull) {
                 bool occluded = false;
                 traverse_pair<COUNT, trg::kBlock, true>(sc, o, so.want_shadow, so.sdir, so.smax, so.want_next, d, rmask, occluded, h, found, stk, cnt);
-                if (so.want_shadow) {
-                    n_shadow++;
-                    if (!occluded) rad = rad + so.scol;
-                }
-                if (so.want_next) n_bounce++;
+                if (so.want_shadow && !occluded) rad = rad + so.scol;
             }
         }
     }
@@ -184,10 +194,13 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES : TRG_EXP_WA
     stk.klds = (int)p.stack.klds;
     stk.gstride = gridDim.x * trg::kBlock;
     stk.gbase = p.stack.overflow ? p.stack.overflow + (size_t)blockIdx.x * trg::kBlock + threadIdx.x : nullptr;
+    stk.init();  // the sentinel at level 0 of this thread's stack column
 
     // workgroup -> 16x16 tile, wavefront -> 8x8 sub-tile, lane -> pixel (8 consecutive pixels of a row
     // per 8 lanes: each wavefront writes eight 128-byte row segments)
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // The wavefront index is wave-uniform (an SGPR) and the lane index is re-read with v_mbcnt wherever it is needed, so that
+    // pixel coordinates, the pixel index and threadIdx do not occupy VGPRs across the frame loop (they used to be spilled).
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // workgroup -> tile: image columns from the centre outwards (rows inner).  Any bijection is correct; this one
     // starts the tiles a camera usually points at first, so the tail of the launch is made of the cheap
     // edge tiles (C2: the 16:9 side bars) instead of leaving CUs idle behind a few expensive ones (+9 %).
@@ -195,23 +208,34 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES : TRG_EXP_WA
     const uint32_t crank = blockIdx.x / tiles_y, by = blockIdx.x % tiles_y;
     const uint32_t cleft = (p.tiles_x - 1u) / 2u;
     const uint32_t bx = (crank & 1u) ? cleft + 1u + crank / 2u : cleft - crank / 2u;
-    const uint32_t x = bx * trg::kTileW + (wave % (trg::kTileW / 8)) * 8 + (lane & 7);
-    const uint32_t y = p.row0 + by * trg::kTileH + (wave / (trg::kTileW / 8)) * 8 + (lane >> 3);
-    const bool valid = (x < p.u.width) && (y < p.row0 + p.rows) && (y < p.u.height);
-    const uint32_t pix = y * p.u.width + x;
+    const uint32_t x0 = bx * trg::kTileW + (wave % (trg::kTileW / 8)) * 8;           // wave-uniform
+    const uint32_t y0 = p.row0 + by * trg::kTileH + (wave / (trg::kTileW / 8)) * 8;  // wave-uniform
+    bool valid;
+    uint32_t offset = 0u;
+    V3 acc = mk(0.0f, 0.0f, 0.0f);
+    v4f *accum = reinterpret_cast<v4f *>(p.accum);
+    {
+        const uint32_t lane = lane_id();
+        const uint32_t x = x0 + (lane & 7), y = y0 + (lane >> 3);
+        valid = (x < p.u.width) && (y < p.row0 + p.rows) && (y < p.u.height);
+        const uint32_t pix = y * p.u.width + x;
+        if (valid) offset = p.offsets[pix];
+        if (valid && p.frame_begin > 0) { const v4f a = accum[pix]; acc = mk(a.x, a.y, a.z); }
+    }
 
     PathCounters pc; pc.primary = 0; pc.bounce = 0; pc.shadow = 0; pc.shaded = 0;
     Counters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.wnodes = 0; cnt.wtris = 0;
-
-    const uint32_t offset = valid ? p.offsets[pix] : 0u;
-    v4f *accum = reinterpret_cast<v4f *>(p.accum);
-    V3 acc = mk(0.0f, 0.0f, 0.0f);
-    if (valid && p.frame_begin > 0) { const v4f a = accum[pix]; acc = mk(a.x, a.y, a.z); }
     const V3 light_color = mk(p.u.light_color[0], p.u.light_color[1], p.u.light_color[2]);
 
     for (uint32_t f = p.frame_begin; f < p.frame_begin + p.spp; ++f) {
         const uint32_t hidx = offset + f;  // Raytracing.metal:67: offset + uniforms.frameIndex (wraps mod 2^32)
-        const V3 rad = path_radiance<LDS_SCENE, COUNT>(p, sc, stk, x, y, hidx, valid, light_color, pc, cnt);
+        // the lane index is re-read every frame (an opaque v_mbcnt pair): otherwise LICM hoists the pixel coordinates and
+        // raygen's per-pixel products out of the frame loop, values that then live in VGPRs across every traversal of every
+        // frame and were spilled to scratch at 8 waves/SIMD (profiles/r01: 13 scratch stores per pixel = the 3.4x write
+        // amplification, 8 scratch reloads per frame).  Recomputing them costs a dozen VALU instructions per frame.
+        const uint32_t lane_f = lane_id_opaque();
+        const uint32_t xf = x0 + (lane_f & 7), yf = y0 + (lane_f >> 3);
+        const V3 rad = path_radiance<LDS_SCENE, COUNT>(p, sc, stk, xf, yf, hidx, valid, light_color, pc, cnt);
         // Accumulate.metal:19-39
         if (f == 0) {
             acc = rad;
@@ -222,9 +246,11 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES : TRG_EXP_WA
             acc = mk(c.x / f1, c.y / f1, c.z / f1);
         }
     }
+    const uint32_t lane = lane_id_opaque();
     if (valid) {
+        const uint32_t x = x0 + (lane & 7), y = y0 + (lane >> 3);
         v4f outv; outv.x = acc.x; outv.y = acc.y; outv.z = acc.z; outv.w = 1.0f;
-        accum[pix] = outv;
+        accum[y * p.u.width + x] = outv;
     }
 
     // ray counters: wavefront reduce -> workgroup reduce in LDS -> one atomic per counter per workgroup,
@@ -234,12 +260,12 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES : TRG_EXP_WA
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         if (!COUNT && k >= 4) break;
-        const uint32_t s = wave_sum(vals[k]);
+        const uint32_t s = k < 4 ? vals[k] : wave_sum(vals[k]);   // the ray counters are already wave totals
         if (lane == 0) red[wave * 8 + k] = s;
     }
     __syncthreads();
-    if (threadIdx.x < (COUNT ? 8 : 4)) {
-        const uint32_t k = threadIdx.x;
+    if (wave == 0 && lane < (COUNT ? 8u : 4u)) {
+        const uint32_t k = lane;
         unsigned long long s = 0;
         for (int wv = 0; wv < trg::kWaves; ++wv) s += red[wv * 8 + k];
         if (s) atomicAdd(&p.counters[(blockIdx.x % trg::kCounterSlots) * trg::kCounterWords + k], s);
@@ -269,6 +295,7 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES_FP : TRG_EXP
     stk.klds = (int)p.stack.klds;
     stk.gstride = gridDim.x * trg::kBlock;
     stk.gbase = p.stack.overflow ? p.stack.overflow + (size_t)blockIdx.x * trg::kBlock + threadIdx.x : nullptr;
+    stk.init();  // the sentinel at level 0 of this thread's stack column
 
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t F = p.fsplit, subt = trg::kWaves / F;   // frame lanes, sub-tiles per workgroup (F in {2,4})
@@ -333,7 +360,7 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES_FP : TRG_EXP
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         if (!COUNT && k >= 4) break;
-        const uint32_t s = wave_sum(vals[k]);
+        const uint32_t s = k < 4 ? vals[k] : wave_sum(vals[k]);   // the ray counters are already wave totals
         if (lane == 0) red[wave * 8 + k] = s;
     }
     __syncthreads();
@@ -366,6 +393,7 @@ __global__ __launch_bounds__(trg::kBlock) void render_pool_kernel(const trg::Ren
     stk.klds = (int)p.stack.klds;
     stk.gstride = gridDim.x * trg::kBlock;
     stk.gbase = p.stack.overflow ? p.stack.overflow + (size_t)blockIdx.x * trg::kBlock + threadIdx.x : nullptr;
+    stk.init();  // the sentinel at level 0 of this thread's stack column
     constexpr int P = trg::kBlock * S;
     PoolView pv;
     pv.R0 = reinterpret_cast<v4f *>(smem + p.pool_off);
@@ -543,6 +571,7 @@ __global__ __launch_bounds__(trg::kBlock) void trace_kernel(const trg::TracePara
     stk.klds = (int)p.stack.klds;
     stk.gstride = gridDim.x * trg::kBlock;
     stk.gbase = p.stack.overflow ? p.stack.overflow + (size_t)blockIdx.x * trg::kBlock + threadIdx.x : nullptr;
+    stk.init();  // the sentinel at level 0 of this thread's stack column
     const uint32_t i = blockIdx.x * trg::kBlock + threadIdx.x;
     if (i >= p.n) return;
     const trg_ray r = p.rays[i];
