@@ -98,9 +98,9 @@ static bool plan_scene_layout(uint64_t n_nodes, uint32_t node_bytes, uint64_t nt
     return true;
 }
 
-constexpr uint32_t kStackLdsLevels = 16;  // HBM scenes: stack levels kept in LDS (deeper ones spill to global scratch)
+constexpr uint32_t kStackLdsLevels = TRG_STACK_LDS_LEVELS;  // HBM scenes: stack levels kept in LDS (deeper ones spill to global scratch)
 
-struct LdsPlan { bool lds_scene; uint32_t stack_off, red_off, pool_off, total, klds, overflow_levels; };
+struct LdsPlan { bool lds_scene; uint32_t stack_off, red_off, pool_off, acc_off, total, klds, overflow_levels; };
 static bool plan_lds_as(const trg_ctx *c, LdsPlan &p, bool lds_scene, bool pool, uint32_t fp_slots, uint32_t &limit) {
     p.lds_scene = lds_scene;
     uint32_t levels;
@@ -122,6 +122,10 @@ static bool plan_lds_as(const trg_ctx *c, LdsPlan &p, bool lds_scene, bool pool,
         p.total = p.pool_off + slots * kPoolSlotBytes + 4u * slots * 2u + 16u;  // slots, two lists of 2P u16, counters
     }
     if (fp_slots) p.total = p.pool_off + fp_slots * (uint32_t)kBlock * 12u;  // render_fp_kernel: parked radiances, 3 floats x 256 pixel-frames per slot group
+    // render_kernel on an HBM-resident scene parks the running average in LDS between frames (three VGPRs less across every
+    // traversal; an LDS-resident scene has neither the room -- 8 workgroups of 20 KB per CU -- nor the need: it is spill-free)
+    p.acc_off = 0;
+    if (!p.lds_scene && !pool && !fp_slots) { p.acc_off = p.total; p.total += (uint32_t)kBlock * (TRG_PARK_PATH ? 36u : 12u); }
     limit = (pool || fp_slots) ? 160u * 1024u : 64u * 1024u;  // above 64 KB the launcher opts in per kernel
     return p.total <= limit;
 }
@@ -440,7 +444,7 @@ int trg_render(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces,
     p.counters = c->counters;
     p.frame_begin = frame_begin; p.spp = spp; p.bounces = bounces; p.row0 = row0; p.rows = rows;
     p.stack_off = plan.stack_off; p.red_off = plan.red_off; p.pool_off = plan.pool_off;
-    p.fsplit = fsplit; p.fp_rounds = fp_rounds;
+    p.fsplit = fsplit; p.fp_rounds = fp_rounds; p.acc_off = plan.acc_off;
     // workgroup tile: 16x16 pixels, or (4/fsplit) 8x8 sub-tiles side by side when the frames are split over waves
     const uint32_t tile_w = fsplit > 1 ? 8u * (kWaves / fsplit) : (uint32_t)kTileW, tile_h = fsplit > 1 ? 8u : (uint32_t)kTileH;
     p.tiles_x = (c->w + tile_w - 1) / tile_w;

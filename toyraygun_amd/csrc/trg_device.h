@@ -539,22 +539,27 @@ constexpr int kNodeDone = (int)0x80000000;  // "traversal finished" marker in th
 // for an empty stack (two instructions less per pop, and neither the marker nor the stack base has to stay in a VGPR).
 template <int BLOCK, bool OVERFLOW = false>
 struct LdsStackT {
-    int *base;         // LDS, already offset by the thread index
-    int *gbase;        // global overflow column of this thread (nullptr when unused)
+    uint32_t lds;      // LDS byte address of level 0 of this thread's column (already offset by the thread index)
+    int *overflow;     // global scratch for the levels beyond klds (wave-uniform: stays in SGPRs), or nullptr
+    uint32_t gcol;     // this thread's column in the scratch: workgroup * BLOCK + thread
     uint32_t gstride;  // elements between consecutive overflow levels
     int klds;          // levels held in LDS (level 0 = the sentinel)
     static constexpr int unit = OVERFLOW ? 1 : BLOCK * 4;
-    TRG_DEV void init() const { *(lds_int_t *)base = kNodeDone; }
-    TRG_DEV int first() const { return OVERFLOW ? 1 : (int)(uint32_t)(uintptr_t)(lds_int_t *)base + BLOCK * 4; }
+    TRG_DEV void set(unsigned char *smem, uint32_t stack_off, int *ovf, uint32_t klds_) {
+        lds = (uint32_t)(uintptr_t)(lds_int_t *)(reinterpret_cast<int *>(smem + stack_off) + threadIdx.x);
+        overflow = ovf; gcol = blockIdx.x * BLOCK + threadIdx.x; gstride = gridDim.x * BLOCK; klds = (int)klds_;
+        *(lds_int_t *)(uintptr_t)lds = kNodeDone;   // the sentinel at level 0
+    }
+    TRG_DEV int first() const { return OVERFLOW ? 1 : (int)lds + BLOCK * 4; }
     TRG_DEV void push(int sp, int v) {
         if (!OVERFLOW) *(lds_int_t *)(uintptr_t)(uint32_t)sp = v;
-        else if (sp < klds) base[sp * BLOCK] = v;
-        else gbase[(size_t)(sp - klds) * gstride] = v;
+        else if (sp < klds) *(lds_int_t *)(uintptr_t)(lds + (uint32_t)sp * (BLOCK * 4u)) = v;
+        else overflow[(size_t)((uint32_t)(sp - klds) * gstride + gcol)] = v;
     }
     TRG_DEV int pop(int sp) {
         if (!OVERFLOW) return *(lds_int_t *)(uintptr_t)(uint32_t)sp;
-        if (sp < klds) return base[sp * BLOCK];
-        return gbase[(size_t)(sp - klds) * gstride];
+        if (sp < klds) return *(lds_int_t *)(uintptr_t)(lds + (uint32_t)sp * (BLOCK * 4u));
+        return overflow[(size_t)((uint32_t)(sp - klds) * gstride + gcol)];
     }
 };
 

@@ -20,6 +20,14 @@ static_assert(kBlock == 64 || kBlock == 128 || kBlock == 256, "workgroup must be
 constexpr int kCounterSlots = 64;  // ray counters are spread over 64 slots to avoid same-address atomics
 constexpr int kCounterWords = 8;   // primary, bounce, shadow, shaded, node_fetches, tri_tests, 2 spare
 constexpr uint32_t kMaxLdsScene = 40u * 1024u;  // scenes up to this size are staged in LDS per workgroup
+// render_kernel on an HBM-resident scene: park throughput + radiance in LDS while a ray pair is traced (6 floats per thread next
+// to the 3 of the running average), and keep this many traversal-stack levels in LDS (deeper ones go to global scratch)
+#ifndef TRG_PARK_PATH
+#define TRG_PARK_PATH 1
+#endif
+#ifndef TRG_STACK_LDS_LEVELS
+#define TRG_STACK_LDS_LEVELS 12
+#endif
 #ifndef TRG_POOL_S
 #define TRG_POOL_S 2
 #endif
@@ -54,6 +62,7 @@ struct RenderParams {
     uint32_t red_off;              // byte offset of the counter-reduction scratch in dynamic LDS
     uint32_t pool_off;             // render_pool_kernel: byte offset of the path pool (slots, lists, counters);
                                    // render_fp_kernel: byte offset of the parked per-frame radiances
+    uint32_t acc_off;              // render_kernel on an HBM-resident scene: byte offset of the parked running average (3 x kBlock floats)
     uint32_t fsplit, fp_rounds;    // render_fp_kernel: frame lanes per workgroup (2 or 4), rounds parked per fold
     StackDesc stack;
 };

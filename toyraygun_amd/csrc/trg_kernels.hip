@@ -117,9 +117,10 @@ TRG_DEV ShadeOut shade_event(const trg_uniforms &u, const SceneView &sc, const H
 // counters live in SGPRs instead of four VGPRs per lane (the per-lane form cost 4 of the 64 registers of the 8-waves/SIMD build).
 struct PathCounters { uint32_t primary, bounce, shadow, shaded; };
 TRG_DEV uint32_t wave_count(bool pred) { return (uint32_t)__popcll(__ballot(pred)); }
+typedef __attribute__((address_space(3))) float lds_float_t;
 template <bool LDS_SCENE, bool COUNT, typename STK>
 TRG_DEV V3 path_radiance(const trg::RenderParams &p, const SceneView &sc, STK stk, uint32_t x, uint32_t y, uint32_t hidx, bool valid,
-                         V3 light_color, PathCounters &pc, Counters &cnt) {
+                         V3 light_color, PathCounters &pc, Counters &cnt, lds_float_t *path_park = nullptr) {
     V3 o, d;
     constexpr bool TAB = LDS_SCENE && !TRG_STRICT && TRG_HALTON_TABLES;  // Halton group tables staged with the scene
     raygen<TAB>(p.u, x, y, hidx, o, d, sc.htab);
@@ -168,7 +169,17 @@ TRG_DEV V3 path_radiance(const trg::RenderParams &p, const SceneView &sc, STK st
             pc.bounce += wave_count(so.want_next);
             if (__ballot(so.want_shadow || so.want_next) != 0ull) {
                 bool occluded = false;
+                // throughput and radiance are not needed while the pair is traced: parked in LDS ([component][thread]) instead of
+                // being spilled to scratch by the register allocator (6 scratch stores + 6 loads per bounce in profiles/r01)
+                if (path_park) {
+                    path_park[0] = thr.x; path_park[trg::kBlock] = thr.y; path_park[2 * trg::kBlock] = thr.z;
+                    path_park[3 * trg::kBlock] = rad.x; path_park[4 * trg::kBlock] = rad.y; path_park[5 * trg::kBlock] = rad.z;
+                }
                 traverse_pair<COUNT, trg::kBlock, true>(sc, o, so.want_shadow, so.sdir, so.smax, so.want_next, d, rmask, occluded, h, found, stk, cnt);
+                if (path_park) {
+                    thr = mk(path_park[0], path_park[trg::kBlock], path_park[2 * trg::kBlock]);
+                    rad = mk(path_park[3 * trg::kBlock], path_park[4 * trg::kBlock], path_park[5 * trg::kBlock]);
+                }
                 if (so.want_shadow && !occluded) rad = rad + so.scol;
             }
         }
@@ -190,11 +201,7 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES : TRG_EXP_WA
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const SceneView sc = scene_view<LDS_SCENE>(p.sc, smem);
     LdsStackT<trg::kBlock, !LDS_SCENE> stk;  // HBM scenes may spill deep stack levels to global scratch
-    stk.base = reinterpret_cast<int *>(smem + p.stack_off) + threadIdx.x;
-    stk.klds = (int)p.stack.klds;
-    stk.gstride = gridDim.x * trg::kBlock;
-    stk.gbase = p.stack.overflow ? p.stack.overflow + (size_t)blockIdx.x * trg::kBlock + threadIdx.x : nullptr;
-    stk.init();  // the sentinel at level 0 of this thread's stack column
+    stk.set(smem, p.stack_off, p.stack.overflow, p.stack.klds);  // also writes the sentinel at level 0 of this thread's column
 
     // workgroup -> 16x16 tile, wavefront -> 8x8 sub-tile, lane -> pixel (8 consecutive pixels of a row
     // per 8 lanes: each wavefront writes eight 128-byte row segments)
@@ -212,8 +219,13 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES : TRG_EXP_WA
     const uint32_t y0 = p.row0 + by * trg::kTileH + (wave / (trg::kTileW / 8)) * 8;  // wave-uniform
     bool valid;
     uint32_t offset = 0u;
-    V3 acc = mk(0.0f, 0.0f, 0.0f);
     v4f *accum = reinterpret_cast<v4f *>(p.accum);
+    // The running average of the pixel: in registers for an LDS-resident scene; PARKED IN LDS between frames for an HBM-resident
+    // one (its traversal needs the registers, and its LDS holds only the stacks): [component][thread], conflict-free.
+    constexpr bool PARK = !LDS_SCENE;
+    lds_float_t *park = (lds_float_t *)(reinterpret_cast<float *>(smem + p.acc_off) + threadIdx.x);
+    lds_float_t *path_park = (PARK && TRG_PARK_PATH) ? park + 3 * trg::kBlock : nullptr;
+    V3 acc = mk(0.0f, 0.0f, 0.0f);
     {
         const uint32_t lane = lane_id();
         const uint32_t x = x0 + (lane & 7), y = y0 + (lane >> 3);
@@ -221,6 +233,7 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES : TRG_EXP_WA
         const uint32_t pix = y * p.u.width + x;
         if (valid) offset = p.offsets[pix];
         if (valid && p.frame_begin > 0) { const v4f a = accum[pix]; acc = mk(a.x, a.y, a.z); }
+        if (PARK) { park[0] = acc.x; park[trg::kBlock] = acc.y; park[2 * trg::kBlock] = acc.z; }
     }
 
     PathCounters pc; pc.primary = 0; pc.bounce = 0; pc.shadow = 0; pc.shaded = 0;
@@ -235,7 +248,8 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES : TRG_EXP_WA
         // amplification, 8 scratch reloads per frame).  Recomputing them costs a dozen VALU instructions per frame.
         const uint32_t lane_f = lane_id_opaque();
         const uint32_t xf = x0 + (lane_f & 7), yf = y0 + (lane_f >> 3);
-        const V3 rad = path_radiance<LDS_SCENE, COUNT>(p, sc, stk, xf, yf, hidx, valid, light_color, pc, cnt);
+        const V3 rad = path_radiance<LDS_SCENE, COUNT>(p, sc, stk, xf, yf, hidx, valid, light_color, pc, cnt, path_park);
+        if (PARK) acc = mk(park[0], park[trg::kBlock], park[2 * trg::kBlock]);
         // Accumulate.metal:19-39
         if (f == 0) {
             acc = rad;
@@ -245,10 +259,12 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES : TRG_EXP_WA
             const float f1 = (float)(f + 1u);
             acc = mk(c.x / f1, c.y / f1, c.z / f1);
         }
+        if (PARK) { park[0] = acc.x; park[trg::kBlock] = acc.y; park[2 * trg::kBlock] = acc.z; }
     }
     const uint32_t lane = lane_id_opaque();
     if (valid) {
         const uint32_t x = x0 + (lane & 7), y = y0 + (lane >> 3);
+        if (PARK) acc = mk(park[0], park[trg::kBlock], park[2 * trg::kBlock]);
         v4f outv; outv.x = acc.x; outv.y = acc.y; outv.z = acc.z; outv.w = 1.0f;
         accum[y * p.u.width + x] = outv;
     }
@@ -291,11 +307,7 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES_FP : TRG_EXP
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const SceneView sc = scene_view<LDS_SCENE>(p.sc, smem);
     LdsStackT<trg::kBlock, !LDS_SCENE> stk;
-    stk.base = reinterpret_cast<int *>(smem + p.stack_off) + threadIdx.x;
-    stk.klds = (int)p.stack.klds;
-    stk.gstride = gridDim.x * trg::kBlock;
-    stk.gbase = p.stack.overflow ? p.stack.overflow + (size_t)blockIdx.x * trg::kBlock + threadIdx.x : nullptr;
-    stk.init();  // the sentinel at level 0 of this thread's stack column
+    stk.set(smem, p.stack_off, p.stack.overflow, p.stack.klds);  // also writes the sentinel at level 0 of this thread's column
 
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t F = p.fsplit, subt = trg::kWaves / F;   // frame lanes, sub-tiles per workgroup (F in {2,4})
@@ -389,11 +401,7 @@ __global__ __launch_bounds__(trg::kBlock) void render_pool_kernel(const trg::Ren
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const SceneView sc = scene_view<LDS_SCENE>(p.sc, smem);
     LdsStackT<trg::kBlock, !LDS_SCENE> stk;  // HBM scenes may spill deep stack levels to global scratch
-    stk.base = reinterpret_cast<int *>(smem + p.stack_off) + threadIdx.x;
-    stk.klds = (int)p.stack.klds;
-    stk.gstride = gridDim.x * trg::kBlock;
-    stk.gbase = p.stack.overflow ? p.stack.overflow + (size_t)blockIdx.x * trg::kBlock + threadIdx.x : nullptr;
-    stk.init();  // the sentinel at level 0 of this thread's stack column
+    stk.set(smem, p.stack_off, p.stack.overflow, p.stack.klds);  // also writes the sentinel at level 0 of this thread's column
     constexpr int P = trg::kBlock * S;
     PoolView pv;
     pv.R0 = reinterpret_cast<v4f *>(smem + p.pool_off);
@@ -567,11 +575,7 @@ __global__ __launch_bounds__(trg::kBlock) void trace_kernel(const trg::TracePara
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const SceneView sc = scene_view<LDS_SCENE>(p.sc, smem);
     LdsStackT<trg::kBlock, !LDS_SCENE> stk;  // HBM scenes may spill deep stack levels to global scratch
-    stk.base = reinterpret_cast<int *>(smem + p.stack_off) + threadIdx.x;
-    stk.klds = (int)p.stack.klds;
-    stk.gstride = gridDim.x * trg::kBlock;
-    stk.gbase = p.stack.overflow ? p.stack.overflow + (size_t)blockIdx.x * trg::kBlock + threadIdx.x : nullptr;
-    stk.init();  // the sentinel at level 0 of this thread's stack column
+    stk.set(smem, p.stack_off, p.stack.overflow, p.stack.klds);  // also writes the sentinel at level 0 of this thread's column
     const uint32_t i = blockIdx.x * trg::kBlock + threadIdx.x;
     if (i >= p.n) return;
     const trg_ray r = p.rays[i];
