@@ -97,7 +97,11 @@ enum trg_option {
 };
 enum trg_kernel {
     TRG_KERNEL_DIRECT = 0,    /* one path per lane, rays traced by the lane that owns the pixel */
-    TRG_KERNEL_POOL = 1       /* workgroup path pool: ballot/prefix-compacted ray queues drained by all lanes */
+    TRG_KERNEL_POOL = 1,      /* workgroup path pool: ballot/prefix-compacted ray queues drained by all lanes */
+    TRG_KERNEL_WAVEFRONT = 2, /* rays and path state of a batch of pixel-samples in HBM: a persistent tracer whose lanes pull the next ray of
+                                 a ballot/prefix-compacted queue as soon as they are free + one shading kernel per bounce (same arithmetic
+                                 and results; the schedule for scenes that live in HBM, where ray lengths diverge and paths die) */
+    TRG_KERNEL_AUTO = -1      /* default: TRG_KERNEL_WAVEFRONT for a scene that is traversed from HBM, TRG_KERNEL_DIRECT for one staged in LDS */
 };
 
 /* --- lifetime: replaces MetalRenderer::init / resize (src/engine/Metal/MetalRenderer.mm:282-338,557-574):

@@ -434,7 +434,7 @@ def test_degenerate_scenes(capi, O):
 
 
 # ------------------------------------------------------------------ whole path
-KERNELS = [0, 1]   # TRG_KERNEL_DIRECT, TRG_KERNEL_POOL: two schedules of the same arithmetic
+KERNELS = [0, 1, 2]   # TRG_KERNEL_DIRECT, TRG_KERNEL_POOL, TRG_KERNEL_WAVEFRONT: three schedules of the same arithmetic
 
 
 @pytest.mark.parametrize("kernel", KERNELS)

@@ -34,12 +34,17 @@ struct trg_ctx {
     static constexpr int kScratchSlots = 16;
     int *stack_scratch[kScratchSlots] = {};
     size_t stack_scratch_bytes[kScratchSlots] = {};
+    // wavefront schedule: path state + ray queues of one batch, one set per launch in flight (grow-only)
+    unsigned char *wf_mem[kScratchSlots] = {};
+    size_t wf_bytes[kScratchSlots] = {};
+    int cu_count = 256;
     uint32_t bvh_depth4 = 0, bvh_nodes4 = 0;
     SceneDesc sc{};
     bool scene_loaded = false, have_uniforms = false, have_offsets = false;
     trg_uniforms u{};
     bool opt_strict = false, opt_counters = false, opt_force_global = false, opt_timing = true;
-    int opt_kernel = TRG_KERNEL_DIRECT;
+    int opt_kernel = TRG_KERNEL_AUTO;
+    uint32_t last_kernel = TRG_KERNEL_DIRECT;
     bool opt_gpu_build = false;
     int opt_fsplit = 0;  // 0 = auto
     int opt_in_flight = 1;  // launches of this context the caller keeps in flight (TRG_OPT_LAUNCHES_IN_FLIGHT)
@@ -98,10 +103,13 @@ static bool plan_scene_layout(uint64_t n_nodes, uint32_t node_bytes, uint64_t nt
     return true;
 }
 
-constexpr uint32_t kStackLdsLevels = TRG_STACK_LDS_LEVELS;  // HBM scenes: stack levels kept in LDS (deeper ones spill to global scratch)
+constexpr uint32_t kStackLdsLevels = TRG_STACK_LDS_LEVELS;
+#ifndef TRG_WAVEFRONT_FOR_HBM
+#define TRG_WAVEFRONT_FOR_HBM 0   // what TRG_KERNEL_AUTO picks for a scene traversed from HBM (1 = the wavefront schedule)
+#endif  // HBM scenes: stack levels kept in LDS (deeper ones spill to global scratch)
 
 struct LdsPlan { bool lds_scene; uint32_t stack_off, red_off, pool_off, acc_off, total, klds, overflow_levels; };
-static bool plan_lds_as(const trg_ctx *c, LdsPlan &p, bool lds_scene, bool pool, uint32_t fp_slots, uint32_t &limit) {
+static bool plan_lds_as(const trg_ctx *c, LdsPlan &p, bool lds_scene, bool pool, uint32_t fp_slots, uint32_t &limit, bool park = true) {
     p.lds_scene = lds_scene;
     uint32_t levels;
     if (p.lds_scene) {
@@ -125,16 +133,16 @@ static bool plan_lds_as(const trg_ctx *c, LdsPlan &p, bool lds_scene, bool pool,
     // render_kernel on an HBM-resident scene parks the running average in LDS between frames (three VGPRs less across every
     // traversal; an LDS-resident scene has neither the room -- 8 workgroups of 20 KB per CU -- nor the need: it is spill-free)
     p.acc_off = 0;
-    if (!p.lds_scene && !pool && !fp_slots) { p.acc_off = p.total; p.total += (uint32_t)kBlock * (TRG_PARK_PATH ? 36u : 12u); }
+    if (park && !p.lds_scene && !pool && !fp_slots) { p.acc_off = p.total; p.total += (uint32_t)kBlock * (TRG_PARK_PATH ? 36u : 12u); }
     limit = (pool || fp_slots) ? 160u * 1024u : 64u * 1024u;  // above 64 KB the launcher opts in per kernel
     return p.total <= limit;
 }
-static int plan_lds(trg_ctx *c, LdsPlan &p, bool pool = false, uint32_t fp_slots = 0) {
+static int plan_lds(trg_ctx *c, LdsPlan &p, bool pool = false, uint32_t fp_slots = 0, bool park = true) {
     const bool want_lds = !c->opt_force_global && c->sc.lds_stage_bytes != 0 && c->sc.lds_stage_bytes <= kMaxLdsScene;
     uint32_t limit = 0;
-    if (want_lds && plan_lds_as(c, p, true, pool, fp_slots, limit)) return TRG_OK;
+    if (want_lds && plan_lds_as(c, p, true, pool, fp_slots, limit, park)) return TRG_OK;
     // the scene stays in HBM -- also a small one whose tree is too deep for its traversal stacks to fit in LDS next to it
-    if (plan_lds_as(c, p, false, pool, fp_slots, limit)) return TRG_OK;
+    if (plan_lds_as(c, p, false, pool, fp_slots, limit, park)) return TRG_OK;
     return fail(c, TRG_ERR_RANGE, "BVH depth %u needs %u B of LDS per workgroup (limit %u)", c->bvh_depth, p.total, limit);
 }
 
@@ -174,6 +182,8 @@ static int ensure_stack_scratch(trg_ctx *c, const LdsPlan &plan, uint64_t grid_t
     out.overflow = c->stack_scratch[slot];
     return TRG_OK;
 }
+
+static int render_wavefront(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces, uint32_t row0, uint32_t rows, int slot);
 
 // trg_load_scene with TRG_OPT_GPU_BUILD: LBVH on the device (trg_build.hip), 4-wide nodes only (never LDS-staged).
 static int load_scene_gpu_build(trg_ctx *c, const float *pos, const float *nrm, const float *col, const uint32_t *idx,
@@ -233,6 +243,58 @@ static int load_scene_gpu_build(trg_ctx *c, const float *pos, const float *nrm, 
     return plan_lds(c, plan, c->opt_kernel == TRG_KERNEL_POOL);
 }
 
+// TRG_KERNEL_WAVEFRONT: the frames of the launch in batches of at most kWfMaxPaths pixel-samples; per batch
+//   raygen, bounces x [persistent trace, shade + compacting append], one more trace for the last shadow rays, accumulate.
+// Nothing synchronises with the host: queue lengths stay on the device.
+static int render_wavefront(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces, uint32_t row0, uint32_t rows, int slot) {
+    LdsPlan plan;
+    if (int rc = plan_lds(c, plan, false, 0, false)) return rc;   // the tracer's LDS: scene (if staged) + stacks only
+    const uint64_t npix = (uint64_t)c->w * rows;
+    const uint32_t fb = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(spp, kWfMaxPaths / std::max<uint64_t>(npix, 1)));
+    const uint64_t nb_max = npix * fb;
+    if (nb_max >= (1ull << 31)) return fail(c, TRG_ERR_RANGE, "trg_render: %llu pixels in one band are too many for the wavefront schedule", (unsigned long long)npix);
+    // layout of the slot: 7 float4 arrays, two lists of 2 nb entries, the stage counters
+    const size_t arr = (size_t)nb_max * 16u, lst = (size_t)nb_max * 2u * 4u;
+    const size_t need = 7u * arr + 2u * lst + kWfMaxStages * 16u + 256u;
+    if (need > c->wf_bytes[slot]) {
+        if (c->wf_mem[slot]) { (void)hipDeviceSynchronize(); (void)hipFree(c->wf_mem[slot]); c->wf_mem[slot] = nullptr; c->wf_bytes[slot] = 0; }
+        hipError_t e = hipMalloc((void **)&c->wf_mem[slot], need);
+        if (e != hipSuccess) return fail(c, TRG_ERR_NOMEM, "wavefront buffers hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+        c->wf_bytes[slot] = need;
+    }
+    unsigned char *m = c->wf_mem[slot];
+    WfParams p{};
+    p.u = c->u; p.sc = c->sc; p.offsets = c->offsets; p.accum = c->accum; p.counters = c->counters;
+    p.b.ray_o = m; p.b.ray_d = m + arr; p.b.sh = m + 2 * arr; p.b.hit = m + 3 * arr; p.b.thr = m + 4 * arr; p.b.rad = m + 5 * arr; p.b.scol = m + 6 * arr;
+    p.b.list[0] = reinterpret_cast<uint32_t *>(m + 7 * arr); p.b.list[1] = reinterpret_cast<uint32_t *>(m + 7 * arr + lst);
+    p.b.ctr = reinterpret_cast<uint32_t *>(m + 7 * arr + 2 * lst);
+    p.npix = (uint32_t)npix; p.pix0 = row0 * c->w; p.bounces = bounces;
+    p.stack_off = plan.stack_off;
+    // the persistent tracer: as many workgroups as the chip holds at 8 waves/SIMD; late ones find the queue empty
+    const uint32_t trace_grid = (uint32_t)c->cu_count * 8u;
+    if (int rc = ensure_stack_scratch(c, plan, (uint64_t)trace_grid * kBlock, p.stack, slot)) return rc;
+    const uint32_t shade_grid = (uint32_t)c->cu_count * 8u;
+    const bool strict = c->opt_strict;
+    for (uint32_t f0 = 0; f0 < spp; f0 += fb) {
+        p.frame0 = frame_begin + f0;
+        p.nframes = std::min(fb, spp - f0);
+        p.nb = p.npix * p.nframes;
+        HIPCHK(c, hipMemsetAsync(p.b.ctr, 0, kWfMaxStages * 16u, c->stream));
+        HIPCHK(c, strict ? launch_wf_raygen_strict(p, c->stream) : launch_wf_raygen_fast(p, c->stream));
+        for (uint32_t b = 0; b <= bounces; ++b) {
+            if (bounces == 0) break;
+            p.stage = b; p.bounce = b;
+            HIPCHK(c, strict ? launch_wf_trace_strict(p, plan.lds_scene, c->opt_counters, trace_grid, plan.total, c->stream)
+                             : launch_wf_trace_fast(p, plan.lds_scene, c->opt_counters, trace_grid, plan.total, c->stream));
+            if (b == bounces) break;   // that was the trace of the last bounce's shadow rays
+            HIPCHK(c, strict ? launch_wf_shade_strict(p, shade_grid, c->stream) : launch_wf_shade_fast(p, shade_grid, c->stream));
+        }
+        HIPCHK(c, strict ? launch_wf_accumulate_strict(p, c->stream) : launch_wf_accumulate_fast(p, c->stream));
+    }
+    return TRG_OK;
+}
+
+
 extern "C" {
 
 const char *trg_last_error(trg_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
@@ -253,6 +315,7 @@ int trg_create(trg_ctx **out, int device, uint32_t width, uint32_t height) {
     trg_ctx *c = new (std::nothrow) trg_ctx;
     if (!c) return fail(nullptr, TRG_ERR_NOMEM, "trg_create: out of host memory");
     c->device = device; c->w = width; c->h = height;
+    c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const size_t npix = (size_t)width * height;
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
@@ -278,8 +341,10 @@ void trg_destroy(trg_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     if (c->blob) (void)hipFree(c->blob);
-    for (int k = 0; k < trg_ctx::kScratchSlots; ++k)
+    for (int k = 0; k < trg_ctx::kScratchSlots; ++k) {
         if (c->stack_scratch[k]) (void)hipFree(c->stack_scratch[k]);
+        if (c->wf_mem[k]) (void)hipFree(c->wf_mem[k]);
+    }
     if (c->counters) (void)hipFree(c->counters);
     if (c->offsets) (void)hipFree(c->offsets);
     if (c->accum_own) (void)hipFree(c->accum_own);
@@ -427,7 +492,27 @@ int trg_render(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces,
     if ((uint64_t)frame_begin + spp > 0xFFFFFFFFull) return fail(c, TRG_ERR_INVALID, "trg_render: frame range overflows");
     if (spp == 0 || rows == 0) { c->last_ms = 0.0; return TRG_OK; }
     HIPCHK(c, hipSetDevice(c->device));
-    const bool pool = c->opt_kernel == TRG_KERNEL_POOL;
+    int kernel = c->opt_kernel;
+    if (kernel == TRG_KERNEL_AUTO) {
+        LdsPlan probe;
+        if (int rc = plan_lds(c, probe)) return rc;
+        kernel = (!probe.lds_scene && TRG_WAVEFRONT_FOR_HBM) ? TRG_KERNEL_WAVEFRONT : TRG_KERNEL_DIRECT;
+    }
+    if (kernel == TRG_KERNEL_WAVEFRONT) {
+        if (c->opt_timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+        if (int rc = render_wavefront(c, frame_begin, spp, bounces, row0, rows, (int)(c->launches % (uint32_t)c->opt_in_flight))) return rc;
+        c->renders++; c->launches++; c->last_fsplit = 1; c->last_kernel = TRG_KERNEL_WAVEFRONT;
+        if (c->opt_timing) {
+            HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+            HIPCHK(c, hipEventSynchronize(c->ev1));
+            float ms = 0.f;
+            HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+            c->last_ms = ms; c->total_ms += ms;
+        }
+        return TRG_OK;
+    }
+    c->last_kernel = (uint32_t)kernel;
+    const bool pool = kernel == TRG_KERNEL_POOL;
     // frame lanes per workgroup (render_fp_kernel) -- see choose_fsplit
     uint32_t fsplit = pool ? 1u : choose_fsplit(c, spp, rows);
     uint32_t fp_rounds = fsplit > 1 ? std::min<uint32_t>((spp + fsplit - 1) / fsplit, kFpMaxRounds) : 0u;
@@ -539,7 +624,8 @@ int trg_set_option(trg_ctx *c, int option, int64_t value) {
         c->opt_in_flight = (int)value;
         break;
     case TRG_OPT_KERNEL:
-        if (value != TRG_KERNEL_DIRECT && value != TRG_KERNEL_POOL) return fail(c, TRG_ERR_INVALID, "trg_set_option: unknown kernel %lld", (long long)value);
+        if (value != TRG_KERNEL_DIRECT && value != TRG_KERNEL_POOL && value != TRG_KERNEL_WAVEFRONT && value != TRG_KERNEL_AUTO)
+            return fail(c, TRG_ERR_INVALID, "trg_set_option: unknown kernel %lld", (long long)value);
         c->opt_kernel = (int)value;
         break;
     default: return fail(c, TRG_ERR_INVALID, "trg_set_option: unknown option %d", option);

@@ -67,6 +67,27 @@ struct RenderParams {
     StackDesc stack;
 };
 
+// ---- wavefront schedule (TRG_KERNEL_WAVEFRONT, trg_wavefront.inc.h): path state and ray queues of one batch in HBM ----
+constexpr uint32_t kWfMaxPaths = 8u << 20;   // pixel-samples per batch (112 B of state each)
+constexpr uint32_t kWfMaxStages = TRG_MAX_BOUNCES + 2u;
+constexpr uint32_t kWfPathBytes = 7u * 16u;  // ray_o, ray_d, sh, hit, thr, rad, scol
+struct WfBuffers {
+    void *ray_o, *ray_d, *sh, *hit, *thr, *rad, *scol;   // float4[nb] each
+    uint32_t *list[2];                                   // 2 * nb entries each
+    uint32_t *ctr;                                       // 4 per stage: head, count, -, -
+};
+struct WfParams {
+    trg_uniforms u;
+    SceneDesc sc;
+    const uint32_t *offsets;
+    float *accum;
+    unsigned long long *counters;
+    WfBuffers b;
+    uint32_t nb, npix, pix0, frame0, nframes, bounces, stage, bounce;
+    uint32_t stack_off;
+    StackDesc stack;
+};
+
 struct TraceParams {
     SceneDesc sc;
     const trg_ray *rays;
@@ -107,6 +128,11 @@ static_assert(!kSignedLds || kWideHbm, "sign-ordered LDS nodes replace the BVH2 
                                         size_t lds_bytes, hipStream_t s);                                        \
     hipError_t launch_render_fp_##SFX(const RenderParams &p, bool lds_scene, bool counters, uint32_t grid,       \
                                       size_t lds_bytes, hipStream_t s);                                          \
+    hipError_t launch_wf_raygen_##SFX(const WfParams &p, hipStream_t s);                                         \
+    hipError_t launch_wf_trace_##SFX(const WfParams &p, bool lds_scene, bool counters, uint32_t grid, size_t lds_bytes, \
+                                     hipStream_t s);                                                             \
+    hipError_t launch_wf_shade_##SFX(const WfParams &p, uint32_t grid, hipStream_t s);                           \
+    hipError_t launch_wf_accumulate_##SFX(const WfParams &p, hipStream_t s);                                     \
     hipError_t launch_trace_##SFX(const TraceParams &p, bool lds_scene, bool any_hit, size_t lds_bytes,          \
                                   hipStream_t s);                                                                \
     hipError_t launch_halton_##SFX(const uint32_t *i, const uint32_t *d, uint32_t n, float *out, hipStream_t s); \

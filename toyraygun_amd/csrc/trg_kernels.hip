@@ -569,6 +569,8 @@ __global__ __launch_bounds__(trg::kBlock) void render_pool_kernel(const trg::Ren
     }
 }
 
+#include "trg_wavefront.inc.h"
+
 // ---- a7 / a12 in isolation: one ray per thread ----
 template <bool LDS_SCENE, bool ANY>
 __global__ __launch_bounds__(trg::kBlock) void trace_kernel(const trg::TraceParams p) {
@@ -705,6 +707,29 @@ hipError_t SFX(launch_render_fp)(const RenderParams &p, bool lds_scene, bool cou
     }
     if (counters) return launch_big_lds(render_fp_kernel<false, true>, p, grid, lds_bytes, s);
     return launch_big_lds(render_fp_kernel<false, false>, p, grid, lds_bytes, s);
+}
+
+hipError_t SFX(launch_wf_raygen)(const WfParams &p, hipStream_t s) {
+    hipLaunchKernelGGL(wf_raygen_kernel, dim3((p.nb + 255u) / 256u), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+hipError_t SFX(launch_wf_trace)(const WfParams &p, bool lds_scene, bool counters, uint32_t grid, size_t lds_bytes, hipStream_t s) {
+    if (lds_scene) {
+        if (counters) hipLaunchKernelGGL((wf_trace_kernel<true, true>), dim3(grid), dim3(kBlock), lds_bytes, s, p);
+        else hipLaunchKernelGGL((wf_trace_kernel<true, false>), dim3(grid), dim3(kBlock), lds_bytes, s, p);
+    } else {
+        if (counters) hipLaunchKernelGGL((wf_trace_kernel<false, true>), dim3(grid), dim3(kBlock), lds_bytes, s, p);
+        else hipLaunchKernelGGL((wf_trace_kernel<false, false>), dim3(grid), dim3(kBlock), lds_bytes, s, p);
+    }
+    return hipGetLastError();
+}
+hipError_t SFX(launch_wf_shade)(const WfParams &p, uint32_t grid, hipStream_t s) {
+    hipLaunchKernelGGL(wf_shade_kernel, dim3(grid), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+hipError_t SFX(launch_wf_accumulate)(const WfParams &p, hipStream_t s) {
+    hipLaunchKernelGGL(wf_accumulate_kernel, dim3((p.npix + 255u) / 256u), dim3(256), 0, s, p);
+    return hipGetLastError();
 }
 
 hipError_t SFX(launch_trace)(const TraceParams &p, bool lds_scene, bool any_hit, size_t lds_bytes, hipStream_t s) {
