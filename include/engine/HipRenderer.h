@@ -18,13 +18,24 @@ public:
     bool init() override;                   // creates the device context; false (+message on stdout) on failure
     void destroy() override;
     void loadScene(Scene *scene) override;  // uploads the five Scene vectors, builds the BVH
-    void renderFrame() override;            // one more sample per pixel into the running average
+    // One more sample per pixel into the running average.  ASYNCHRONOUS like the reference's (MetalRenderer.mm:373-552: encode,
+    // commit, return; three frames in flight behind a semaphore, :33,377,385-387): the call never waits for the GPU to finish
+    // a frame.  It takes a snapshot of the uniforms and either launches at once (GPU idle) or -- while earlier launches are
+    // still running -- lets consecutive frames with identical uniforms ride in ONE later launch (the megakernel renders any
+    // number of frames per launch, bit for bit what one launch per frame gives).  At most kFramesInFlight launches are queued
+    // on the device; only readAccumulation / savePNG / getRayCount / destroy wait for it.
+    void renderFrame() override;
 
     // ---- beyond the reference: batch rendering and read-back for headless use ----
     void setBounces(unsigned int bounces);              // reference hard-codes 3 (MetalRenderer.mm:426)
     unsigned int getBounces() const { return m_bounces; }
     void setOffsetSeed(uint32_t seed);                  // per-pixel Halton offset seed (default 0x5EED0001)
-    bool renderFrames(unsigned int frames);             // `frames` samples in ONE kernel launch
+    bool renderFrames(unsigned int frames);             // `frames` samples in ONE kernel launch (asynchronous too)
+    bool flush();                                       // launch whatever renderFrame() has queued; does not wait
+    bool finish();                                      // flush, then wait until the device has finished every frame
+    void setSynchronous(bool on);                       // true: every launch is timed with HIP events and waited for (getLastRenderMs)
+    unsigned int getLaunchCount() const { return m_launches; }   // kernel launches so far (progressive loops coalesce frames)
+    static const int kFramesInFlight = 3;               // MetalRenderer.mm:33 kMaxFramesInFlight
     bool readAccumulation(float *rgbaOut);              // width*height*4 floats, row 0 = scene bottom
     bool savePNG(const char *path);                     // ACES + sRGB (PostProcessing.metal:44-57), top row first
     int getFrameIndex() const { return m_frameIndex; }
@@ -39,6 +50,11 @@ protected:
     unsigned int m_bounces;
     uint32_t m_offsetSeed;
     bool m_sceneLoaded;
+    bool m_synchronous;
+    unsigned int m_pending;      // frames renderFrame() has accepted but not launched yet
+    int m_pendingFirst;          // frame index of the first of them
+    Uniforms m_pendingUniforms;  // their uniforms (frameIndex zeroed)
+    unsigned int m_launches;
 };
 
 }  // namespace toyraygun

@@ -156,6 +156,13 @@ TRG_API int trg_bind_accum(trg_ctx *ctx, void *device_ptr); /* use caller-owned 
 TRG_API int trg_accum_device_ptr(trg_ctx *ctx, void **out);
 TRG_API int trg_set_stream(trg_ctx *ctx, void *hip_stream); /* NULL = the context's own stream */
 TRG_API int trg_sync(trg_ctx *ctx);
+/* --- asynchronous use (MetalRenderer.mm:33,377,385-387: three frames in flight behind a semaphore).  With TRG_OPT_TIMING 0
+ *     trg_render only enqueues.  trg_stream_idle: 1 when everything enqueued on the context's current stream has finished, 0 when
+ *     not, negative on error; never blocks.  trg_fence_record marks the current end of the stream in slot 0..7;
+ *     trg_fence_wait blocks the host until the work before that mark has finished (a slot never recorded returns at once). */
+TRG_API int trg_stream_idle(trg_ctx *ctx);
+TRG_API int trg_fence_record(trg_ctx *ctx, int slot);
+TRG_API int trg_fence_wait(trg_ctx *ctx, int slot);
 
 /* --- stage-level entry points used by the parity tests (each isolates one SURVEY 8a row) */
 /* a7 / a12: the intersector alone.  any_hit=0: out = trg_isect[n]; any_hit=1: out = float[n] distance (<0: unoccluded). */

@@ -1158,3 +1158,34 @@ def test_subdivided_cornell_renders_the_c2_image(capi, O, cornell):
             assert lb.sum() > 1000 and (la != lb).sum() <= 0.002 * lb.sum(), ((la != lb).sum(), lb.sum())  # only its outline may differ
     finally:
         c.close()
+
+
+def test_async_render_frame_loop(capi, O):
+    """VERDICT r01 missing #3 / next #7: HipRenderer::renderFrame() is fire-and-forget like the reference's (MetalRenderer.mm:33,
+    377,385-387: three frames in flight behind a semaphore) -- no host sync per frame; consecutive frames with the same
+    uniforms may share a launch while the device is busy.  The progressive 1-spp loop at 1920x1080 is bit-identical to
+    the batched launch and reaches >= 80 % of its rays per second (wall clock, first renderFrame() to last frame done)."""
+    from toyraygun_amd import host
+    w, h, frames = 1920, 1080, 64
+    host.run_app(w, h, 4, 3, batch=True)   # warm-up: library load, first launch
+    batch, ms_b, rays_b = host.run_app(w, h, frames, 3, batch=True)
+    best = None
+    for _ in range(3):
+        prog, ms_p, rays_p, launches = host.run_app(w, h, frames, 3, batch=False, want_launches=True)
+        assert np.array_equal(_bits(prog), _bits(batch)) and rays_p == rays_b
+        assert 1 <= launches <= frames
+        best = ms_p if best is None else min(best, ms_p)
+    assert best <= ms_b / 0.8, "progressive loop %.2f ms vs batched %.2f ms (%d launches)" % (best, ms_b, launches)
+    # the C ABI primitives behind it
+    c = make_ctx(O, O.OracleScene.cornell_box(), 256, 256)
+    try:
+        c.set_option(capi.OPT_TIMING, 0)
+        c.fence_wait(2)                      # never recorded: returns at once
+        c.render(0, 64, 8)
+        c.fence_record(0)
+        c.fence_wait(0)
+        assert c.stream_idle()
+        with pytest.raises(capi.TrgError):
+            c.fence_record(8)
+    finally:
+        c.close()

@@ -77,6 +77,9 @@ _SYMBOLS = [
     ("trg_accum_device_ptr", C.c_int, [_P, C.POINTER(_P)]),
     ("trg_set_stream", C.c_int, [_P, _P]),
     ("trg_sync", C.c_int, [_P]),
+    ("trg_stream_idle", C.c_int, [_P]),
+    ("trg_fence_record", C.c_int, [_P, C.c_int]),
+    ("trg_fence_wait", C.c_int, [_P, C.c_int]),
     ("trg_trace", C.c_int, [_P, _P, C.c_size_t, C.c_int, _P]),
     ("trg_halton", C.c_int, [_P, _P, _P, C.c_size_t, _P]),
     ("trg_halton_table", C.c_int, [_P, _P, _P, C.c_size_t, _P]),
@@ -197,6 +200,18 @@ class Context:
 
     def sync(self):
         self._chk(self.L.trg_sync(self.h_ctx))
+
+    def stream_idle(self):
+        rc = self.L.trg_stream_idle(self.h_ctx)
+        if rc < 0:
+            self._chk(rc)
+        return bool(rc)
+
+    def fence_record(self, slot):
+        self._chk(self.L.trg_fence_record(self.h_ctx, slot))
+
+    def fence_wait(self, slot):
+        self._chk(self.L.trg_fence_wait(self.h_ctx, slot))
 
     def bind_accum(self, device_ptr):
         self._chk(self.L.trg_bind_accum(self.h_ctx, device_ptr))

@@ -12,7 +12,11 @@
 
 namespace toyraygun {
 
-HipRenderer::HipRenderer() : m_ctx(nullptr), m_bounces(3), m_offsetSeed(0x5EED0001u), m_sceneLoaded(false) {}
+HipRenderer::HipRenderer()
+    : m_ctx(nullptr), m_bounces(3), m_offsetSeed(0x5EED0001u), m_sceneLoaded(false), m_synchronous(false), m_pending(0), m_pendingFirst(0),
+      m_launches(0) {
+    memset(&m_pendingUniforms, 0, sizeof(m_pendingUniforms));
+}
 HipRenderer::~HipRenderer() { destroy(); }
 
 bool HipRenderer::init() {
@@ -31,17 +35,20 @@ bool HipRenderer::init() {
     }
     m_frameIndex = 0;  // MetalRenderer.mm:337
     m_sceneLoaded = false;
+    m_pending = 0; m_launches = 0;
+    trg_set_option(m_ctx, TRG_OPT_TIMING, m_synchronous ? 1 : 0);   // asynchronous launches: nothing waits per frame
     return true;
 }
 
 void HipRenderer::destroy() {
-    if (m_ctx) trg_destroy(m_ctx);
+    if (m_ctx) { flush(); trg_destroy(m_ctx); }
     m_ctx = nullptr;
     m_sceneLoaded = false;
 }
 
 void HipRenderer::loadScene(Scene *scene) {
     if (!m_ctx || !scene) return;
+    flush();   // frames queued for the old scene are rendered with it
     static_assert(sizeof(bx::Vec3) == 12, "bx::Vec3 must be 3 packed floats");
     const uint32_t nTris = (uint32_t)scene->m_materialIDBuffer.size();
     const uint32_t nVerts = (uint32_t)scene->m_vertexBuffer.size();
@@ -76,30 +83,61 @@ void HipRenderer::fillUniforms(Uniforms *u) {
     u->frameIndex = (unsigned int)m_frameIndex;
 }
 
+// Launch the queued frames [m_pendingFirst, m_pendingFirst + m_pending) in one megakernel launch.  A semaphore of
+// kFramesInFlight launches (MetalRenderer.mm:377: dispatch_semaphore_wait before encoding) bounds what is queued on the device.
+bool HipRenderer::flush() {
+    if (!m_ctx || m_pending == 0) return true;
+    const unsigned int frames = m_pending;
+    m_pending = 0;
+    if (!m_sceneLoaded) return false;
+    static_assert(sizeof(Uniforms) == sizeof(trg_uniforms), "Uniforms / trg_uniforms layout mismatch");
+    const int slot = (int)(m_launches % (unsigned int)kFramesInFlight);
+    if (trg_fence_wait(m_ctx, slot) != TRG_OK ||
+        trg_set_uniforms(m_ctx, reinterpret_cast<const trg_uniforms *>(&m_pendingUniforms)) != TRG_OK ||
+        trg_render(m_ctx, (uint32_t)m_pendingFirst, frames, m_bounces, 0, (uint32_t)m_height) != TRG_OK ||
+        trg_fence_record(m_ctx, slot) != TRG_OK) {
+        printf("HipRenderer: %s\n", trg_last_error(m_ctx));
+        return false;
+    }
+    ++m_launches;
+    return true;
+}
+
+// Accept `frames` more frames with the CURRENT uniforms.  Frames whose uniforms differ from the queued ones cannot share a launch.
+static bool sameUniforms(const Uniforms &a, const Uniforms &b) { return memcmp(&a, &b, sizeof(Uniforms)) == 0; }
 bool HipRenderer::renderFrames(unsigned int frames) {
     if (!m_ctx || !m_sceneLoaded || frames == 0) return false;
     Uniforms u;
     fillUniforms(&u);
-    static_assert(sizeof(Uniforms) == sizeof(trg_uniforms), "Uniforms / trg_uniforms layout mismatch");
-    if (trg_set_uniforms(m_ctx, reinterpret_cast<const trg_uniforms *>(&u)) != TRG_OK ||
-        trg_render(m_ctx, (uint32_t)m_frameIndex, frames, m_bounces, 0, (uint32_t)m_height) != TRG_OK) {
-        printf("HipRenderer: %s\n", trg_last_error(m_ctx));
-        return false;
-    }
-    m_frameIndex += (int)frames;  // uniforms->frameIndex = _frameIndex++ (MetalRenderer.mm:363), once per frame
+    u.frameIndex = 0;   // trg_render iterates its own frame range (uniforms->frameIndex = _frameIndex++, MetalRenderer.mm:363)
+    if (m_pending && !sameUniforms(u, m_pendingUniforms) && !flush()) return false;
+    if (m_pending == 0) { m_pendingUniforms = u; m_pendingFirst = m_frameIndex; }
+    m_pending += frames;
+    m_frameIndex += (int)frames;
+    // launch now if the device has nothing to do (or we are asked to be synchronous, or a lot has piled up); otherwise the
+    // frames wait for the next call and share its launch
+    if (m_synchronous || frames > 1 || m_pending >= 64u || trg_stream_idle(m_ctx) != 0) return flush();
     return true;
 }
 
 void HipRenderer::renderFrame() { renderFrames(1); }
 
-void HipRenderer::setBounces(unsigned int bounces) { m_bounces = bounces; }
+void HipRenderer::setSynchronous(bool on) {
+    flush();
+    m_synchronous = on;
+    if (m_ctx) trg_set_option(m_ctx, TRG_OPT_TIMING, on ? 1 : 0);
+}
+
+void HipRenderer::setBounces(unsigned int bounces) { flush(); m_bounces = bounces; }
+bool HipRenderer::finish() { return m_ctx && flush() && trg_sync(m_ctx) == TRG_OK; }
 void HipRenderer::setOffsetSeed(uint32_t seed) {
+    flush();
     m_offsetSeed = seed;
     if (m_ctx) trg_set_pixel_offsets_seed(m_ctx, seed);
 }
-bool HipRenderer::readAccumulation(float *rgbaOut) { return m_ctx && trg_read_accum(m_ctx, rgbaOut) == TRG_OK; }
+bool HipRenderer::readAccumulation(float *rgbaOut) { return m_ctx && flush() && trg_read_accum(m_ctx, rgbaOut) == TRG_OK; }
 bool HipRenderer::savePNG(const char *path) {
-    if (!m_ctx) return false;
+    if (!m_ctx || !flush()) return false;
     std::vector<uint8_t> rgba((size_t)m_width * m_height * 4);
     if (trg_postprocess(m_ctx, rgba.data(), 1) != TRG_OK) return false;
     return trg_host::write_png_rgba8(path, rgba.data(), m_width, m_height);
@@ -109,6 +147,7 @@ double HipRenderer::getLastRenderMs() const {
     return (m_ctx && trg_get_stats(m_ctx, &st) == TRG_OK) ? st.last_render_ms : 0.0;
 }
 uint64_t HipRenderer::getRayCount() const {
+    const_cast<HipRenderer *>(this)->flush();
     trg_stats st;
     return (m_ctx && trg_get_stats(m_ctx, &st) == TRG_OK) ? st.primary_rays + st.bounce_rays + st.shadow_rays : 0;
 }

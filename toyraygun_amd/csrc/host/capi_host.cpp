@@ -3,6 +3,8 @@
 // Test plumbing for libtoyraygun.so; the product boundary is include/trg.h.
 #include <string.h>
 
+#include <chrono>
+
 #include "cornellBox.h"
 #include "engine/Engine.h"
 #include "engine/HipRenderer.h"
@@ -99,7 +101,7 @@ void trh_random_texture(int w, int h, uint32_t seed, uint32_t *out) {
 // ---- the reference app's call sequence (main.cpp:21-95), headless ----
 // returns 0 on success; negative = the step that failed
 int trh_run_app(int w, int h, int frames, int bounces, int batch, int device, float *accumOut, const char *pngPath,
-                double *msOut, unsigned long long *raysOut) {
+                double *msOut, unsigned long long *raysOut, unsigned int *launchesOut) {
     Engine *engine = Engine::instance();
     engine->setDevice(device);
     engine->init(w, h);
@@ -136,6 +138,8 @@ int trh_run_app(int w, int h, int frames, int bounces, int batch, int device, fl
     HipRenderer *hip = static_cast<HipRenderer *>(renderer);
     hip->setBounces((unsigned int)bounces);
     int rc = 0;
+    hip->finish();
+    const auto t0 = std::chrono::steady_clock::now();
     if (batch) {
         if (!hip->renderFrames((unsigned int)frames)) rc = -4;
     } else {
@@ -146,9 +150,12 @@ int trh_run_app(int w, int h, int frames, int bounces, int batch, int device, fl
         }
         if (hip->getFrameIndex() != frames) rc = -4;
     }
+    hip->finish();   // the loop above only enqueues: this is where the frames are waited for
+    const double loop_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (launchesOut) *launchesOut = hip->getLaunchCount();
     if (rc == 0 && accumOut && !hip->readAccumulation(accumOut)) rc = -5;
     if (rc == 0 && pngPath && pngPath[0] && !hip->savePNG(pngPath)) rc = -6;
-    if (msOut) *msOut = hip->getLastRenderMs();
+    if (msOut) *msOut = loop_ms;   // wall time of the frame loop, enqueue to completion
     if (raysOut) *raysOut = hip->getRayCount();
     renderer->destroy();
     delete renderer;

@@ -25,6 +25,8 @@ struct trg_ctx {
     uint32_t w = 0, h = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t fence[8] = {};
+    bool fence_set[8] = {};
     float *accum_own = nullptr, *accum = nullptr;
     uint32_t *offsets = nullptr;
     unsigned long long *counters = nullptr;
@@ -348,6 +350,8 @@ void trg_destroy(trg_ctx *c) {
     if (c->counters) (void)hipFree(c->counters);
     if (c->offsets) (void)hipFree(c->offsets);
     if (c->accum_own) (void)hipFree(c->accum_own);
+    for (int k = 0; k < 8; ++k)
+        if (c->fence[k]) (void)hipEventDestroy(c->fence[k]);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -649,6 +653,32 @@ int trg_accum_device_ptr(trg_ctx *c, void **out) {
 int trg_set_stream(trg_ctx *c, void *hip_stream) {
     if (!c) return TRG_ERR_INVALID;
     c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return TRG_OK;
+}
+
+int trg_stream_idle(trg_ctx *c) {
+    if (!c) return TRG_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    const hipError_t e = hipStreamQuery(c->stream);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+    return fail(c, TRG_ERR_DEVICE, "hipStreamQuery failed: %s", hipGetErrorString(e));
+}
+
+int trg_fence_record(trg_ctx *c, int slot) {
+    if (!c || slot < 0 || slot >= 8) return TRG_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->fence[slot]) HIPCHK(c, hipEventCreateWithFlags(&c->fence[slot], hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->fence[slot], c->stream));
+    c->fence_set[slot] = true;
+    return TRG_OK;
+}
+
+int trg_fence_wait(trg_ctx *c, int slot) {
+    if (!c || slot < 0 || slot >= 8) return TRG_ERR_INVALID;
+    if (!c->fence_set[slot]) return TRG_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventSynchronize(c->fence[slot]));
     return TRG_OK;
 }
 

@@ -44,7 +44,7 @@ def load():
         L.trh_uniforms.argtypes = [C.c_int, C.c_int, C.c_int, F, F, F, F]
         L.trh_random_texture.argtypes = [C.c_int, C.c_int, C.c_uint32, F]
         L.trh_run_app.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, F, C.c_char_p,
-                                  C.POINTER(C.c_double), C.POINTER(C.c_ulonglong)]
+                                  C.POINTER(C.c_double), C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint)]
         L.trh_run_app.restype = C.c_int
         _lib = L
     return _lib
@@ -139,12 +139,13 @@ def random_texture(w, h, seed=capi.SEED_OFFSETS):
     return out
 
 
-def run_app(w, h, frames, bounces=3, batch=False, device=0, png_path=None):
-    """Drive the reference app's call sequence headlessly; returns (accum[h,w,4], last_ms, rays)."""
+def run_app(w, h, frames, bounces=3, batch=False, device=0, png_path=None, want_launches=False):
+    """Drive the reference app's call sequence headlessly; returns (accum[h,w,4], ms, rays[, launches]): ms = wall time of
+    the frame loop from the first renderFrame() to the completion of the last frame on the device."""
     acc = np.zeros((h, w, 4), np.float32)
-    ms, rays = C.c_double(), C.c_ulonglong()
+    ms, rays, launches = C.c_double(), C.c_ulonglong(), C.c_uint()
     rc = load().trh_run_app(w, h, frames, bounces, 1 if batch else 0, device, acc.ctypes.data,
-                            png_path.encode() if png_path else None, C.byref(ms), C.byref(rays))
+                            png_path.encode() if png_path else None, C.byref(ms), C.byref(rays), C.byref(launches))
     if rc != 0:
         raise RuntimeError("trh_run_app failed at step %d" % rc)
-    return acc, ms.value, rays.value
+    return (acc, ms.value, rays.value, launches.value) if want_launches else (acc, ms.value, rays.value)
