@@ -7,6 +7,7 @@
 #include "engine/Renderer.h"
 
 struct trg_ctx;
+struct trg_group;
 
 namespace toyraygun {
 
@@ -25,6 +26,11 @@ public:
     // number of frames per launch, bit for bit what one launch per frame gives).  At most kFramesInFlight launches are queued
     // on the device; only readAccumulation / savePNG / getRayCount / destroy wait for it.
     void renderFrame() override;
+
+    // ---- beyond the reference: several GPUs of one node.  Call before init(): the frame is then sharded by row bands over the
+    //      devices (trg_group_*, include/trg.h) and gathered on the first one, which presents / reads back / writes the PNG.
+    bool setDevices(const int *devices, int count);
+    int getDeviceCount() const { return m_deviceCount; }
 
     // ---- beyond the reference: batch rendering and read-back for headless use ----
     void setBounces(unsigned int bounces);              // reference hard-codes 3 (MetalRenderer.mm:426)
@@ -46,7 +52,10 @@ public:
     void fillUniforms(Uniforms *out);                   // MetalRenderer.mm:340-371 updateUniforms
 
 protected:
-    trg_ctx *m_ctx;
+    trg_ctx *m_ctx;              // the context (of the first device when a group is used)
+    trg_group *m_group;          // non-null when rendering on several devices
+    int m_devices[16];
+    int m_deviceCount;
     unsigned int m_bounces;
     uint32_t m_offsetSeed;
     bool m_sceneLoaded;

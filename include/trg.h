@@ -164,6 +164,34 @@ TRG_API int trg_stream_idle(trg_ctx *ctx);
 TRG_API int trg_fence_record(trg_ctx *ctx, int slot);
 TRG_API int trg_fence_wait(trg_ctx *ctx, int slot);
 
+/* --- multi-GPU (the reference is single-device): one process, one context per device, frames sharded by contiguous ROW
+ *     BANDS, one RCCL exchange per frame over xGMI.  Device g of G renders rows [g*B, min(h, (g+1)*B)), B = ceil(h / G), into its
+ *     slice of a full-frame buffer (padded to G*B rows, so that the in-place all-gather is exact for any height).  One host thread
+ *     per context drives the launches.  A group of one device needs no RCCL (it is loaded with dlopen for G > 1). */
+typedef struct trg_group trg_group;
+enum trg_gather {
+    TRG_GATHER_NONE = 0,  /* every device keeps only its own band */
+    TRG_GATHER_ALL = 1,   /* in-place ncclAllGather: every device ends with the whole frame */
+    TRG_GATHER_ROOT = 2   /* grouped ncclSend / ncclRecv: only device `root` ends with the whole frame */
+};
+TRG_API void trg_band_rows(uint32_t height, uint32_t n, uint32_t rank, uint32_t *row0, uint32_t *rows); /* host-only arithmetic */
+TRG_API int trg_group_create(trg_group **out, const int *devices, int n, uint32_t width, uint32_t height);
+TRG_API void trg_group_destroy(trg_group *g);
+TRG_API const char *trg_group_last_error(trg_group *g); /* g may be NULL: error of the last failed trg_group_create */
+TRG_API int trg_group_size(trg_group *g);
+TRG_API trg_ctx *trg_group_ctx(trg_group *g, int rank); /* the context of one device (options, stats); owned by the group */
+TRG_API int trg_group_load_scene(trg_group *g, const float *positions3, const float *normals3, const float *colors3, const uint32_t *indices,
+                                 const uint32_t *material_ids, uint32_t n_verts, uint32_t n_tris); /* replicated on every device */
+TRG_API int trg_group_set_uniforms(trg_group *g, const trg_uniforms *u);
+TRG_API int trg_group_set_pixel_offsets_seed(trg_group *g, uint32_t seed);
+TRG_API int trg_group_set_option(trg_group *g, int option, int64_t value);
+/* frames [frameIndexBegin, frameIndexBegin + spp) on every device's band, then the exchange `gather` (enqueued behind each device's
+ * render on its stream; trg_group_sync / trg_group_read_accum wait for it) */
+TRG_API int trg_group_render(trg_group *g, uint32_t frameIndexBegin, uint32_t spp, uint32_t bounces, int gather, int root);
+TRG_API int trg_group_sync(trg_group *g);
+TRG_API int trg_group_read_accum(trg_group *g, int rank, float *rgba); /* width*height*4 floats of device `rank`'s frame buffer */
+TRG_API int trg_group_get_stats(trg_group *g, trg_stats *out);         /* ray counters summed over the devices, times of the slowest one */
+
 /* --- stage-level entry points used by the parity tests (each isolates one SURVEY 8a row) */
 /* a7 / a12: the intersector alone.  any_hit=0: out = trg_isect[n]; any_hit=1: out = float[n] distance (<0: unoccluded). */
 TRG_API int trg_trace(trg_ctx *ctx, const trg_ray *rays, size_t n, int any_hit, void *out);

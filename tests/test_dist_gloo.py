@@ -72,3 +72,52 @@ def test_gather_to_root_only(tmp_path, world, h, O):
         r0, n = band_rows(h, world, r)
         assert np.array_equal(got[r0:r0 + n], ref[r0:r0 + n])
         assert (np.delete(got, np.s_[r0:r0 + n], axis=0) == 0).all()
+
+
+def test_c_abi_row_band_layout_rehearsal(O):
+    """The multi-GPU path of the C ABI (trg_group_*, toyraygun_amd/csrc/trg_group.cpp) shards by bands of B = ceil(h / G) rows and
+    gathers IN PLACE: device g's band sits at float offset g * B * w * 4 of a frame buffer padded to G * B rows, which is the
+    layout ncclAllGather defines as in-place (sendbuff = recvbuff + rank * count).  Rehearsed here without GPUs: trg_band_rows
+    (host-only) gives the bands, the oracle renders each device's band, the exchange is replayed with numpy exactly as
+    trg_group_render enqueues it, and the first h rows of every device's buffer must equal the unsharded frame bit for bit --
+    for heights that divide evenly, that do not, and for more devices than rows."""
+    from toyraygun_amd import capi
+    capi.load()
+    scene = O.OracleScene.cornell_box()
+    for (w, h, G) in ((40, 32, 2), (40, 30, 4), (24, 17, 3), (16, 5, 8), (32, 24, 1)):
+        bands = [capi.band_rows(h, G, r) for r in range(G)]
+        B = -(-h // G)
+        # the bands tile [0, h) in order, every band has B rows except the tail
+        assert bands[0][0] == 0 and sum(n for _, n in bands) == h
+        for r in range(G):
+            assert bands[r][0] == min(h, r * B) and bands[r][1] == max(0, min(h, (r + 1) * B) - r * B)
+        off = O.pixel_offsets(w, h)
+        full, fst = O.render(scene, w, h, 2, 2, offsets=off)
+        count = B * w * 4
+        frames, rays = [], 0
+        for r in range(G):
+            buf = np.zeros((G * B, w, 4), np.float32)            # the padded frame buffer of device r
+            row0, rows = bands[r]
+            if rows:
+                acc = np.zeros((h, w, 4), np.float32)
+                _, st = O.render(scene, w, h, 2, 2, row0=row0, rows=rows, accum=acc, offsets=off)
+                buf[row0:row0 + rows] = acc[row0:row0 + rows]
+                rays += st.rays
+            frames.append(buf)
+        flat = [f.reshape(-1) for f in frames]
+        # TRG_GATHER_ALL: rank r's `count` floats at offset r * count land at the same offset of every rank
+        gathered = [f.copy() for f in flat]
+        for dst in range(G):
+            for src in range(G):
+                gathered[dst][src * count:(src + 1) * count] = flat[src][src * count:(src + 1) * count]
+        for dst in range(G):
+            got = gathered[dst].reshape(G * B, w, 4)[:h]
+            assert np.array_equal(got.view(np.uint32), full.view(np.uint32)), (w, h, G, dst)
+        # TRG_GATHER_ROOT: only the root receives
+        root = G - 1
+        rootbuf = flat[root].copy()
+        for src in range(G):
+            if src != root:
+                rootbuf[src * count:(src + 1) * count] = flat[src][src * count:(src + 1) * count]
+        assert np.array_equal(rootbuf.reshape(G * B, w, 4)[:h].view(np.uint32), full.view(np.uint32))
+        assert rays == fst.rays

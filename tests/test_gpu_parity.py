@@ -1189,3 +1189,51 @@ def test_async_render_frame_loop(capi, O):
             c.fence_record(8)
     finally:
         c.close()
+
+
+def test_device_group_c_abi(capi, O, cornell):
+    """trg_group_* (multi-GPU behind the C ABI) on the devices that are here: with one device the group path (padded
+    frame buffer bound as the accumulation target, band arithmetic, per-device host thread, stats reduction) must reproduce the
+    plain context bit for bit for every gather mode; with two or more visible devices the RCCL exchange runs and every device
+    ends with the same frame.  (The 8-GPU run is the driver's; the band / in-place layout is rehearsed on CPU in
+    tests/test_dist_gloo.py::test_c_abi_row_band_layout_rehearsal.)"""
+    import torch
+    w, h, spp, bnc = 200, 93, 3, 3          # 93 rows: not a multiple of any device count > 1
+    ref_ctx = make_ctx(O, cornell, w, h)
+    try:
+        ref_ctx.set_option(capi.OPT_STRICT, 1)
+        ref_ctx.reset_stats()
+        ref_ctx.render(0, spp, bnc)
+        ref, rst = ref_ctx.read_accum(), ref_ctx.stats()
+    finally:
+        ref_ctx.close()
+    b = cornell.buffers()
+    ndev = min(torch.cuda.device_count(), 4)
+    for n in sorted({1, ndev}):
+        g = capi.Group(list(range(n)), w, h)
+        try:
+            assert g.n == n
+            g.load_scene(b["positions"], b["normals"], b["colors"], b["indices"], b["material_ids"])
+            g.set_uniforms(O.uniforms_bytes(O.make_uniforms(w, h)))
+            g.set_pixel_offsets_seed()
+            g.set_option(capi.OPT_STRICT, 1)
+            for mode, root in ((capi.GATHER_ALL, 0), (capi.GATHER_ROOT, n - 1), (capi.GATHER_NONE, 0)):
+                g.render(0, spp, bnc, gather=mode, root=root)
+                g.sync()
+                ranks = range(n) if mode == capi.GATHER_ALL else ([root] if mode == capi.GATHER_ROOT else [])
+                for r in ranks:
+                    assert np.array_equal(_bits(g.read_accum(r)), _bits(ref)), (n, mode, r)
+                if mode == capi.GATHER_NONE:
+                    for r in range(n):
+                        r0, nr = capi.band_rows(h, n, r)
+                        assert np.array_equal(_bits(g.read_accum(r)[r0:r0 + nr]), _bits(ref[r0:r0 + nr]))
+            st = g.stats()
+            assert st.rays == 3 * rst.rays    # three renders, the counters of all devices summed
+            with pytest.raises(capi.TrgError):
+                g.render(0, 1, 1, gather=7)
+            with pytest.raises(capi.TrgError):
+                g.render(0, 1, 1, gather=capi.GATHER_ROOT, root=n)
+        finally:
+            g.close()
+    with pytest.raises(capi.TrgError):
+        capi.Group([0, 0], 16, 16)

@@ -49,7 +49,7 @@ def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
     headers = _glob(CSRC, (".h",)) + _glob(os.path.join(ROOT, "include"), (".h",)) + \
-        _glob(os.path.join(ROOT, "include", "toyraygun"), (".h",)) + _glob(os.path.join(ROOT, "include", "bx"), (".h",)) + \
+        _glob(os.path.join(ROOT, "include", "engine"), (".h",)) + _glob(os.path.join(ROOT, "include", "bx"), (".h",)) + \
         _glob(HOST, (".h",)) + [os.path.abspath(__file__)]
     common = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include")]
     hidden = ["-fvisibility=hidden"]
@@ -66,6 +66,7 @@ def build(force=False, verbose=False):
         ("trg_build.o", os.path.join(CSRC, "trg_build.hip"), dev),
         ("trg_capi.o", os.path.join(CSRC, "trg_capi.cpp"), ["-x", "hip", "--offload-arch=" + ARCH]),
         ("bvh_build.o", os.path.join(CSRC, "bvh_build.cpp"), ["-x", "hip", "--offload-arch=" + ARCH]),
+        ("trg_group.o", os.path.join(CSRC, "trg_group.cpp"), ["-x", "hip", "--offload-arch=" + ARCH, "-I/opt/rocm/include"]),
     ]
     for name, src, extra in units:
         o = os.path.join(OBJ, name)
@@ -74,7 +75,7 @@ def build(force=False, verbose=False):
         objs.append(o)
     hip_so = os.path.join(LIB, "libtoyraygun_hip.so")
     if force or _newer(hip_so, objs):
-        _run([hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", hip_so] + objs, verbose)
+        _run([hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", hip_so] + objs + ["-ldl", "-lpthread"], verbose)
 
     # host C++ plugin surface (pure host code; links against the C ABI only)
     host_srcs = _glob(HOST, (".cpp",))

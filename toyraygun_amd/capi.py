@@ -80,6 +80,20 @@ _SYMBOLS = [
     ("trg_stream_idle", C.c_int, [_P]),
     ("trg_fence_record", C.c_int, [_P, C.c_int]),
     ("trg_fence_wait", C.c_int, [_P, C.c_int]),
+    ("trg_band_rows", None, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("trg_group_create", C.c_int, [C.POINTER(_P), C.POINTER(C.c_int), C.c_int, C.c_uint32, C.c_uint32]),
+    ("trg_group_destroy", None, [_P]),
+    ("trg_group_last_error", C.c_char_p, [_P]),
+    ("trg_group_size", C.c_int, [_P]),
+    ("trg_group_ctx", _P, [_P, C.c_int]),
+    ("trg_group_load_scene", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint32, C.c_uint32]),
+    ("trg_group_set_uniforms", C.c_int, [_P, C.POINTER(Uniforms)]),
+    ("trg_group_set_pixel_offsets_seed", C.c_int, [_P, C.c_uint32]),
+    ("trg_group_set_option", C.c_int, [_P, C.c_int, C.c_int64]),
+    ("trg_group_render", C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int]),
+    ("trg_group_sync", C.c_int, [_P]),
+    ("trg_group_read_accum", C.c_int, [_P, C.c_int, _P]),
+    ("trg_group_get_stats", C.c_int, [_P, C.POINTER(Stats)]),
     ("trg_trace", C.c_int, [_P, _P, C.c_size_t, C.c_int, _P]),
     ("trg_halton", C.c_int, [_P, _P, _P, C.c_size_t, _P]),
     ("trg_halton_table", C.c_int, [_P, _P, _P, C.c_size_t, _P]),
@@ -264,6 +278,77 @@ class Context:
         out = np.empty((self.h, self.w, 4), np.uint8)
         self._chk(self.L.trg_postprocess(self.h_ctx, _ptr(out), 1 if flip_y else 0))
         return out
+
+
+GATHER_NONE, GATHER_ALL, GATHER_ROOT = 0, 1, 2
+
+
+def band_rows(height, n, rank):
+    """trg_band_rows: rows [row0, row0 + rows) of device `rank` of `n` (bands of ceil(height / n) rows; host-only)."""
+    a, b = C.c_uint32(), C.c_uint32()
+    load().trg_band_rows(height, n, rank, C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+class Group:
+    """trg_group: one context per device of one node, row-band sharding, RCCL exchange (include/trg.h)."""
+
+    def __init__(self, devices, width, height):
+        self.L = load()
+        self.w, self.h = int(width), int(height)
+        devs = (C.c_int * len(devices))(*devices)
+        g = _P()
+        rc = self.L.trg_group_create(C.byref(g), devs, len(devices), self.w, self.h)
+        if rc != OK:
+            raise TrgError(rc, (self.L.trg_group_last_error(None) or b"").decode())
+        self.g = g
+        self.n = len(devices)
+
+    def close(self):
+        if getattr(self, "g", None):
+            self.L.trg_group_destroy(self.g)
+            self.g = None
+
+    __del__ = close
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise TrgError(rc, (self.L.trg_group_last_error(self.g) or b"").decode())
+
+    def load_scene(self, positions, normals, colors, indices, material_ids):
+        pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+        nrm = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+        col = np.ascontiguousarray(colors, np.float32).reshape(-1, 3)
+        idx = np.ascontiguousarray(indices, np.uint32).reshape(-1)
+        mat = np.ascontiguousarray(material_ids, np.uint32).reshape(-1)
+        self._chk(self.L.trg_group_load_scene(self.g, _ptr(pos), _ptr(nrm), _ptr(col), _ptr(idx), _ptr(mat), pos.shape[0], mat.shape[0]))
+
+    def set_uniforms(self, u):
+        if not isinstance(u, Uniforms):
+            u = Uniforms.from_buffer_copy(bytes(u))
+        self._chk(self.L.trg_group_set_uniforms(self.g, C.byref(u)))
+
+    def set_pixel_offsets_seed(self, seed=SEED_OFFSETS):
+        self._chk(self.L.trg_group_set_pixel_offsets_seed(self.g, seed))
+
+    def set_option(self, opt, value):
+        self._chk(self.L.trg_group_set_option(self.g, opt, int(value)))
+
+    def render(self, frame_begin, spp, bounces, gather=GATHER_ALL, root=0):
+        self._chk(self.L.trg_group_render(self.g, frame_begin, spp, bounces, gather, root))
+
+    def sync(self):
+        self._chk(self.L.trg_group_sync(self.g))
+
+    def read_accum(self, rank=0):
+        out = np.empty((self.h, self.w, 4), np.float32)
+        self._chk(self.L.trg_group_read_accum(self.g, rank, _ptr(out)))
+        return out
+
+    def stats(self):
+        st = Stats()
+        self._chk(self.L.trg_group_get_stats(self.g, C.byref(st)))
+        return st
 
 
 def debug_build_bvh(positions, indices, material_ids):

@@ -13,35 +13,62 @@
 namespace toyraygun {
 
 HipRenderer::HipRenderer()
-    : m_ctx(nullptr), m_bounces(3), m_offsetSeed(0x5EED0001u), m_sceneLoaded(false), m_synchronous(false), m_pending(0), m_pendingFirst(0),
+    : m_ctx(nullptr), m_group(nullptr), m_deviceCount(0), m_bounces(3), m_offsetSeed(0x5EED0001u), m_sceneLoaded(false), m_synchronous(false), m_pending(0), m_pendingFirst(0),
       m_launches(0) {
     memset(&m_pendingUniforms, 0, sizeof(m_pendingUniforms));
 }
 HipRenderer::~HipRenderer() { destroy(); }
 
+bool HipRenderer::setDevices(const int *devices, int count) {
+    if (m_ctx || !devices || count < 1 || count > 16) return false;   // before init() only
+    for (int i = 0; i < count; ++i) m_devices[i] = devices[i];
+    m_deviceCount = count;
+    return true;
+}
+
 bool HipRenderer::init() {
     Renderer::init();  // width/height/aspect from the Engine (Renderer.cpp:18-27)
-    if (m_ctx) { trg_destroy(m_ctx); m_ctx = nullptr; }
-    const int rc = trg_create(&m_ctx, Engine::instance()->getDevice(), (uint32_t)m_width, (uint32_t)m_height);
-    if (rc != TRG_OK) {
-        printf("HipRenderer: %s\n", trg_last_error(nullptr));
-        m_ctx = nullptr;
-        return false;
-    }
-    // the reference creates the random-offset texture in resize() (MetalRenderer.mm:323-335)
-    if (trg_set_pixel_offsets_seed(m_ctx, m_offsetSeed) != TRG_OK) {
-        printf("HipRenderer: %s\n", trg_last_error(m_ctx));
-        return false;
+    destroy();
+    if (m_deviceCount > 1) {
+        const int rc = trg_group_create(&m_group, m_devices, m_deviceCount, (uint32_t)m_width, (uint32_t)m_height);
+        if (rc != TRG_OK) {
+            printf("HipRenderer: %s\n", trg_group_last_error(nullptr));
+            m_group = nullptr;
+            return false;
+        }
+        m_ctx = trg_group_ctx(m_group, 0);
+        if (trg_group_set_pixel_offsets_seed(m_group, m_offsetSeed) != TRG_OK) {
+            printf("HipRenderer: %s\n", trg_group_last_error(m_group));
+            return false;
+        }
+    } else {
+        const int dev = m_deviceCount == 1 ? m_devices[0] : Engine::instance()->getDevice();
+        const int rc = trg_create(&m_ctx, dev, (uint32_t)m_width, (uint32_t)m_height);
+        if (rc != TRG_OK) {
+            printf("HipRenderer: %s\n", trg_last_error(nullptr));
+            m_ctx = nullptr;
+            return false;
+        }
+        // the reference creates the random-offset texture in resize() (MetalRenderer.mm:323-335)
+        if (trg_set_pixel_offsets_seed(m_ctx, m_offsetSeed) != TRG_OK) {
+            printf("HipRenderer: %s\n", trg_last_error(m_ctx));
+            return false;
+        }
     }
     m_frameIndex = 0;  // MetalRenderer.mm:337
     m_sceneLoaded = false;
     m_pending = 0; m_launches = 0;
-    trg_set_option(m_ctx, TRG_OPT_TIMING, m_synchronous ? 1 : 0);   // asynchronous launches: nothing waits per frame
+    // asynchronous launches: nothing waits per frame
+    if (m_group) trg_group_set_option(m_group, TRG_OPT_TIMING, m_synchronous ? 1 : 0);
+    else trg_set_option(m_ctx, TRG_OPT_TIMING, m_synchronous ? 1 : 0);
     return true;
 }
 
 void HipRenderer::destroy() {
-    if (m_ctx) { flush(); trg_destroy(m_ctx); }
+    if (m_ctx) flush();
+    if (m_group) trg_group_destroy(m_group);   // owns every context, m_ctx included
+    else if (m_ctx) trg_destroy(m_ctx);
+    m_group = nullptr;
     m_ctx = nullptr;
     m_sceneLoaded = false;
 }
@@ -57,8 +84,10 @@ void HipRenderer::loadScene(Scene *scene) {
     const float *col = nVerts ? &scene->m_colorBuffer[0].x : nullptr;
     const uint32_t *idx = nVerts ? &scene->m_indexBuffer[0] : nullptr;
     const uint32_t *mat = nTris ? &scene->m_materialIDBuffer[0] : nullptr;
-    if (trg_load_scene(m_ctx, pos, nrm, col, idx, mat, nVerts, nTris) != TRG_OK) {
-        printf("HipRenderer: %s\n", trg_last_error(m_ctx));
+    const int rc = m_group ? trg_group_load_scene(m_group, pos, nrm, col, idx, mat, nVerts, nTris)
+                           : trg_load_scene(m_ctx, pos, nrm, col, idx, mat, nVerts, nTris);
+    if (rc != TRG_OK) {
+        printf("HipRenderer: %s\n", m_group ? trg_group_last_error(m_group) : trg_last_error(m_ctx));
         m_sceneLoaded = false;
         return;
     }
@@ -92,6 +121,15 @@ bool HipRenderer::flush() {
     if (!m_sceneLoaded) return false;
     static_assert(sizeof(Uniforms) == sizeof(trg_uniforms), "Uniforms / trg_uniforms layout mismatch");
     const int slot = (int)(m_launches % (unsigned int)kFramesInFlight);
+    if (m_group) {   // row bands over the devices, gathered on the first one (which presents)
+        if (trg_group_set_uniforms(m_group, reinterpret_cast<const trg_uniforms *>(&m_pendingUniforms)) != TRG_OK ||
+            trg_group_render(m_group, (uint32_t)m_pendingFirst, frames, m_bounces, TRG_GATHER_ROOT, 0) != TRG_OK) {
+            printf("HipRenderer: %s\n", trg_group_last_error(m_group));
+            return false;
+        }
+        ++m_launches;
+        return true;
+    }
     if (trg_fence_wait(m_ctx, slot) != TRG_OK ||
         trg_set_uniforms(m_ctx, reinterpret_cast<const trg_uniforms *>(&m_pendingUniforms)) != TRG_OK ||
         trg_render(m_ctx, (uint32_t)m_pendingFirst, frames, m_bounces, 0, (uint32_t)m_height) != TRG_OK ||
@@ -125,19 +163,26 @@ void HipRenderer::renderFrame() { renderFrames(1); }
 void HipRenderer::setSynchronous(bool on) {
     flush();
     m_synchronous = on;
-    if (m_ctx) trg_set_option(m_ctx, TRG_OPT_TIMING, on ? 1 : 0);
+    if (m_group) trg_group_set_option(m_group, TRG_OPT_TIMING, on ? 1 : 0);
+    else if (m_ctx) trg_set_option(m_ctx, TRG_OPT_TIMING, on ? 1 : 0);
 }
 
 void HipRenderer::setBounces(unsigned int bounces) { flush(); m_bounces = bounces; }
-bool HipRenderer::finish() { return m_ctx && flush() && trg_sync(m_ctx) == TRG_OK; }
+bool HipRenderer::finish() { return m_ctx && flush() && (m_group ? trg_group_sync(m_group) : trg_sync(m_ctx)) == TRG_OK; }
 void HipRenderer::setOffsetSeed(uint32_t seed) {
     flush();
     m_offsetSeed = seed;
-    if (m_ctx) trg_set_pixel_offsets_seed(m_ctx, seed);
+    if (m_group) trg_group_set_pixel_offsets_seed(m_group, seed);
+    else if (m_ctx) trg_set_pixel_offsets_seed(m_ctx, seed);
 }
-bool HipRenderer::readAccumulation(float *rgbaOut) { return m_ctx && flush() && trg_read_accum(m_ctx, rgbaOut) == TRG_OK; }
+bool HipRenderer::readAccumulation(float *rgbaOut) {
+    if (!m_ctx || !flush()) return false;
+    if (m_group && trg_group_sync(m_group) != TRG_OK) return false;   // the gather onto device 0
+    return trg_read_accum(m_ctx, rgbaOut) == TRG_OK;
+}
 bool HipRenderer::savePNG(const char *path) {
     if (!m_ctx || !flush()) return false;
+    if (m_group && trg_group_sync(m_group) != TRG_OK) return false;
     std::vector<uint8_t> rgba((size_t)m_width * m_height * 4);
     if (trg_postprocess(m_ctx, rgba.data(), 1) != TRG_OK) return false;
     return trg_host::write_png_rgba8(path, rgba.data(), m_width, m_height);
@@ -149,6 +194,7 @@ double HipRenderer::getLastRenderMs() const {
 uint64_t HipRenderer::getRayCount() const {
     const_cast<HipRenderer *>(this)->flush();
     trg_stats st;
+    if (m_group) return trg_group_get_stats(m_group, &st) == TRG_OK ? st.primary_rays + st.bounce_rays + st.shadow_rays : 0;
     return (m_ctx && trg_get_stats(m_ctx, &st) == TRG_OK) ? st.primary_rays + st.bounce_rays + st.shadow_rays : 0;
 }
 const char *HipRenderer::getLastError() const { return trg_last_error(m_ctx); }

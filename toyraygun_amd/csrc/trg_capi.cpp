@@ -297,6 +297,8 @@ static int render_wavefront(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint
 }
 
 
+extern "C" void *trg_internal_stream(trg_ctx *c) { return c ? (void *)c->stream : nullptr; }   // for trg_group.cpp; hidden visibility
+
 extern "C" {
 
 const char *trg_last_error(trg_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
