@@ -122,6 +122,15 @@ TRG_API const char *trg_last_error(trg_ctx *ctx); /* ctx may be NULL: error of t
 TRG_API int trg_load_scene(trg_ctx *ctx, const float *positions3, const float *normals3, const float *colors3,
                    const uint32_t *indices, const uint32_t *material_ids, uint32_t n_verts, uint32_t n_tris);
 
+/* --- albedo textures (upstream to-do "OBJ and Texture support", README.md:18-22; Texture::loadFile, src/engine/Texture.cpp:39-48).
+ *     Call after trg_load_scene; the scene then multiplies the interpolated vertex colour of a MATERIAL_DEFAULT hit by a texel.
+ *     uv2: 3*n_tris (u, v) pairs addressed like the normals ([triangle*3 + corner], interpolated with the same weights);
+ *     texture_ids: n_tris entries, 0 = untextured, k = images[k-1]; images: n_textures pointers to tightly packed RGBA8 rows, row 0
+ *     first.  Lookup (project definition): x = min(w-1, (int)(frac(u) * w)), y = min(h-1, (int)(frac(v) * h)), texel RGB / 255,
+ *     nearest, repeat.  n_tris must equal the loaded scene's; n_textures = 0 removes the textures.  Everything is copied. */
+TRG_API int trg_load_textures(trg_ctx *ctx, const float *uv2, const uint32_t *texture_ids, uint32_t n_tris, const uint8_t *const *images_rgba8,
+                              const uint32_t *widths, const uint32_t *heights, uint32_t n_textures);
+
 /* --- per-frame uniforms: replaces MetalRenderer updateUniforms (MetalRenderer.mm:340-371).
  *     frameIndex in the struct is ignored by trg_render (it iterates its own range). */
 TRG_API int trg_set_uniforms(trg_ctx *ctx, const trg_uniforms *u);

@@ -38,6 +38,8 @@ class Scene(C.Structure):
         ("indices", C.POINTER(C.c_uint32)), ("material_ids", C.POINTER(C.c_uint32)),
         ("nverts", C.c_uint32), ("ntris", C.c_uint32), ("cap_verts", C.c_uint32), ("cap_tris", C.c_uint32),
         ("accel", C.c_void_p),
+        ("uvs", C.POINTER(C.c_float)), ("tex_ids", C.POINTER(C.c_uint32)), ("tex_table", C.POINTER(C.c_uint32)),
+        ("texels", C.POINTER(C.c_uint32)), ("ntextures", C.c_uint32),
     ]
 
 
@@ -168,6 +170,18 @@ class OracleScene:
         assert p.shape[0] == 3 * m.shape[0] == n.shape[0] == c.shape[0]
         self.L.orc_scene_add_raw.argtypes = [C.POINTER(Scene), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         self.L.orc_scene_add_raw(self.p, p.ctypes.data, n.ctypes.data, c.ctypes.data, m.ctypes.data, m.shape[0])
+
+    def set_textures(self, uvs, texture_ids, images):
+        """Albedo textures (project definition, see trg_oracle.h): uvs [3*ntris, 2], ids [ntris], images list of [h, w, 4] uint8."""
+        uv = np.ascontiguousarray(uvs, np.float32).reshape(-1, 2)
+        ids = np.ascontiguousarray(texture_ids, np.uint32).reshape(-1)
+        assert uv.shape[0] == 3 * self.ntris and ids.shape[0] == self.ntris
+        imgs = [np.ascontiguousarray(im, np.uint8) for im in images]
+        ptrs = (C.c_void_p * max(len(imgs), 1))(*[im.ctypes.data for im in imgs])
+        ws = np.array([im.shape[1] for im in imgs], np.uint32)
+        hs = np.array([im.shape[0] for im in imgs], np.uint32)
+        self.L.orc_scene_set_textures.argtypes = [C.POINTER(Scene), C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_uint32]
+        self.L.orc_scene_set_textures(self.p, uv.ctypes.data, ids.ctypes.data, ptrs, ws.ctypes.data, hs.ctypes.data, len(imgs))
 
     @property
     def ntris(self):

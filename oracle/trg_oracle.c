@@ -194,8 +194,32 @@ void orc_scene_free(orc_scene *s)
 {
     if (!s) return;
     free(s->positions); free(s->normals); free(s->colors); free(s->indices); free(s->material_ids);
+    free(s->uvs); free(s->tex_ids); free(s->tex_table); free(s->texels);
     accel_free(s->accel);
     free(s);
+}
+/* Albedo textures: the project's definition (the reference has none).  Copies everything; ntextures = 0 removes them. */
+void orc_scene_set_textures(orc_scene *s, const float *uv2, const uint32_t *tex_ids, const uint8_t *const *images_rgba8,
+                            const uint32_t *widths, const uint32_t *heights, uint32_t ntextures)
+{
+    free(s->uvs); free(s->tex_ids); free(s->tex_table); free(s->texels);
+    s->uvs = NULL; s->tex_ids = NULL; s->tex_table = NULL; s->texels = NULL; s->ntextures = 0;
+    if (!ntextures) return;
+    size_t total = 0;
+    for (uint32_t k = 0; k < ntextures; ++k) total += (size_t)widths[k] * heights[k];
+    s->uvs = (float *)malloc((size_t)s->ntris * 6 * sizeof(float));
+    s->tex_ids = (uint32_t *)malloc((size_t)s->ntris * sizeof(uint32_t));
+    s->tex_table = (uint32_t *)malloc((size_t)ntextures * 4 * sizeof(uint32_t));
+    s->texels = (uint32_t *)malloc(total * sizeof(uint32_t));
+    memcpy(s->uvs, uv2, (size_t)s->ntris * 6 * sizeof(float));
+    memcpy(s->tex_ids, tex_ids, (size_t)s->ntris * sizeof(uint32_t));
+    size_t first = 0;
+    for (uint32_t k = 0; k < ntextures; ++k) {
+        s->tex_table[k * 4 + 0] = (uint32_t)first; s->tex_table[k * 4 + 1] = widths[k]; s->tex_table[k * 4 + 2] = heights[k]; s->tex_table[k * 4 + 3] = 0;
+        memcpy(&s->texels[first], images_rgba8[k], (size_t)widths[k] * heights[k] * 4);
+        first += (size_t)widths[k] * heights[k];
+    }
+    s->ntextures = ntextures;
 }
 static void scene_reserve(orc_scene *s, uint32_t more_tris)
 {
@@ -519,6 +543,30 @@ static void interp_attr(const float *attr, const orc_isect *is, float out[3])
     for (int a = 0; a < 3; ++a) out[a] = ux * T0[a] + uy * T1[a] + uz * T2[a];
 }
 
+/* Albedo texel of a shaded hit: project definition (orc_scene_set_textures).  Texture coordinates are interpolated with the
+ * weights of Raytracing.metal:95-112; nearest texel, repeat wrap, row 0 of the image at v = 0; texel RGB / 255 multiplies vc. */
+static void texture_albedo(const orc_scene *s, const orc_isect *is, float vc[3])
+{
+    uint32_t t = (uint32_t)is->primitiveIndex;
+    uint32_t id = s->tex_ids[t];
+    if (id == 0u) return;
+    float ux = is->coordinates[0], uy = is->coordinates[1];
+    float uz = 1.0f - ux - uy;
+    const float *p = &s->uvs[(size_t)t * 6];
+    float uu = ux * p[0] + uy * p[2] + uz * p[4];
+    float vv = ux * p[1] + uy * p[3] + uz * p[5];
+    const uint32_t *tab = &s->tex_table[(id - 1u) * 4];
+    uint32_t w = tab[1], h = tab[2];
+    float fu = uu - floorf(uu), fv = vv - floorf(vv);
+    uint32_t px = (uint32_t)(fu * (float)w), py = (uint32_t)(fv * (float)h);
+    if (px >= w) px = w - 1u;
+    if (py >= h) py = h - 1u;
+    uint32_t texel = s->texels[tab[0] + py * w + px];
+    vc[0] = vc[0] * ((float)(texel & 255u) / 255.0f);
+    vc[1] = vc[1] * ((float)((texel >> 8) & 255u) / 255.0f);
+    vc[2] = vc[2] * ((float)((texel >> 16) & 255u) / 255.0f);
+}
+
 void orc_primary_hit(const orc_uniforms *u, orc_ray *rays, orc_ray *shadow_rays, const orc_isect *isects,
                      const orc_scene *s, uint32_t bounce, const uint32_t *offsets, float *dst,
                      uint32_t x, uint32_t y, orc_stats *st)
@@ -541,6 +589,7 @@ void orc_primary_hit(const orc_uniforms *u, orc_ray *rays, orc_ray *shadow_rays,
         for (int a = 0; a < 3; ++a) P[a] = ray->origin[a] + ray->direction[a] * is->distance;
         float vc[3], vn0[3], vn[3];
         interp_attr(s->colors, is, vc);
+        if (s->uvs) texture_albedo(s, is, vc);
         interp_attr(s->normals, is, vn0);
         normalize3(vn0, vn);
         uint32_t offset = offsets[rayIdx];

@@ -64,6 +64,13 @@ typedef struct orc_scene {
     uint32_t *material_ids; /* ntris */
     uint32_t nverts, ntris, cap_verts, cap_tris;
     void *accel; /* lazily built oracle BVH (large scenes only) */
+    /* albedo textures -- NOT in the reference ("OBJ and Texture support" is on its to-do list, README.md:18-22): the project's
+     * definition, restated here for the parity tests (orc_scene_set_textures) */
+    float *uvs;           /* ntris*3 (u,v) pairs, or NULL */
+    uint32_t *tex_ids;    /* ntris: 0 = none, k = texture k-1 */
+    uint32_t *tex_table;  /* per texture: first texel, width, height, 0 */
+    uint32_t *texels;     /* RGBA8, all textures back to back */
+    uint32_t ntextures;
 } orc_scene;
 
 typedef struct orc_stats {
@@ -99,6 +106,9 @@ void orc_scene_add_geometry(orc_scene *s, const float *verts3, const uint32_t *t
                             const float *mtx, const float color[3], uint32_t material_id);
 void orc_scene_add_raw(orc_scene *s, const float *pos9, const float *nrm9, const float *col9, const uint32_t *material_ids,
                        int tri_count); /* Scene.h:25-29 public vectors, appended as given */
+/* project definition (see orc_scene above): uv2 = ntris*3 pairs, tex_ids = ntris, images = ntextures pointers to RGBA8 rows */
+void orc_scene_set_textures(orc_scene *s, const float *uv2, const uint32_t *tex_ids, const uint8_t *const *images_rgba8,
+                            const uint32_t *widths, const uint32_t *heights, uint32_t ntextures);
 void orc_scene_add_cube(orc_scene *s, const float color[3], const float *mtx);
 void orc_scene_add_plane(orc_scene *s, const float color[3], const float *mtx);
 void orc_scene_add_area_light(orc_scene *s, const float color[3], const float *mtx);

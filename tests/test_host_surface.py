@@ -410,3 +410,67 @@ def test_product_never_touches_the_oracle():
                         if re.search(pat, txt):
                             bad.append((os.path.join(dp, f), pat))
     assert not bad, bad
+
+
+def test_texture_load_file_decodes_png_and_ppm(built, tmp_path):
+    """Texture::loadFile (reference src/engine/Texture.cpp:39-48 via stb_image; here the in-tree reader): 8-bit PNG of every
+    supported colour type, written by PIL with real deflate (dynamic Huffman, adaptive filters), and binary PPM / PGM, decode
+    to exactly PIL's pixels; files it cannot handle are refused, not mis-decoded."""
+    from PIL import Image
+    from toyraygun_amd import host
+    rng = np.random.default_rng(9)
+    yy, xx = np.mgrid[0:97, 0:131]
+    smooth = np.stack([(xx * 2) % 256, (yy * 3) % 256, (xx + yy) % 256, 255 - (xx % 256)], -1).astype(np.uint8)
+    noise = rng.integers(0, 256, (97, 131, 4), dtype=np.uint8)
+    for name, arr in (("smooth", smooth), ("noise", noise)):
+        for mode, ch in (("L", 1), ("LA", 2), ("RGB", 3), ("RGBA", 4)):
+            a = arr[..., :ch] if ch > 1 else arr[..., 0]
+            p = tmp_path / ("%s_%s.png" % (name, mode))
+            Image.fromarray(a, mode).save(p, compress_level=6 if name == "smooth" else 1)
+            t = host.Texture(path=p)
+            assert t.info() == (131, 97, ch)
+            assert np.array_equal(t.pixels(), a.reshape(97, 131, ch)), (name, mode)
+    p = tmp_path / "stored.png"
+    Image.fromarray(noise[..., :3], "RGB").save(p, compress_level=0)     # stored deflate blocks
+    assert np.array_equal(host.Texture(path=p).pixels(), noise[..., :3])
+    p = tmp_path / "a.ppm"
+    Image.fromarray(noise[..., :3], "RGB").save(p)
+    assert np.array_equal(host.Texture(path=p).pixels(), noise[..., :3])
+    p = tmp_path / "a.pgm"
+    Image.fromarray(noise[..., 0], "L").save(p)
+    assert np.array_equal(host.Texture(path=p).pixels()[..., 0], noise[..., 0])
+    # refused: interlaced PNG, 16-bit PNG, palette PNG, truncated file, not an image
+    Image.fromarray(smooth[..., :3], "RGB").convert("P").save(tmp_path / "pal.png")
+    Image.fromarray(smooth[..., 0].astype(np.uint16) * 257).save(tmp_path / "d16.png")
+    data = (tmp_path / "smooth_RGB.png").read_bytes()
+    (tmp_path / "cut.png").write_bytes(data[: len(data) // 2])
+    (tmp_path / "txt.png").write_text("not an image")
+    for bad in ("pal.png", "d16.png", "cut.png", "txt.png", "missing.png"):
+        with pytest.raises(IOError):
+            host.Texture(path=tmp_path / bad)
+    # RGBA expansion used for the upload
+    assert np.array_equal(host.Texture(path=tmp_path / "smooth_L.png").rgba()[..., 1], smooth[..., 0])
+
+
+def test_textured_mesh_buffers(built, tmp_path):
+    """Scene::addMesh with texture coordinates + Texture, and a textured OBJ (vt): the sixth / seventh buffers line up with the
+    five reference buffers; triangles added before and after stay untextured."""
+    from toyraygun_amd import host
+    s = host.Scene.cornell_box()
+    tex = host.Texture(rgba=np.full((4, 4, 4), 200, np.uint8))
+    v = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], np.float32)
+    n = np.tile(np.array([[0, 0, 1]], np.float32), (4, 1))
+    uv = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32)
+    s.add_textured_mesh(v, n, uv, [0, 1, 2, 0, 2, 3], np.eye(4, dtype=np.float32), (1, 1, 1), 1, tex)
+    s.add("cube", (0.5, 0.5, 0.5), np.eye(4, dtype=np.float32))
+    obj = tmp_path / "q.obj"
+    obj.write_text("v 0 0 1\nv 1 0 1\nv 0 1 1\nvt 0.25 0.5\nvt 0.75 0.5\nvt 0.25 1.5\nvn 0 0 1\nf 1/1/1 2/2/1 3/3/1\nf 1 2 3\n")
+    assert s.add_obj(obj, np.eye(4, dtype=np.float32), (1, 1, 1), 1, texture=tex) == 2
+    b = s.buffers()
+    uvs, ids, imgs = s.texture_buffers()
+    nt = b["material_ids"].shape[0]
+    assert nt == 36 + 2 + 12 + 2 and uvs.shape == (3 * nt, 2) and ids.shape == (nt,)
+    assert (ids[:36] == 0).all() and (ids[36:38] == 1).all() and (ids[38:50] == 0).all() and ids[50] == 1 and ids[51] == 0
+    assert np.array_equal(uvs[108:114], uv[[0, 1, 2, 0, 2, 3]])
+    assert np.array_equal(uvs[150:153], np.array([[0.25, 0.5], [0.75, 0.5], [0.25, 1.5]], np.float32))
+    assert len(imgs) == 1 and imgs[0].shape == (4, 4, 4)

@@ -65,6 +65,7 @@ _SYMBOLS = [
     ("trg_destroy", None, [_P]),
     ("trg_last_error", C.c_char_p, [_P]),
     ("trg_load_scene", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint32, C.c_uint32]),
+    ("trg_load_textures", C.c_int, [_P, _P, _P, C.c_uint32, C.POINTER(_P), _P, _P, C.c_uint32]),
     ("trg_set_uniforms", C.c_int, [_P, C.POINTER(Uniforms)]),
     ("trg_set_pixel_offsets", C.c_int, [_P, _P]),
     ("trg_set_pixel_offsets_seed", C.c_int, [_P, C.c_uint32]),
@@ -173,6 +174,19 @@ class Context:
         if idx.shape[0] != 3 * nt or nrm.shape[0] != 3 * nt or col.shape[0] != 3 * nt:
             raise ValueError("expected 3*n_tris indices/normals/colors for %d triangles" % nt)
         self._chk(self.L.trg_load_scene(self.h_ctx, _ptr(pos), _ptr(nrm), _ptr(col), _ptr(idx), _ptr(mat), pos.shape[0], nt))
+
+    def load_textures(self, uvs, texture_ids, images):
+        """trg_load_textures: uvs [3*n_tris, 2], texture_ids [n_tris] (0 = none, k = images[k-1]), images = list of [h, w, 4] uint8."""
+        uv = np.ascontiguousarray(uvs, np.float32).reshape(-1, 2)
+        ids = np.ascontiguousarray(texture_ids, np.uint32).reshape(-1)
+        imgs = [np.ascontiguousarray(im, np.uint8) for im in images]
+        for im in imgs:
+            if im.ndim != 3 or im.shape[2] != 4:
+                raise ValueError("textures must be [h, w, 4] uint8")
+        ptrs = (_P * max(len(imgs), 1))(*[im.ctypes.data for im in imgs])
+        ws = np.array([im.shape[1] for im in imgs], np.uint32)
+        hs = np.array([im.shape[0] for im in imgs], np.uint32)
+        self._chk(self.L.trg_load_textures(self.h_ctx, _ptr(uv), _ptr(ids), ids.shape[0], ptrs, _ptr(ws), _ptr(hs), len(imgs)))
 
     def set_uniforms(self, u):
         if not isinstance(u, Uniforms):

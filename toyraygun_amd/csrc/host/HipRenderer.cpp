@@ -92,6 +92,38 @@ void HipRenderer::loadScene(Scene *scene) {
         return;
     }
     m_sceneLoaded = true;
+    // albedo textures of the scene (Scene::addMesh with a Texture): expanded to RGBA8 and uploaded with the texture coordinates
+    if (!scene->m_textures.empty() && nTris) {
+        std::vector<float> uv(scene->m_uvBuffer);
+        std::vector<uint32_t> ids(scene->m_textureIDBuffer);
+        uv.resize((size_t)nVerts * 2, 0.0f);       // triangles added after the last textured mesh
+        ids.resize(nTris, 0u);
+        std::vector<std::vector<uint8_t> > rgba(scene->m_textures.size());
+        std::vector<const uint8_t *> ptrs;
+        std::vector<uint32_t> ws, hs;
+        for (size_t k = 0; k < scene->m_textures.size(); ++k) {
+            Texture *t = scene->m_textures[k];
+            const int w = t->getWidth(), h = t->getHeight(), ch = t->getChannels();
+            const uint8_t *src = t->getBufferPointer();
+            rgba[k].resize((size_t)w * h * 4);
+            for (size_t i = 0; i < (size_t)w * h; ++i) {
+                const uint8_t *p = src + i * ch;
+                uint8_t *q = &rgba[k][i * 4];
+                if (ch >= 3) { q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; q[3] = ch == 4 ? p[3] : 255; }
+                else { q[0] = q[1] = q[2] = p[0]; q[3] = ch == 2 ? p[1] : 255; }
+            }
+            ptrs.push_back(rgba[k].data()); ws.push_back((uint32_t)w); hs.push_back((uint32_t)h);
+        }
+        const int n = m_group ? trg_group_size(m_group) : 1;
+        for (int r = 0; r < n; ++r) {
+            trg_ctx *c = m_group ? trg_group_ctx(m_group, r) : m_ctx;
+            if (trg_load_textures(c, uv.data(), ids.data(), nTris, ptrs.data(), ws.data(), hs.data(), (uint32_t)ptrs.size()) != TRG_OK) {
+                printf("HipRenderer: %s\n", trg_last_error(c));
+                m_sceneLoaded = false;
+                return;
+            }
+        }
+    }
 }
 
 // MetalRenderer.mm:340-371: inverse view-projection, fixed ceiling light, frame index.

@@ -99,10 +99,38 @@ void Scene::addMesh(const bx::Vec3 *vertices, const bx::Vec3 *normals, const bx:
     }
 }
 
-int Scene::addObj(const char *path, float *transformMtx, bx::Vec3 color, unsigned int materialID) {
+void Scene::padTextureBuffers() {
+    m_uvBuffer.resize(m_vertexBuffer.size() * 2, 0.0f);
+    m_textureIDBuffer.resize(m_materialIDBuffer.size(), 0u);
+}
+uint32_t Scene::textureID(Texture *texture) {
+    if (!texture) return 0u;
+    for (size_t k = 0; k < m_textures.size(); ++k)
+        if (m_textures[k] == texture) return (uint32_t)k + 1u;
+    m_textures.push_back(texture);
+    return (uint32_t)m_textures.size();
+}
+
+void Scene::addMesh(const bx::Vec3 *vertices, const bx::Vec3 *normals, const float *uvs, const uint32_t *indices, int triangleCount,
+                    float *transformMtx, bx::Vec3 color, unsigned int materialID, Texture *texture) {
+    padTextureBuffers();   // whatever was added before has no texture
+    const uint32_t id = textureID(texture);
+    addMesh(vertices, normals, indices, triangleCount, transformMtx, color, materialID);
+    for (int t = 0; t < triangleCount; ++t) {
+        for (int c = 0; c < 3; ++c) {
+            const uint32_t v = indices[t * 3 + c];
+            m_uvBuffer.push_back(uvs ? uvs[v * 2] : 0.0f);
+            m_uvBuffer.push_back(uvs ? uvs[v * 2 + 1] : 0.0f);
+        }
+        m_textureIDBuffer.push_back(id);
+    }
+}
+
+int Scene::addObj(const char *path, float *transformMtx, bx::Vec3 color, unsigned int materialID, Texture *texture) {
     FILE *f = fopen(path, "r");
     if (!f) return -1;
     std::vector<bx::Vec3> pos, nrm;
+    std::vector<float> tex;   // vt u v
     int added = 0;
     char line[1024];
     while (fgets(line, sizeof(line), f)) {
@@ -111,12 +139,15 @@ int Scene::addObj(const char *path, float *transformMtx, bx::Vec3 color, unsigne
         if (p[0] == 'v' && (p[1] == ' ' || p[1] == '\t')) {
             float x = 0, y = 0, z = 0;
             if (sscanf(p + 1, "%f %f %f", &x, &y, &z) == 3) pos.push_back(bx::Vec3(x, y, z));
+        } else if (p[0] == 'v' && p[1] == 't') {
+            float u = 0, v = 0;
+            if (sscanf(p + 2, "%f %f", &u, &v) >= 1) { tex.push_back(u); tex.push_back(v); }
         } else if (p[0] == 'v' && p[1] == 'n') {
             float x = 0, y = 0, z = 0;
             if (sscanf(p + 2, "%f %f %f", &x, &y, &z) == 3) nrm.push_back(bx::Vec3(x, y, z));
         } else if (p[0] == 'f' && (p[1] == ' ' || p[1] == '\t')) {
             // corners: v, v/vt, v//vn, v/vt/vn
-            int vi[64], ni[64], n = 0;
+            int vi[64], ni[64], ti[64], n = 0;
             char *q = const_cast<char *>(p + 1);
             while (n < 64) {
                 while (*q == ' ' || *q == '\t') ++q;
@@ -130,7 +161,7 @@ int Scene::addObj(const char *path, float *transformMtx, bx::Vec3 color, unsigne
                     if (*q != '/') { t = strtol(q, &end, 10); q = end; }
                     if (*q == '/') { ++q; nn = strtol(q, &end, 10); q = end; }
                 }
-                (void)t;
+                ti[n] = t == 0 ? -1 : (int)(t < 0 ? (long)(tex.size() / 2) + t : t - 1);
                 vi[n] = (int)(v < 0 ? (long)pos.size() + v : v - 1);
                 ni[n] = nn == 0 ? -1 : (int)(nn < 0 ? (long)nrm.size() + nn : nn - 1);
                 ++n;
@@ -145,11 +176,19 @@ int Scene::addObj(const char *path, float *transformMtx, bx::Vec3 color, unsigne
                 if (!ok) continue;
                 bx::Vec3 v3[3] = { pos[vi[c3[0]]], pos[vi[c3[1]]], pos[vi[c3[2]]] };
                 uint32_t idx[3] = { 0, 1, 2 };
+                bool have_t = texture != nullptr;
+                for (int j = 0; j < 3; ++j)
+                    if (ti[c3[j]] < 0 || ti[c3[j]] >= (int)(tex.size() / 2)) have_t = false;
+                if (have_t) padTextureBuffers();
                 if (have_n) {
                     bx::Vec3 n3[3] = { nrm[ni[c3[0]]], nrm[ni[c3[1]]], nrm[ni[c3[2]]] };
                     addMesh(v3, n3, idx, 1, transformMtx, color, materialID);
                 } else {
                     addGeometry(v3, idx, 1, transformMtx, color, materialID);
+                }
+                if (have_t) {   // a face with texture coordinates of a textured OBJ
+                    for (int j = 0; j < 3; ++j) { m_uvBuffer.push_back(tex[ti[c3[j]] * 2]); m_uvBuffer.push_back(tex[ti[c3[j]] * 2 + 1]); }
+                    m_textureIDBuffer.push_back(textureID(texture));
                 }
                 ++added;
             }

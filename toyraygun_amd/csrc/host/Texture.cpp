@@ -4,6 +4,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "image_reader.h"
+
 namespace toyraygun {
 namespace {
 uint32_t pcg_hash32(uint32_t v) {
@@ -43,7 +45,11 @@ void Texture::init(int width, int height, int channels) {
     m_data = malloc((size_t)width * height * channels);
     m_width = width; m_height = height; m_channels = channels;
 }
-bool Texture::loadFile(std::string) { return false; }
+bool Texture::loadFile(std::string path) {
+    destroy();
+    m_data = trg_host::read_image(path.c_str(), &m_width, &m_height, &m_channels);   // like stbi_load(path, &w, &h, &c, 0)
+    return m_data != nullptr;
+}
 void Texture::destroy() {
     if (m_data) free(m_data);
     m_data = nullptr;

@@ -44,6 +44,50 @@ void trh_scene_add_mesh_colors(void *s, const float *verts3, const float *normal
     static_cast<Scene *>(s)->addMesh(reinterpret_cast<const bx::Vec3 *>(verts3), reinterpret_cast<const bx::Vec3 *>(normals3),
                                      reinterpret_cast<const bx::Vec3 *>(colors3), indices, triCount, m, materialID);
 }
+// ---- textures (N4) ----
+void *trh_texture_load(const char *path) {
+    Texture *t = new Texture;
+    if (!t->loadFile(path)) { delete t; return nullptr; }
+    return t;
+}
+void *trh_texture_from_rgba(const uint8_t *rgba, int w, int h) {
+    Texture *t = new Texture;
+    t->init(w, h, 4);
+    memcpy(t->getBufferPointer(), rgba, (size_t)w * h * 4);
+    return t;
+}
+void trh_texture_info(void *t, int *w, int *h, int *channels) {
+    Texture *x = static_cast<Texture *>(t);
+    *w = x->getWidth(); *h = x->getHeight(); *channels = x->getChannels();
+}
+void trh_texture_copy(void *t, uint8_t *out) {
+    Texture *x = static_cast<Texture *>(t);
+    memcpy(out, x->getBufferPointer(), x->getBufferSize());
+}
+void trh_texture_free(void *t) {
+    Texture *x = static_cast<Texture *>(t);
+    x->destroy();
+    delete x;
+}
+void trh_scene_add_textured_mesh(void *s, const float *verts3, const float *normals3, const float *uvs2, const uint32_t *indices, int triCount,
+                                 const float *mtx16, const float *color3, unsigned int materialID, void *texture) {
+    float m[16];
+    memcpy(m, mtx16, sizeof(m));
+    static_cast<Scene *>(s)->addMesh(reinterpret_cast<const bx::Vec3 *>(verts3), reinterpret_cast<const bx::Vec3 *>(normals3), uvs2, indices,
+                                     triCount, m, bx::Vec3(color3[0], color3[1], color3[2]), materialID, static_cast<Texture *>(texture));
+}
+int trh_scene_add_obj_textured(void *s, const char *path, const float *mtx16, const float *color3, unsigned int materialID, void *texture) {
+    float m[16];
+    memcpy(m, mtx16, sizeof(m));
+    return static_cast<Scene *>(s)->addObj(path, m, bx::Vec3(color3[0], color3[1], color3[2]), materialID, static_cast<Texture *>(texture));
+}
+// uv [nVerts*2] and texture ids [nTris], padded with "no texture" for triangles added after the last textured mesh
+void trh_scene_copy_textures(void *s, float *uv, uint32_t *ids) {
+    Scene *sc = static_cast<Scene *>(s);
+    const size_t nv = sc->m_vertexBuffer.size(), nt = sc->m_materialIDBuffer.size();
+    for (size_t i = 0; i < nv * 2; ++i) uv[i] = i < sc->m_uvBuffer.size() ? sc->m_uvBuffer[i] : 0.0f;
+    for (size_t i = 0; i < nt; ++i) ids[i] = i < sc->m_textureIDBuffer.size() ? sc->m_textureIDBuffer[i] : 0u;
+}
 int trh_scene_add_obj(void *s, const char *path, const float *mtx16, const float *color3, unsigned int materialID) {
     float m[16];
     memcpy(m, mtx16, sizeof(m));

@@ -31,6 +31,8 @@ struct trg_ctx {
     uint32_t *offsets = nullptr;
     unsigned long long *counters = nullptr;
     unsigned char *blob = nullptr;
+    unsigned char *tex_mem = nullptr;   // uv | ids | table | texels (trg_load_textures)
+    TexDesc tex{};
     // global overflow levels of the traversal stacks (grow-only), one buffer per launch the caller keeps in flight
     // (TRG_OPT_LAUNCHES_IN_FLIGHT): launch k uses slot k mod in_flight, so overlapping launches never share one
     static constexpr int kScratchSlots = 16;
@@ -267,6 +269,7 @@ static int render_wavefront(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint
     unsigned char *m = c->wf_mem[slot];
     WfParams p{};
     p.u = c->u; p.sc = c->sc; p.offsets = c->offsets; p.accum = c->accum; p.counters = c->counters;
+    p.tex = c->tex;
     p.b.ray_o = m; p.b.ray_d = m + arr; p.b.sh = m + 2 * arr; p.b.hit = m + 3 * arr; p.b.thr = m + 4 * arr; p.b.rad = m + 5 * arr; p.b.scol = m + 6 * arr;
     p.b.list[0] = reinterpret_cast<uint32_t *>(m + 7 * arr); p.b.list[1] = reinterpret_cast<uint32_t *>(m + 7 * arr + lst);
     p.b.ctr = reinterpret_cast<uint32_t *>(m + 7 * arr + 2 * lst);
@@ -345,6 +348,7 @@ void trg_destroy(trg_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     if (c->blob) (void)hipFree(c->blob);
+    if (c->tex_mem) (void)hipFree(c->tex_mem);
     for (int k = 0; k < trg_ctx::kScratchSlots; ++k) {
         if (c->stack_scratch[k]) (void)hipFree(c->stack_scratch[k]);
         if (c->wf_mem[k]) (void)hipFree(c->wf_mem[k]);
@@ -374,6 +378,10 @@ int trg_load_scene(trg_ctx *c, const float *pos, const float *nrm, const float *
             return fail(c, TRG_ERR_RANGE, "trg_load_scene: %u triangles need at least %llu B on the device (limit 4 GiB)", n_tris, (unsigned long long)least);
     }
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->tex_mem) {   // textures belong to the scene they were loaded for
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->tex_mem); c->tex_mem = nullptr; c->tex = TexDesc{};
+    }
     if (c->opt_gpu_build && n_tris >= 2) return load_scene_gpu_build(c, pos, nrm, col, idx, mat, n_verts, n_tris);
 
     const auto host_t0 = std::chrono::steady_clock::now();
@@ -462,6 +470,48 @@ int trg_load_scene(trg_ctx *c, const float *pos, const float *nrm, const float *
     return plan_lds(c, plan, c->opt_kernel == TRG_KERNEL_POOL);
 }
 
+int trg_load_textures(trg_ctx *c, const float *uv2, const uint32_t *texture_ids, uint32_t n_tris, const uint8_t *const *images, const uint32_t *widths,
+                      const uint32_t *heights, uint32_t n_textures) {
+    if (!c) return TRG_ERR_INVALID;
+    if (!c->scene_loaded) return fail(c, TRG_ERR_INVALID, "trg_load_textures: load the scene first");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->tex_mem) { (void)hipFree(c->tex_mem); c->tex_mem = nullptr; }
+    c->tex = TexDesc{};
+    if (n_textures == 0) return TRG_OK;
+    if (!uv2 || !texture_ids || !images || !widths || !heights) return fail(c, TRG_ERR_INVALID, "trg_load_textures: null argument");
+    if (n_tris != c->sc.n_tris) return fail(c, TRG_ERR_INVALID, "trg_load_textures: %u triangles, the scene has %u", n_tris, c->sc.n_tris);
+    uint64_t texels = 0;
+    for (uint32_t k = 0; k < n_textures; ++k) {
+        if (!images[k] || widths[k] == 0 || heights[k] == 0 || widths[k] > 32768u || heights[k] > 32768u)
+            return fail(c, TRG_ERR_INVALID, "trg_load_textures: texture %u is empty or larger than 32768", k);
+        texels += (uint64_t)widths[k] * heights[k];
+    }
+    if (texels > 0xFFFFFFF0ull / 4u) return fail(c, TRG_ERR_RANGE, "trg_load_textures: %llu texels (limit 2^30)", (unsigned long long)texels);
+    for (uint32_t t = 0; t < n_tris; ++t)
+        if (texture_ids[t] > n_textures) return fail(c, TRG_ERR_INVALID, "trg_load_textures: triangle %u names texture %u of %u", t, texture_ids[t], n_textures);
+    const size_t uv_bytes = (size_t)n_tris * 24u, id_bytes = (size_t)n_tris * 4u, tab_bytes = (size_t)n_textures * 16u;
+    const size_t off_ids = (uv_bytes + 15u) & ~(size_t)15u, off_tab = (off_ids + id_bytes + 15u) & ~(size_t)15u, off_tex = (off_tab + tab_bytes + 15u) & ~(size_t)15u;
+    std::vector<unsigned char> host(off_tex + (size_t)texels * 4u, 0);
+    memcpy(&host[0], uv2, uv_bytes);
+    memcpy(&host[off_ids], texture_ids, id_bytes);
+    uint32_t *tab = reinterpret_cast<uint32_t *>(&host[off_tab]);
+    uint64_t first = 0;
+    for (uint32_t k = 0; k < n_textures; ++k) {
+        tab[k * 4 + 0] = (uint32_t)first; tab[k * 4 + 1] = widths[k]; tab[k * 4 + 2] = heights[k]; tab[k * 4 + 3] = 0u;
+        memcpy(&host[off_tex + (size_t)first * 4u], images[k], (size_t)widths[k] * heights[k] * 4u);
+        first += (uint64_t)widths[k] * heights[k];
+    }
+    hipError_t e = hipMalloc((void **)&c->tex_mem, host.size());
+    if (e != hipSuccess) return fail(c, TRG_ERR_NOMEM, "trg_load_textures: hipMalloc(%zu) failed: %s", host.size(), hipGetErrorString(e));
+    HIPCHK(c, hipMemcpy(c->tex_mem, host.data(), host.size(), hipMemcpyHostToDevice));
+    c->tex.uv = reinterpret_cast<const float *>(c->tex_mem);
+    c->tex.ids = reinterpret_cast<const uint32_t *>(c->tex_mem + off_ids);
+    c->tex.table = reinterpret_cast<const uint32_t *>(c->tex_mem + off_tab);
+    c->tex.texels = reinterpret_cast<const uint32_t *>(c->tex_mem + off_tex);
+    return TRG_OK;
+}
+
 int trg_set_uniforms(trg_ctx *c, const trg_uniforms *u) {
     if (!c || !u) return TRG_ERR_INVALID;
     if (u->width != c->w || u->height != c->h)
@@ -536,6 +586,7 @@ int trg_render(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces,
     p.frame_begin = frame_begin; p.spp = spp; p.bounces = bounces; p.row0 = row0; p.rows = rows;
     p.stack_off = plan.stack_off; p.red_off = plan.red_off; p.pool_off = plan.pool_off;
     p.fsplit = fsplit; p.fp_rounds = fp_rounds; p.acc_off = plan.acc_off;
+    p.tex = c->tex;
     // workgroup tile: 16x16 pixels, or (4/fsplit) 8x8 sub-tiles side by side when the frames are split over waves
     const uint32_t tile_w = fsplit > 1 ? 8u * (kWaves / fsplit) : (uint32_t)kTileW, tile_h = fsplit > 1 ? 8u : (uint32_t)kTileH;
     p.tiles_x = (c->w + tile_w - 1) / tile_w;

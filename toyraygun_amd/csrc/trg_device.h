@@ -9,6 +9,7 @@
 #include <stdint.h>
 
 #include "../../include/trg.h"
+#include "trg_kernels.h"
 
 #ifndef TRG_STRICT
 #define TRG_STRICT 0
@@ -506,6 +507,7 @@ struct SceneView {
     const float *colors;    // 9 per triangle, ORIGINAL order (reference vertexColors buffer)
     const uint32_t *mats;   // 1 per triangle, ORIGINAL order (reference triangleMasks buffer)
     const float *htab;      // Halton group tables in LDS (trg_kernels.h kHtab), or nullptr
+    trg::TexDesc tex;       // albedo textures in global memory (tex.uv == nullptr: none)
 };
 struct Hit { float t; int prim; float u, v; };  // u, v = Moeller-Trumbore weights of vertex 1 and 2
 struct Counters { uint32_t nodes, tris, wnodes, wtris; };  // per-lane work and wave-level iterations (first active lane counts)
@@ -1032,6 +1034,24 @@ TRG_DEV V3 interp_attr(const float *attr, int prim, float cx, float cy) {
     const float *p = attr + prim * 9;
     const V3 T0 = mk(p[0], p[1], p[2]), T1 = mk(p[3], p[4], p[5]), T2 = mk(p[6], p[7], p[8]);
     return cx * T0 + cy * T1 + cz * T2;
+}
+
+// Albedo texel of a shaded hit (trg_load_textures; project definition, the reference has no textures): the texture coordinates
+// are interpolated like every other vertex attribute (Raytracing.metal:95-112), the lookup is nearest-texel with repeat wrap.
+TRG_DEV V3 texture_albedo(const trg::TexDesc &tex, int prim, float cx, float cy, V3 vcol) {
+    const uint32_t id = tex.ids[prim];
+    if (id == 0u) return vcol;
+    const float cz = 1.0f - cx - cy;
+    const float *p = tex.uv + prim * 6;
+    const float u = cx * p[0] + cy * p[2] + cz * p[4], v = cx * p[1] + cy * p[3] + cz * p[5];
+    const uint32_t *t = tex.table + (id - 1u) * 4u;
+    const uint32_t w = t[1], h = t[2];
+    const float fu = u - floorf(u), fv = v - floorf(v);
+    uint32_t x = (uint32_t)(fu * (float)w), y = (uint32_t)(fv * (float)h);
+    x = x < w ? x : w - 1u; y = y < h ? y : h - 1u;
+    const uint32_t texel = tex.texels[t[0] + y * w + x];
+    const V3 c = mk(div_fast((float)(texel & 255u), 255.0f), div_fast((float)((texel >> 8) & 255u), 255.0f), div_fast((float)((texel >> 16) & 255u), 255.0f));
+    return vcol * c;
 }
 
 // ACES + sRGB (N1): common.h:36-43,163-171

@@ -45,6 +45,15 @@ struct SceneDesc {
     uint32_t off_htab;              // Halton group tables (kHtabFloats floats), inside the staged region
 };
 
+// albedo textures (trg_load_textures): per-corner texture coordinates, per-triangle texture id (0 = none), a table of
+// (first texel, width, height, -) per texture and the RGBA8 texels of all textures back to back.  uv == nullptr: no textures.
+struct TexDesc {
+    const float *uv;
+    const uint32_t *ids;
+    const uint32_t *table;
+    const uint32_t *texels;
+};
+
 // traversal stack: the first `klds` levels live in LDS, deeper ones in a global scratch column per thread
 struct StackDesc {
     int *overflow;      // (levels - klds) x grid_threads ints, or nullptr
@@ -62,6 +71,7 @@ struct RenderParams {
     uint32_t red_off;              // byte offset of the counter-reduction scratch in dynamic LDS
     uint32_t pool_off;             // render_pool_kernel: byte offset of the path pool (slots, lists, counters);
                                    // render_fp_kernel: byte offset of the parked per-frame radiances
+    TexDesc tex;
     uint32_t acc_off;              // render_kernel on an HBM-resident scene: byte offset of the parked running average (3 x kBlock floats)
     uint32_t fsplit, fp_rounds;    // render_fp_kernel: frame lanes per workgroup (2 or 4), rounds parked per fold
     StackDesc stack;
@@ -83,6 +93,7 @@ struct WfParams {
     float *accum;
     unsigned long long *counters;
     WfBuffers b;
+    TexDesc tex;
     uint32_t nb, npix, pix0, frame0, nframes, bounces, stage, bounce;
     uint32_t stack_off;
     StackDesc stack;

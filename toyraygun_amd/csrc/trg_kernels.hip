@@ -44,6 +44,7 @@ TRG_DEV SceneView scene_view(const trg::SceneDesc &sc, unsigned char *smem) {
         v.mats = reinterpret_cast<const uint32_t *>(sc.blob + sc.off_mats);
         v.htab = nullptr;
     }
+    v.tex.uv = nullptr; v.tex.ids = nullptr; v.tex.table = nullptr; v.tex.texels = nullptr;
     return v;
 }
 
@@ -79,7 +80,8 @@ TRG_DEV ShadeOut shade_event(const trg_uniforms &u, const SceneView &sc, const H
         // Raytracing.metal:150-199
         const V3 P = o + d * h.t;
         const float cx = 1.0f - h.u - h.v, cy = h.u;  // weights of vertex 0, 1
-        const V3 vcol = interp_attr(sc.colors, h.prim, cx, cy);
+        V3 vcol = interp_attr(sc.colors, h.prim, cx, cy);
+        if (sc.tex.uv) vcol = texture_albedo(sc.tex, h.prim, cx, cy, vcol);   // wave-uniform test: scenes without textures skip it
         const V3 nrm = normalize(interp_attr(sc.normals, h.prim, cx, cy));
         float r[4];
         // opaque copy: stops LICM from hoisting every bounce's Halton digits (all 60 dimensions) out of the
@@ -199,7 +201,8 @@ TRG_DEV V3 path_radiance(const trg::RenderParams &p, const SceneView &sc, STK st
 template <bool LDS_SCENE, bool COUNT>
 __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES : TRG_EXP_WAVES_HBM) void render_kernel(const trg::RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const SceneView sc = scene_view<LDS_SCENE>(p.sc, smem);
+    SceneView sc = scene_view<LDS_SCENE>(p.sc, smem);
+    sc.tex = p.tex;
     LdsStackT<trg::kBlock, !LDS_SCENE> stk;  // HBM scenes may spill deep stack levels to global scratch
     stk.set(smem, p.stack_off, p.stack.overflow, p.stack.klds);  // also writes the sentinel at level 0 of this thread's column
 
@@ -305,7 +308,8 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES : TRG_EXP_WA
 template <bool LDS_SCENE, bool COUNT>
 __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES_FP : TRG_EXP_WAVES_HBM) void render_fp_kernel(const trg::RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const SceneView sc = scene_view<LDS_SCENE>(p.sc, smem);
+    SceneView sc = scene_view<LDS_SCENE>(p.sc, smem);
+    sc.tex = p.tex;
     LdsStackT<trg::kBlock, !LDS_SCENE> stk;
     stk.set(smem, p.stack_off, p.stack.overflow, p.stack.klds);  // also writes the sentinel at level 0 of this thread's column
 
@@ -399,7 +403,8 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES_FP : TRG_EXP
 template <bool LDS_SCENE, bool COUNT, int S>
 __global__ __launch_bounds__(trg::kBlock) void render_pool_kernel(const trg::RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const SceneView sc = scene_view<LDS_SCENE>(p.sc, smem);
+    SceneView sc = scene_view<LDS_SCENE>(p.sc, smem);
+    sc.tex = p.tex;
     LdsStackT<trg::kBlock, !LDS_SCENE> stk;  // HBM scenes may spill deep stack levels to global scratch
     stk.set(smem, p.stack_off, p.stack.overflow, p.stack.klds);  // also writes the sentinel at level 0 of this thread's column
     constexpr int P = trg::kBlock * S;
@@ -490,7 +495,8 @@ __global__ __launch_bounds__(trg::kBlock) void render_pool_kernel(const trg::Ren
                             const V3 o = mk(r0.x, r0.y, r0.z), d = mk(r1.x, r1.y, r1.z);
                             const V3 Pp = o + d * h.x;
                             const float cx = 1.0f - hu - hv, cy = hu;
-                            const V3 vcol = interp_attr(sc.colors, prim, cx, cy);
+                            V3 vcol = interp_attr(sc.colors, prim, cx, cy);
+                            if (sc.tex.uv) vcol = texture_albedo(sc.tex, prim, cx, cy, vcol);
                             const V3 nrm = normalize(interp_attr(sc.normals, prim, cx, cy));
                             float r[4];
                             uint32_t hi = offset + f0 + j;

@@ -231,6 +231,7 @@ __global__ __launch_bounds__(256) void wf_shade_kernel(const trg::WfParams p) {
     const trg::SceneDesc &sd = p.sc;
     SceneView sc;
     sc.nodes = nullptr; sc.tris = nullptr; sc.htab = nullptr;
+    sc.tex = p.tex;
     sc.normals = reinterpret_cast<const float *>(sd.blob + sd.off_normals);
     sc.colors = reinterpret_cast<const float *>(sd.blob + sd.off_colors);
     sc.mats = reinterpret_cast<const uint32_t *>(sd.blob + sd.off_mats);

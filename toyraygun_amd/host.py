@@ -13,7 +13,8 @@ from . import capi
 HOST_SO = os.path.join(capi.LIB_DIR, "libtoyraygun.so")
 _lib = None
 
-SYMBOL_NAMES = ["trh_scene_new", "trh_scene_cornell", "trh_scene_lattice", "trh_scene_free", "trh_scene_add", "trh_scene_add_mesh", "trh_scene_add_mesh_colors", "trh_scene_add_obj",
+SYMBOL_NAMES = ["trh_scene_new", "trh_scene_cornell", "trh_scene_lattice", "trh_scene_free", "trh_scene_add", "trh_scene_add_mesh", "trh_scene_add_mesh_colors", "trh_scene_add_obj", "trh_texture_load", "trh_texture_from_rgba",
+                "trh_texture_info", "trh_texture_copy", "trh_texture_free", "trh_scene_add_textured_mesh", "trh_scene_add_obj_textured", "trh_scene_copy_textures",
                 "trh_scene_counts", "trh_scene_copy", "trh_mtx_srt", "trh_mtx_inverse", "trh_uniforms",
                 "trh_random_texture", "trh_run_app"]
 
@@ -34,6 +35,17 @@ def load():
         L.trh_scene_add.argtypes = [P, C.c_int, F, F]
         L.trh_scene_add_mesh.argtypes = [P, F, F, F, C.c_int, F, F, C.c_uint]
         L.trh_scene_add_mesh_colors.argtypes = [P, F, F, F, F, C.c_int, F, C.c_uint]
+        L.trh_texture_load.argtypes = [C.c_char_p]
+        L.trh_texture_load.restype = P
+        L.trh_texture_from_rgba.argtypes = [F, C.c_int, C.c_int]
+        L.trh_texture_from_rgba.restype = P
+        L.trh_texture_info.argtypes = [P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.trh_texture_copy.argtypes = [P, F]
+        L.trh_texture_free.argtypes = [P]
+        L.trh_scene_add_textured_mesh.argtypes = [P, F, F, F, F, C.c_int, F, F, C.c_uint, P]
+        L.trh_scene_add_obj_textured.argtypes = [P, C.c_char_p, F, F, C.c_uint, P]
+        L.trh_scene_add_obj_textured.restype = C.c_int
+        L.trh_scene_copy_textures.argtypes = [P, F, F]
         L.trh_scene_add_obj.argtypes = [P, C.c_char_p, F, F, C.c_uint]
         L.trh_scene_add_obj.restype = C.c_int
         L.trh_scene_counts.argtypes = [P, C.POINTER(C.c_uint)]
@@ -61,6 +73,7 @@ class Scene:
     def __init__(self, handle=None):
         self.L = load()
         self.h = handle if handle is not None else self.L.trh_scene_new()
+        self._textures = []   # Texture objects the native Scene borrows
 
     @classmethod
     def cornell_box(cls):
@@ -93,10 +106,34 @@ class Scene:
         self.L.trh_scene_add_mesh(self.h, v.ctypes.data, n.ctypes.data, t.ctypes.data, t.size // 3, m.ctypes.data,
                                   c.ctypes.data, material_id)
 
-    def add_obj(self, path, mtx, color, material_id=1):
+    def add_obj(self, path, mtx, color, material_id=1, texture=None):
         """Scene::addObj: returns the number of triangles added (-1: unreadable file)."""
         m, c = _f32(mtx).reshape(16), _f32(color)
+        if texture is not None:
+            self._textures.append(texture)
+            return int(self.L.trh_scene_add_obj_textured(self.h, str(path).encode(), m.ctypes.data, c.ctypes.data, material_id, texture.h))
         return int(self.L.trh_scene_add_obj(self.h, str(path).encode(), m.ctypes.data, c.ctypes.data, material_id))
+
+    def add_textured_mesh(self, verts, normals, uvs, tri_idx, mtx, color, material_id, texture):
+        """Scene::addMesh with texture coordinates [n_verts, 2] and an albedo Texture."""
+        v, n, uv, m, c = _f32(verts), _f32(normals), _f32(uvs), _f32(mtx).reshape(16), _f32(color)
+        t = np.ascontiguousarray(tri_idx, np.uint32)
+        self._textures.append(texture)   # the Scene borrows it
+        self.L.trh_scene_add_textured_mesh(self.h, v.ctypes.data, n.ctypes.data, uv.ctypes.data, t.ctypes.data, t.size // 3, m.ctypes.data,
+                                           c.ctypes.data, material_id, texture.h)
+
+    def texture_buffers(self):
+        """(uvs [n_verts, 2], texture_ids [n_tris], images list of [h, w, 4] uint8 in texture-id order) for trg_load_textures."""
+        nt = C.c_uint()
+        nv = self.L.trh_scene_counts(self.h, C.byref(nt))
+        uv, ids = np.zeros((nv, 2), np.float32), np.zeros(nt.value, np.uint32)
+        self.L.trh_scene_copy_textures(self.h, uv.ctypes.data, ids.ctypes.data)
+        seen, imgs = [], []
+        for t in self._textures:
+            if t.h not in seen:
+                seen.append(t.h)
+                imgs.append(t.rgba())
+        return uv, ids, imgs
 
     def buffers(self):
         nt = C.c_uint()
@@ -108,6 +145,53 @@ class Scene:
         self.L.trh_scene_copy(self.h, out["positions"].ctypes.data, out["normals"].ctypes.data, out["colors"].ctypes.data,
                               out["indices"].ctypes.data, out["material_ids"].ctypes.data)
         return out
+
+
+class Texture:
+    """toyraygun::Texture: loadFile (8-bit PNG / binary PPM) or raw RGBA8 pixels."""
+
+    def __init__(self, path=None, rgba=None):
+        self.L = load()
+        if path is not None:
+            self.h = self.L.trh_texture_load(str(path).encode())
+            if not self.h:
+                raise IOError("Texture::loadFile failed for %s" % path)
+        else:
+            a = np.ascontiguousarray(rgba, np.uint8)
+            assert a.ndim == 3 and a.shape[2] == 4
+            self.h = self.L.trh_texture_from_rgba(a.ctypes.data, a.shape[1], a.shape[0])
+
+    def info(self):
+        w, h, c = C.c_int(), C.c_int(), C.c_int()
+        self.L.trh_texture_info(self.h, C.byref(w), C.byref(h), C.byref(c))
+        return w.value, h.value, c.value
+
+    def pixels(self):
+        w, h, c = self.info()
+        out = np.zeros((h, w, c), np.uint8)
+        self.L.trh_texture_copy(self.h, out.ctypes.data)
+        return out
+
+    def rgba(self):
+        p = self.pixels()
+        h, w, c = p.shape
+        out = np.full((h, w, 4), 255, np.uint8)
+        if c >= 3:
+            out[..., :3] = p[..., :3]
+            if c == 4:
+                out[..., 3] = p[..., 3]
+        else:
+            out[..., :3] = p[..., :1]
+            if c == 2:
+                out[..., 3] = p[..., 1]
+        return out
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.trh_texture_free(self.h)
+        except Exception:
+            pass
 
 
 def mtx_srt(scale, rot, pos):
