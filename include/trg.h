@@ -88,8 +88,9 @@ enum trg_option {
     TRG_OPT_GPU_BUILD = 6,    /* 1: the next trg_load_scene builds the BVH on the GPU (LBVH, 4-wide, HBM traversal only); 0 (default): host SAH build */
     TRG_OPT_KERNEL = 5,       /* which megakernel trg_render launches: TRG_KERNEL_DIRECT (default) or TRG_KERNEL_POOL */
     TRG_OPT_LAUNCHES_IN_FLIGHT = 8, /* hint, default 1: how many trg_render launches of this context the caller keeps in flight on different
-                                 streams (at most 16).  Consecutive launches then use separate scratch buffers, and the automatic frame split favours
-                                 throughput (the overlap hides a launch's tail) */
+                                 streams (at most 16): the automatic frame split then favours throughput (the overlap hides a launch's tail).
+                                 Per-launch scratch is keyed on the stream (trg_set_stream), so launches on different streams never share
+                                 any, in whatever order the streams are used; at most 15 streams besides the context's own */
     TRG_OPT_FRAME_SPLIT = 7   /* TRG_KERNEL_DIRECT only: frame lanes per workgroup. 1: a pixel's frames run one after the other in one
                                  lane; 2 or 4: that many wavefronts share a pixel's frames (same result bit for bit; fills the chip
                                  when the pixel grid alone does not -- small windows, row bands of a multi-GPU job);
@@ -146,8 +147,8 @@ TRG_API int trg_set_pixel_offsets_seed(trg_ctx *ctx, uint32_t seed); /* offset(x
  *     Result: running average in the float4 accumulation buffer (row 0 = scene bottom).  If
  *     frameIndexBegin > 0 the buffer must hold the average of frames [0, frameIndexBegin).
  *     Asynchronous when TRG_OPT_TIMING is 0.  Launches of one context into DIFFERENT accumulation buffers (trg_bind_accum) on
- *     different streams (trg_set_stream) may be in flight together, up to the number announced with
- *     TRG_OPT_LAUNCHES_IN_FLIGHT (each gets its own traversal-stack scratch; default 1 = keep them on one stream). */
+ *     different streams (trg_set_stream) may be in flight together (every stream gets its own traversal-stack / wavefront
+ *     scratch; announce how many with TRG_OPT_LAUNCHES_IN_FLIGHT so that the schedule is chosen for throughput). */
 TRG_API int trg_render(trg_ctx *ctx, uint32_t frameIndexBegin, uint32_t spp, uint32_t bounces, uint32_t row0, uint32_t rows);
 
 /* --- read back the accumulation target (what the reference hands to its blit pass,

@@ -36,6 +36,8 @@ struct trg_ctx {
     // global overflow levels of the traversal stacks (grow-only), one buffer per launch the caller keeps in flight
     // (TRG_OPT_LAUNCHES_IN_FLIGHT): launch k uses slot k mod in_flight, so overlapping launches never share one
     static constexpr int kScratchSlots = 16;
+    hipStream_t slot_stream[kScratchSlots] = {};   // which stream owns scratch slot k (slot 0 = the context's own stream)
+    int slots_used = 1;
     int *stack_scratch[kScratchSlots] = {};
     size_t stack_scratch_bytes[kScratchSlots] = {};
     // wavefront schedule: path state + ray queues of one batch, one set per launch in flight (grow-only)
@@ -188,6 +190,18 @@ static int ensure_stack_scratch(trg_ctx *c, const LdsPlan &plan, uint64_t grid_t
 }
 
 static int render_wavefront(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces, uint32_t row0, uint32_t rows, int slot);
+
+// Per-launch scratch (traversal-stack overflow, wavefront buffers) is keyed on the STREAM a launch goes to: launches on one stream
+// are ordered and may share a buffer, launches on different streams may overlap and never do -- whatever order the caller uses
+// its streams in (it used to be launch count modulo the announced number in flight, which was only safe for strict round-robin).
+static int scratch_slot(trg_ctx *c) {
+    if (c->stream == c->own_stream) return 0;
+    for (int k = 1; k < c->slots_used; ++k)
+        if (c->slot_stream[k] == c->stream) return k;
+    if (c->slots_used >= trg_ctx::kScratchSlots) return -1;
+    c->slot_stream[c->slots_used] = c->stream;
+    return c->slots_used++;
+}
 
 // trg_load_scene with TRG_OPT_GPU_BUILD: LBVH on the device (trg_build.hip), 4-wide nodes only (never LDS-staged).
 static int load_scene_gpu_build(trg_ctx *c, const float *pos, const float *nrm, const float *col, const uint32_t *idx,
@@ -548,6 +562,8 @@ int trg_render(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces,
     if ((uint64_t)frame_begin + spp > 0xFFFFFFFFull) return fail(c, TRG_ERR_INVALID, "trg_render: frame range overflows");
     if (spp == 0 || rows == 0) { c->last_ms = 0.0; return TRG_OK; }
     HIPCHK(c, hipSetDevice(c->device));
+    const int slot = scratch_slot(c);
+    if (slot < 0) return fail(c, TRG_ERR_RANGE, "trg_render: more than %d different streams used with this context", trg_ctx::kScratchSlots - 1);
     int kernel = c->opt_kernel;
     if (kernel == TRG_KERNEL_AUTO) {
         LdsPlan probe;
@@ -556,7 +572,7 @@ int trg_render(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces,
     }
     if (kernel == TRG_KERNEL_WAVEFRONT) {
         if (c->opt_timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-        if (int rc = render_wavefront(c, frame_begin, spp, bounces, row0, rows, (int)(c->launches % (uint32_t)c->opt_in_flight))) return rc;
+        if (int rc = render_wavefront(c, frame_begin, spp, bounces, row0, rows, slot)) return rc;
         c->renders++; c->launches++; c->last_fsplit = 1; c->last_kernel = TRG_KERNEL_WAVEFRONT;
         if (c->opt_timing) {
             HIPCHK(c, hipEventRecord(c->ev1, c->stream));
@@ -593,7 +609,7 @@ int trg_render(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces,
     const uint32_t tiles_y = (rows + tile_h - 1) / tile_h;
     if ((uint64_t)p.tiles_x * tiles_y > 0x7FFFFFFFull) return fail(c, TRG_ERR_RANGE, "trg_render: grid too large");
     const uint32_t grid = p.tiles_x * tiles_y;
-    if (int rc = ensure_stack_scratch(c, plan, (uint64_t)grid * kBlock, p.stack, (int)(c->launches % (uint32_t)c->opt_in_flight))) return rc;
+    if (int rc = ensure_stack_scratch(c, plan, (uint64_t)grid * kBlock, p.stack, slot)) return rc;
 
     if (c->opt_timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     hipError_t e;
@@ -836,7 +852,9 @@ int trg_trace(trg_ctx *c, const trg_ray *rays, size_t n, int any_hit, void *out)
     HIPCHK(c, hipMemcpyAsync(dr.p, rays, n * sizeof(trg_ray), hipMemcpyHostToDevice, c->stream));
     TraceParams p{};
     p.sc = c->sc; p.rays = static_cast<const trg_ray *>(dr.p); p.out = dout.p; p.n = (uint32_t)n; p.stack_off = plan.stack_off;
-    if (int rc = ensure_stack_scratch(c, plan, (uint64_t)((n + kBlock - 1) / kBlock) * kBlock, p.stack)) return rc;
+    const int slot = scratch_slot(c);
+    if (slot < 0) return fail(c, TRG_ERR_RANGE, "trg_trace: more than %d different streams used with this context", trg_ctx::kScratchSlots - 1);
+    if (int rc = ensure_stack_scratch(c, plan, (uint64_t)((n + kBlock - 1) / kBlock) * kBlock, p.stack, slot)) return rc;
     hipError_t e = c->opt_strict ? launch_trace_strict(p, plan.lds_scene, any_hit != 0, plan.total, c->stream)
                                  : launch_trace_fast(p, plan.lds_scene, any_hit != 0, plan.total, c->stream);
     if (e != hipSuccess) return fail(c, TRG_ERR_DEVICE, "trg_trace: launch failed: %s", hipGetErrorString(e));
