@@ -10,10 +10,13 @@ import sys
 
 out = sys.argv[1]
 cfgs = sys.argv[2:] or ["c2", "c4"]
-try:
-    commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
-except Exception:
-    commit = ""
+import os
+commit = os.environ.get("TRG_COMMIT", "")
+if not commit:
+    try:
+        commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except Exception:
+        commit = ""
 summary = {}
 for cfg in cfgs:
     counters = {}
@@ -51,18 +54,23 @@ for cfg in cfgs:
     if counters:
         kname = max(counters, key=lambda k: max(v["launches"] for v in counters[k].values()))
         c = {n: v["mean"] for n, v in counters[kname].items()}
-        fetch = c.get("FETCH_SIZE", 0.0) * 1024.0   # rocprofv3 reports KiB
+        # FETCH_SIZE: rocprofv3 reports KiB and, on gfx950, tallies every 128-byte memory-side read request at 64 bytes
+        # (TCC_BUBBLE reads 0): profiles/r02/fetch_calibration.md -- x2 for every access shape.  WRITE_SIZE is exact.
+        fetch_raw = c.get("FETCH_SIZE", 0.0) * 1024.0
+        fetch = 2.0 * fetch_raw
         write = c.get("WRITE_SIZE", 0.0) * 1024.0
+        dram32 = c.get("TCC_EA0_RDREQ_DRAM_32B_sum")
         rec = {"kernel": kname, "commit": commit,
                "valu_insts_per_launch": c.get("SQ_INSTS_VALU"), "salu_insts_per_launch": c.get("SQ_INSTS_SALU"), "lds_insts_per_launch": c.get("SQ_INSTS_LDS"),
                "lanes_active_per_valu_inst": (c["SQ_THREAD_CYCLES_VALU"] / c["SQ_INSTS_VALU"]) if c.get("SQ_THREAD_CYCLES_VALU") and c.get("SQ_INSTS_VALU") else None,
-               "fetch_bytes": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
+               "fetch_bytes": fetch, "fetch_size_raw_bytes": fetch_raw, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
+               "rdreq_dram_32b_bytes": (dram32 * 32.0) if dram32 else None,
                "wave_cycles": c.get("SQ_WAVE_CYCLES"), "wait_any_cycles": c.get("SQ_WAIT_ANY"), "busy_cycles": c.get("SQ_BUSY_CYCLES"),
                "lds_idx_active": c.get("SQ_LDS_IDX_ACTIVE"), "lds_bank_conflict": c.get("SQ_LDS_BANK_CONFLICT"),
                "tcc_hit": c.get("TCC_HIT_sum"), "tcc_miss": c.get("TCC_MISS_sum"), "ta_busy_avr": c.get("TA_BUSY_avr"), "gui_active": c.get("GRBM_GUI_ACTIVE"),
                "alone_mean_ms": summary[cfg].get("launches", {}).get("alone_mean_ms"),
                "source": "scripts/profile_round.sh at commit %s: one rocprofv3 --pmc pass per counter group of `python3 bench.py%s`, per-launch means; "
-                         "FETCH_SIZE/WRITE_SIZE in KiB x 1024, no width correction applied (profiles/%s: fetch_calibration)" % (commit, "" if cfg == "c2" else " --config " + cfg, "r02")}
+                         "fetch_bytes = 2 x FETCH_SIZE x 1024 (gfx950 counts each 128-byte request as 64: profiles/%s/fetch_calibration.md), write_bytes = WRITE_SIZE x 1024" % (commit, "" if cfg == "c2" else " --config " + cfg, "r02")}
         json.dump(rec, open(f"{out}/{cfg}_counters.json", "w"), indent=1)
         print(cfg, json.dumps({k: (round(v) if isinstance(v, float) and v > 100 else v) for k, v in rec.items() if k not in ("source",)}))
     for r in stats[:2]:

@@ -21,6 +21,7 @@ for cfg in $WHAT; do
   run ${cfg}_write --pmc WRITE_SIZE --output-format csv -d "$OUT/${cfg}_write" -- $CMD
   run ${cfg}_sq1 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --output-format csv -d "$OUT/${cfg}_sq1" -- $CMD
   run ${cfg}_sq2 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d "$OUT/${cfg}_sq2" -- $CMD
+  run ${cfg}_dram --pmc TCC_EA0_RDREQ_DRAM_32B_sum TCC_EA0_RDREQ_sum --output-format csv -d "$OUT/${cfg}_dram" -- $CMD
   if [ "$cfg" = c4 ]; then
     run c4_tcc --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d "$OUT/c4_tcc" -- $CMD
     run c4_ta --pmc TA_BUSY_avr TA_TA_BUSY_sum GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT --output-format csv -d "$OUT/c4_ta" -- $CMD

@@ -11,7 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
-HIP_SO = os.path.join(LIB_DIR, "libtoyraygun_hip.so")
+HIP_SO = os.environ.get("TRG_HIP_SO") or os.path.join(LIB_DIR, "libtoyraygun_hip.so")   # TRG_HIP_SO: an experimental build (scripts/exp_build.sh)
 
 OK = 0
 ERR_INVALID, ERR_NOMEM, ERR_DEVICE, ERR_NODEV, ERR_RANGE = -22, -12, -5, -19, -34

@@ -119,7 +119,9 @@ static bool plan_lds_as(const trg_ctx *c, LdsPlan &p, bool lds_scene, bool pool,
     p.lds_scene = lds_scene;
     uint32_t levels;
     if (p.lds_scene) {
-        levels = c->bvh_depth + 3;      // the sentinel at level 0 + BVH2, near child first: at most one pending entry per level + the scratch slot above the top
+        // the sentinel at level 0 + BVH2, near child first: at most one pending entry per level + the scratch slot above the top;
+        // 4-wide LDS tree: up to three pending entries per level (its branch-free pushes write at most into those slots)
+        levels = kWideLds ? 3 * c->bvh_depth4 + 2 : c->bvh_depth + 3;
         p.klds = levels;
     } else {
         levels = kWideHbm ? 3 * c->bvh_depth4 + 3 : c->bvh_depth + 3;  // the sentinel at level 0; 4-wide: up to three pending entries per level
@@ -412,18 +414,37 @@ int trg_load_scene(trg_ctx *c, const float *pos, const float *nrm, const float *
     // [ BVH2 nodes | triangle records | normals | colours | material ids ] [ quantised 4-wide nodes | 128 B pad ]
     // The first bracket is what a workgroup stages into LDS when it is small enough; scenes that can only be
     // traversed from HBM skip the BVH2 nodes when the HBM kernels use the 4-wide tree.
-    const uint64_t small_bytes = (uint64_t)bvh.n_nodes * kLdsNodeBytes + (uint64_t)nt_rec * 48u + (uint64_t)attr_tris * 76u + 64u + kHtabBytes;
+    const uint64_t small_bytes = (uint64_t)(kWideLds ? bvh.n_nodes4 : bvh.n_nodes) * kLdsNodeBytes + (uint64_t)nt_rec * 48u + (uint64_t)attr_tris * 76u + 64u + kHtabBytes;
     const bool lds_candidate = small_bytes <= kMaxLdsScene;
     const bool keep_bvh2 = lds_candidate || !kWideHbm;
     SceneDesc sc{};
-    sc.n_nodes = keep_bvh2 ? bvh.n_nodes : 0u; sc.n_tris = n_tris;
+    sc.n_nodes = keep_bvh2 ? ((kWideLds && lds_candidate) ? bvh.n_nodes4 : bvh.n_nodes) : 0u; sc.n_tris = n_tris;
     const uint32_t node_bytes = lds_candidate ? kLdsNodeBytes : 64u;
     sc.n_nodes4 = kWideHbm ? bvh.n_nodes4 : 0u;
     uint64_t total = 0;
     if (!plan_scene_layout(sc.n_nodes, node_bytes, nt_rec, attr_tris, lds_candidate, sc.n_nodes4, sc, total))
         return fail(c, TRG_ERR_RANGE, "trg_load_scene: scene needs %llu B on the device (limit 4 GiB)", (unsigned long long)total);
     std::vector<unsigned char> host(sc.blob_bytes, 0);
-    if (sc.n_nodes && lds_candidate && kSignedLds) {
+    if (sc.n_nodes && lds_candidate && kWideLds) {
+        // sign-ordered 4-wide LDS nodes (trav_node4_step_lds): per axis [lo x4 | hi x4 | lo x4] = 48 bytes, so that a 32-byte read at
+        // +0 gives (near, far) for a positive direction and at +16 for a negative one; then the four children (inner: byte offset
+        // of the node; leaf code < 0; unused slot: 0x80000000 behind an inverted box that no ray enters)
+        for (uint32_t i = 0; i < sc.n_nodes; ++i) {
+            const F4 *n = &bvh.nodes4[(size_t)i * 8];   // lo.x hi.x lo.y hi.y lo.z hi.z children pad
+            float *o = reinterpret_cast<float *>(&host[sc.off_nodes + (size_t)i * kLdsNodeBytes]);
+            int32_t ch[4];
+            memcpy(ch, &n[6].x, 16);
+            for (int a = 0; a < 3; ++a) {
+                float lo[4] = { n[a * 2].x, n[a * 2].y, n[a * 2].z, n[a * 2].w }, hi[4] = { n[a * 2 + 1].x, n[a * 2 + 1].y, n[a * 2 + 1].z, n[a * 2 + 1].w };
+                for (int k = 0; k < 4; ++k)
+                    if (ch[k] == (int32_t)0x80000000) { lo[k] = INFINITY; hi[k] = -INFINITY; }
+                memcpy(o + a * 12, lo, 16); memcpy(o + a * 12 + 4, hi, 16); memcpy(o + a * 12 + 8, lo, 16);
+            }
+            for (int k = 0; k < 4; ++k)
+                if (ch[k] >= 0) ch[k] *= (int32_t)kLdsNodeBytes;
+            memcpy(o + 36, ch, 16);
+        }
+    } else if (sc.n_nodes && lds_candidate && kSignedLds) {
         // sign-ordered LDS nodes (trav_node_step_signed): per axis the slab planes of both children as
         // (lo_a, hi_a, lo_b, hi_b) and swapped; children of inner nodes become byte offsets
         for (uint32_t i = 0; i < sc.n_nodes; ++i) {

@@ -586,7 +586,7 @@ TRG_DEV float clamp_away_from_zero(float v) {
     const uint32_t mag = b & 0x7fffffffu, tiny = 0x0da24260u;  // 1e-30f
     return __uint_as_float((b & 0x80000000u) | (mag < tiny ? tiny : mag));
 }
-TRG_DEV void trav_begin(Trav &tv, V3 o, V3 d, float tmax, uint32_t rmask, int sp0, uint32_t node_base = 0u) {
+TRG_DEV void trav_begin(Trav &tv, V3 o, V3 d, float tmax, uint32_t rmask, int sp0, uint32_t node_base = 0u, bool wide_lds = false) {
     // Reciprocal direction with zero components pushed to +-1e-30: the slab products stay finite (no
     // inf - inf = NaN whose fmin/fmax would pick the wrong endpoint), and a ray that moves 1e-30 per
     // unit t along an axis is parallel to the slab for every practical purpose.
@@ -602,9 +602,15 @@ TRG_DEV void trav_begin(Trav &tv, V3 o, V3 d, float tmax, uint32_t rmask, int sp
     tv.node = 0; tv.sp = sp0;  // sp0 = stk.first(): the empty stack
     // sign-ordered LDS nodes: LDS address of the slab copy to read per axis, for node 0 (node_base = LDS address of the
     // node array).  X+ X- at +0 / +16, Y+ Y- at +32 / +48, Z+ Z- at +64 / +96 (each Z copy is followed by the child pair).
-    tv.sx = (int)(node_base + ((__float_as_uint(dx) >> 31) << 4));
-    tv.sy = (int)(node_base + 32u + ((__float_as_uint(dy) >> 31) << 4));
-    tv.sz = (int)(node_base + 64u + ((__float_as_uint(dz) >> 31) << 5));
+    if (wide_lds) {   // 4-wide LDS nodes: [lo4 | hi4 | lo4] per axis at +0 / +48 / +96, read at +16 for a negative direction
+        tv.sx = (int)(node_base + ((__float_as_uint(dx) >> 31) << 4));
+        tv.sy = (int)(node_base + 48u + ((__float_as_uint(dy) >> 31) << 4));
+        tv.sz = (int)(node_base + 96u + ((__float_as_uint(dz) >> 31) << 4));
+    } else {
+        tv.sx = (int)(node_base + ((__float_as_uint(dx) >> 31) << 4));
+        tv.sy = (int)(node_base + 32u + ((__float_as_uint(dy) >> 31) << 4));
+        tv.sz = (int)(node_base + 64u + ((__float_as_uint(dz) >> 31) << 5));
+    }
 }
 
 // One inner-node step: test both child boxes, descend into the nearer hit child, push the other, or pop.
@@ -686,9 +692,9 @@ TRG_DEV void trav_node_step_signed(const SceneView &sc, Trav &tv, STK stk, Count
     tv.node = next; tv.sp = sp;
 }
 
-template <bool COUNT, int BLOCK, bool SIGNED = false, typename STK>
+template <bool COUNT, int BLOCK, int LMODE = 0, typename STK>
 TRG_DEV void trav_node_step(const SceneView &sc, Trav &tv, STK stk, Counters &cnt) {
-    if (SIGNED) { trav_node_step_signed<COUNT, BLOCK>(sc, tv, stk, cnt); return; }
+    if (LMODE == 4) { trav_node_step_signed<COUNT, BLOCK>(sc, tv, stk, cnt); return; }
     const v4f *n = sc.nodes + tv.node * 4;
     const v4f n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
     trav_node_math<COUNT, BLOCK>(n0, n1, n2, n3, tv, stk, cnt);
@@ -746,6 +752,28 @@ TRG_DEV bool trav_leaf_step(const SceneView &sc, Trav &tv, bool any, STK stk, Co
         (ca) = cc_;                                       \
     }
 
+// Common tail of the 4-wide node steps: t_k = entry distance of child k or +inf when the ray does not enter it.  Sorts the four
+// (distance, child) pairs nearest first (5-comparator network; misses sink to the end), pushes the farther hits, continues with
+// the nearest or pops.
+template <int BLOCK, typename STK>
+TRG_DEV void wide_select(float t0, float t1, float t2, float t3, int c0, int c1, int c2, int c3, Trav &tv, STK stk) {
+    TRG_CSWAP(t0, c0, t1, c1) TRG_CSWAP(t2, c2, t3, c3) TRG_CSWAP(t0, c0, t2, c2) TRG_CSWAP(t1, c1, t3, c3) TRG_CSWAP(t1, c1, t2, c2)
+    const bool h4 = t3 < INFINITY, h3 = t2 < INFINITY, h2 = t1 < INFINITY, h0 = !(t0 < INFINITY);  // sorted: t_k finite <=> more than k hits
+    int sp = tv.sp;
+    if (h4) stk.push(sp, c3);
+    sp += h4 ? STK::unit : 0;
+    if (h3) stk.push(sp, c2);
+    sp += h3 ? STK::unit : 0;
+    if (h2) stk.push(sp, c1);
+    sp += h2 ? STK::unit : 0;
+    int next = c0;
+    if (h0) {
+        sp -= STK::unit;
+        next = stk.pop(sp);  // the sentinel at level 0 when nothing is pending
+    }
+    tv.node = next; tv.sp = sp;
+}
+
 // One 4-wide step on a QUANTISED node (q4node.h): 64 bytes = four 16-byte loads.  plane = origin + q * scale, so
 // t = (plane - o) / d = q * (scale / d) + (origin / d - o / d): two ray-dependent constants per axis (A, B), then one
 // v_cvt_f32_ubyteN + one fma per plane.  The near / far plane dwords are picked by the sign of the direction (one
@@ -774,23 +802,37 @@ TRG_DEV void trav_node4_math(const v4f q0, const v4f q1, const v4f q2, const v4f
         // needs no check of its own (-4 % on C4)
         t[k] = (tmin <= tmax) ? tmin : INFINITY;
     }
-    float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
-    // sort the four (entry distance, child) pairs, nearest first (5-comparator network); misses sink to the end
-    TRG_CSWAP(t0, c0, t1, c1) TRG_CSWAP(t2, c2, t3, c3) TRG_CSWAP(t0, c0, t2, c2) TRG_CSWAP(t1, c1, t3, c3) TRG_CSWAP(t1, c1, t2, c2)
-    const bool h4 = t3 < INFINITY, h3 = t2 < INFINITY, h2 = t1 < INFINITY, h0 = !(t0 < INFINITY);  // sorted: t_k finite <=> more than k hits
-    int sp = tv.sp;
-    if (h4) stk.push(sp, c3);
-    sp += h4 ? STK::unit : 0;
-    if (h3) stk.push(sp, c2);
-    sp += h3 ? STK::unit : 0;
-    if (h2) stk.push(sp, c1);
-    sp += h2 ? STK::unit : 0;
-    int next = c0;
-    if (h0) {
-        sp -= STK::unit;
-        next = stk.pop(sp);  // the sentinel at level 0 when nothing is pending
+    wide_select<BLOCK>(t[0], t[1], t[2], t[3], c0, c1, c2, c3, tv, stk);
+}
+
+// One 4-wide step on a sign-ordered FLOAT node in LDS (TRG_TRAV_LDS == 5; trg_capi.cpp stages the layout): six 16-byte reads give
+// the near and far planes of the four children per axis in the order the ray meets them (the address carries the direction sign,
+// trav_begin), one more the children.  24 fma + 8 three-operand min/max + 8 min/max; any-hit rays skip the ordering.
+template <bool COUNT, int BLOCK, typename STK>
+TRG_DEV void trav_node4_step_lds(const SceneView &sc, Trav &tv, STK stk, Counters &cnt, uint32_t child_base) {
+    if (COUNT) { cnt.nodes += 2; if (mbcnt64(__ballot(1)) == 0) cnt.wnodes++; }
+    const v4f nx = *(const lds_v4f_t *)(uintptr_t)(uint32_t)(tv.node + tv.sx), fx = *(const lds_v4f_t *)(uintptr_t)(uint32_t)(tv.node + tv.sx + 16);
+    const v4f ny = *(const lds_v4f_t *)(uintptr_t)(uint32_t)(tv.node + tv.sy), fy = *(const lds_v4f_t *)(uintptr_t)(uint32_t)(tv.node + tv.sy + 16);
+    const v4f nz = *(const lds_v4f_t *)(uintptr_t)(uint32_t)(tv.node + tv.sz), fz = *(const lds_v4f_t *)(uintptr_t)(uint32_t)(tv.node + tv.sz + 16);
+    const v4f ch = *(const lds_v4f_t *)(uintptr_t)(uint32_t)(tv.node + child_base);
+    float t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float tnx = nx[k] * tv.idx - tv.oix, tfx = fx[k] * tv.idx - tv.oix;
+        const float tny = ny[k] * tv.idy - tv.oiy, tfy = fy[k] * tv.idy - tv.oiy;
+        const float tnz = nz[k] * tv.idz - tv.oiz, tfz = fz[k] * tv.idz - tv.oiz;
+        const float tmin = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
+        const float tmax = fminf(fminf(tfx, tfy), min_raw(tfz, tv.best));
+        t[k] = (tmin <= tmax) ? tmin : INFINITY;   // an unused slot has an inverted box: never entered
     }
-    tv.node = next; tv.sp = sp;
+    wide_select<BLOCK>(t[0], t[1], t[2], t[3], __float_as_int(ch.x), __float_as_int(ch.y), __float_as_int(ch.z), __float_as_int(ch.w), tv, stk);
+}
+
+// the inner-node step of the while-while schedules: BVH2 (0), sign-ordered BVH2 in LDS (4), sign-ordered 4-wide in LDS (5)
+template <bool COUNT, int BLOCK, int LMODE, typename STK>
+TRG_DEV void trav_inner_step(const SceneView &sc, Trav &tv, STK stk, Counters &cnt) {
+    if (LMODE == 5) trav_node4_step_lds<COUNT, BLOCK>(sc, tv, stk, cnt, (uint32_t)(uintptr_t)(const lds_v4f_t *)sc.nodes + 144u);
+    else trav_node_step<COUNT, BLOCK, LMODE>(sc, tv, stk, cnt);
 }
 
 // one unit of work per lane per iteration on the 4-wide tree: a quantised node (four 16-byte loads = 64 bytes)
@@ -858,7 +900,7 @@ TRG_DEV void trav_step_unified(const SceneView &sc, Trav &tv, bool any, STK stk,
 // LDS address of the node array when the traversal reads sign-ordered LDS nodes (UNIFIED = false selects the LDS schedule)
 template <bool UNIFIED>
 TRG_DEV uint32_t lds_node_base(const SceneView &sc) {
-    return (!UNIFIED && TRG_TRAV_LDS == 4) ? (uint32_t)(uintptr_t)(const lds_v4f_t *)sc.nodes : 0u;
+    return (!UNIFIED && (TRG_TRAV_LDS == 4 || TRG_TRAV_LDS == 5)) ? (uint32_t)(uintptr_t)(const lds_v4f_t *)sc.nodes : 0u;
 }
 
 // Nearest-hit (ANY=false) or any-hit (ANY=true) query for one ray per lane.
@@ -870,7 +912,7 @@ TRG_DEV bool traverse(const SceneView &sc, V3 o, V3 d, float tmax_ray, uint32_t 
     return !ANY;
 #endif
     Trav tv;
-    trav_begin(tv, o, d, tmax_ray, rmask, stk.first(), lds_node_base<UNIFIED>(sc));
+    trav_begin(tv, o, d, tmax_ray, rmask, stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED && TRG_TRAV_LDS == 5);
     constexpr int mode = UNIFIED ? TRG_TRAV_HBM : TRG_TRAV_LDS;
     if (mode == 3) {
         while (tv.node != kNodeDone) trav_step_wide<COUNT, BLOCK>(sc, tv, ANY, stk, cnt);
@@ -878,7 +920,7 @@ TRG_DEV bool traverse(const SceneView &sc, V3 o, V3 d, float tmax_ray, uint32_t 
         while (tv.node != kNodeDone) trav_step_unified<COUNT, BLOCK>(sc, tv, ANY, stk, cnt);
     } else {
         for (;;) {
-            while (tv.node >= 0) trav_node_step<COUNT, BLOCK, mode == 4>(sc, tv, stk, cnt);
+            while (tv.node >= 0) trav_inner_step<COUNT, BLOCK, (mode >= 4 ? mode : 0)>(sc, tv, stk, cnt);
             if (tv.node == kNodeDone) break;
             if (trav_leaf_step<COUNT, BLOCK>(sc, tv, ANY, stk, cnt)) break;   // any-hit satisfied
             if (tv.node == kNodeDone) break;
@@ -900,7 +942,7 @@ TRG_DEV void traverse_pair(const SceneView &sc, V3 org, bool has_shadow, V3 sdir
     nhit.t = -1.0f; nhit.prim = -1; nhit.u = 0.0f; nhit.v = 0.0f;
     int phase = has_shadow ? 0 : (has_next ? 1 : 2);
     Trav tv;
-    trav_begin(tv, org, phase == 0 ? sdir : ndir, phase == 0 ? smax : INFINITY, phase == 0 ? 1u : nmask, stk.first(), lds_node_base<UNIFIED>(sc));
+    trav_begin(tv, org, phase == 0 ? sdir : ndir, phase == 0 ? smax : INFINITY, phase == 0 ? 1u : nmask, stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED && TRG_TRAV_LDS == 5);
     if (phase == 2) tv.node = kNodeDone;
     constexpr int mode = UNIFIED ? TRG_TRAV_HBM : TRG_TRAV_LDS;
     while (phase < 2) {
@@ -910,14 +952,14 @@ TRG_DEV void traverse_pair(const SceneView &sc, V3 org, bool has_shadow, V3 sdir
         } else if (mode == 1) {
             trav_step_unified<COUNT, BLOCK>(sc, tv, any, stk, cnt);
         } else {
-            while (tv.node >= 0) trav_node_step<COUNT, BLOCK, mode == 4>(sc, tv, stk, cnt);
+            while (tv.node >= 0) trav_inner_step<COUNT, BLOCK, (mode >= 4 ? mode : 0)>(sc, tv, stk, cnt);
             if (tv.node != kNodeDone && trav_leaf_step<COUNT, BLOCK>(sc, tv, any, stk, cnt)) tv.node = kNodeDone;
         }
         if (tv.node == kNodeDone) {
             if (phase == 0) {
                 occluded = tv.found;
                 phase = has_next ? 1 : 2;
-                if (phase == 1) trav_begin(tv, org, ndir, INFINITY, nmask, stk.first(), lds_node_base<UNIFIED>(sc));
+                if (phase == 1) trav_begin(tv, org, ndir, INFINITY, nmask, stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED && TRG_TRAV_LDS == 5);
             } else {
                 nhit = tv.hit; nfound = tv.found;
                 phase = 2;
@@ -960,7 +1002,7 @@ TRG_DEV void trace_queue(const SceneView &sc, const PoolView pv, const unsigned 
     bool busy = false, exhausted = false, any = false;
     uint32_t slot = 0;
     Trav tv;
-    trav_begin(tv, mk(0.0f, 0.0f, 0.0f), mk(0.0f, 0.0f, 1.0f), 0.0f, 0u, stk.first(), lds_node_base<UNIFIED>(sc));
+    trav_begin(tv, mk(0.0f, 0.0f, 0.0f), mk(0.0f, 0.0f, 1.0f), 0.0f, 0u, stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED && TRG_TRAV_LDS == 5);
     tv.node = kNodeDone;
     for (;;) {
         // ---- refill: idle lanes take the next list entries ----
@@ -980,7 +1022,7 @@ TRG_DEV void trace_queue(const SceneView &sc, const PoolView pv, const unsigned 
                 const v4f r0 = pv.R0[slot];  // the shadow ray starts where the next ray starts
                 const v4f r1 = any ? pv.SH[slot] : pv.R1[slot];
                 trav_begin(tv, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), any ? r1.w : r0.w,
-                           any ? 1u : (uint32_t)__float_as_int(r1.w), stk.first(), lds_node_base<UNIFIED>(sc));
+                           any ? 1u : (uint32_t)__float_as_int(r1.w), stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED && TRG_TRAV_LDS == 5);
                 busy = true;
             }
         }
@@ -993,7 +1035,7 @@ TRG_DEV void trace_queue(const SceneView &sc, const PoolView pv, const unsigned 
                 } else if (mode == 1) {
                     trav_step_unified<COUNT, BLOCK>(sc, tv, any, stk, cnt);
                 } else {
-                    while (tv.node >= 0) trav_node_step<COUNT, BLOCK, mode == 4>(sc, tv, stk, cnt);
+                    while (tv.node >= 0) trav_inner_step<COUNT, BLOCK, (mode >= 4 ? mode : 0)>(sc, tv, stk, cnt);
                     if (tv.node == kNodeDone) break;
                     if (trav_leaf_step<COUNT, BLOCK>(sc, tv, any, stk, cnt)) tv.node = kNodeDone;
                 }

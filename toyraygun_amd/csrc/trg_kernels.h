@@ -129,8 +129,9 @@ constexpr bool kWideHbm = (TRG_TRAV_HBM == 3);
 #define TRG_TRAV_LDS 4
 #endif
 constexpr bool kSignedLds = (TRG_TRAV_LDS == 4);
-constexpr uint32_t kLdsNodeBytes = kSignedLds ? 144u : 64u;
-static_assert(!kSignedLds || kWideHbm, "sign-ordered LDS nodes replace the BVH2 array: the HBM kernels must use the 4-wide tree");
+constexpr bool kWideLds = (TRG_TRAV_LDS == 5);   // sign-ordered 4-wide float nodes in LDS (160 bytes)
+constexpr uint32_t kLdsNodeBytes = kWideLds ? 160u : (kSignedLds ? 144u : 64u);
+static_assert(!(kSignedLds || kWideLds) || kWideHbm, "the LDS node layouts replace the BVH2 array: the HBM kernels must use the 4-wide tree");
 
 #define TRG_DECL_LAUNCHERS(SFX)                                                                                   \
     hipError_t launch_render_##SFX(const RenderParams &p, bool lds_scene, bool counters, uint32_t grid,          \

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(trg::kBlock, 8) void wf_trace_kernel(const trg::WfP
     bool busy = false, exhausted = false, any = false;
     uint32_t pid = 0;
     Trav tv;
-    trav_begin(tv, mk(0.0f, 0.0f, 0.0f), mk(0.0f, 0.0f, 1.0f), 0.0f, 0u, stk.first(), lds_node_base<UNIFIED>(sc));
+    trav_begin(tv, mk(0.0f, 0.0f, 0.0f), mk(0.0f, 0.0f, 1.0f), 0.0f, 0u, stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED && TRG_TRAV_LDS == 5);
     tv.node = kNodeDone;
     // This wavefront's reserved slice [cur, end) of the queue.  A slice is taken with ONE atomic on the queue head and then handed
     // out to idle lanes with a ballot / mbcnt prefix, no memory traffic: one word sustains only ~90 atomics per microsecond
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(trg::kBlock, 8) void wf_trace_kernel(const trg::WfP
                 const v4f r0 = wf_ld(&w.ray_o[pid]);
                 const v4f r1 = any ? wf_ld(&w.sh[pid]) : wf_ld(&w.ray_d[pid]);
                 trav_begin(tv, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), any ? r1.w : r0.w, any ? 1u : (uint32_t)__float_as_int(r1.w),
-                           stk.first(), lds_node_base<UNIFIED>(sc));
+                           stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED && TRG_TRAV_LDS == 5);
                 busy = true;
             }
             const uint32_t n_idle = (uint32_t)__popcll(idle);
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(trg::kBlock, 8) void wf_trace_kernel(const trg::WfP
                 } else if (mode == 1) {
                     trav_step_unified<COUNT, trg::kBlock>(sc, tv, any, stk, cnt);
                 } else {
-                    while (tv.node >= 0) trav_node_step<COUNT, trg::kBlock, mode == 4>(sc, tv, stk, cnt);
+                    while (tv.node >= 0) trav_inner_step<COUNT, trg::kBlock, (mode >= 4 ? mode : 0)>(sc, tv, stk, cnt);
                     if (tv.node == kNodeDone) break;
                     if (trav_leaf_step<COUNT, trg::kBlock>(sc, tv, any, stk, cnt)) tv.node = kNodeDone;
                 }
