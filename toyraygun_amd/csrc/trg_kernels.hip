@@ -18,6 +18,10 @@ using namespace trgdev;
 #define SFX(name) name##_fast
 #endif
 
+#ifndef TRG_UNIFORMS_AT_USE
+#define TRG_UNIFORMS_AT_USE 1
+#endif
+
 namespace SFX(trgk) {
 
 // Stage the scene blob into LDS (16-byte copies by the whole workgroup) or point at it in HBM.
@@ -121,14 +125,32 @@ struct PathCounters { uint32_t primary, bounce, shadow, shaded; };
 TRG_DEV uint32_t wave_count(bool pred) { return (uint32_t)__popcll(__ballot(pred)); }
 typedef __attribute__((address_space(3))) float lds_float_t;
 template <bool LDS_SCENE, bool COUNT, typename STK>
-TRG_DEV V3 path_radiance(const trg::RenderParams &p, const SceneView &sc, STK stk, uint32_t x, uint32_t y, uint32_t hidx, bool valid,
+TRG_DEV V3 path_radiance(const trg::RenderParams &p, const SceneView &sc, STK stk, uint32_t x, uint32_t y, uint32_t offset, uint32_t frame, bool valid,
                          V3 light_color, PathCounters &pc, Counters &cnt, lds_float_t *path_park = nullptr) {
+    // Halton index of this pixel-sample (Raytracing.metal:67: offset + uniforms.frameIndex, wraps mod 2^32).  `frame` is wave-uniform:
+    // the sum is re-formed where it is used instead of living in a VGPR of its own across the traversals.
+#define TRG_HIDX (offset + frame)
     V3 o, d;
     constexpr bool TAB = LDS_SCENE && !TRG_STRICT && TRG_HALTON_TABLES;  // Halton group tables staged with the scene
-    raygen<TAB>(p.u, x, y, hidx, o, d, sc.htab);
+    // The 176-byte uniform block is read from the kernel-argument segment WHERE IT IS USED (scalar loads, cached) through a pointer
+    // the optimiser cannot see through: loaded once at kernel entry its 44 dwords sat in SGPRs across every traversal, and with
+    // 80 (LDS scenes) / 96 (HBM scenes) SGPRs per wave about 60 of them were spilled to VGPR lanes and, from there, to scratch.
+#if TRG_UNIFORMS_AT_USE
+    typedef const __attribute__((address_space(4))) trg_uniforms cu_t;
+    cu_t *up = (cu_t *)__builtin_amdgcn_kernarg_segment_ptr();   // RenderParams::u is the first member
+    static_assert(offsetof(trg::RenderParams, u) == 0, "uniforms must lead the kernel arguments");
+    asm volatile("" : "+s"(up));
+#define TRG_U (*(const trg_uniforms *)up)
+#else
+#define TRG_U p.u
+#endif
+    raygen<TAB>(TRG_U, x, y, TRG_HIDX, o, d, sc.htab);
     V3 thr = mk(1.0f, 1.0f, 1.0f);  // ray.color
     V3 rad = mk(0.0f, 0.0f, 0.0f);  // the render target texel of this frame
-    uint32_t rmask = 3u;            // RAY_MASK_PRIMARY
+    // the ray mask is RAY_MASK_PRIMARY (3) until the first shading event and RAY_MASK_SECONDARY (1) afterwards (a path that only ever
+    // hit an invalid material keeps its primary ray): one bit per lane -- a lane mask in SGPRs -- instead of a VGPR
+    bool primary_ray = true;
+#define TRG_RMASK (primary_ray ? 3u : 1u)
     bool active = valid;
     pc.primary += wave_count(active);
 
@@ -138,12 +160,17 @@ TRG_DEV V3 path_radiance(const trg::RenderParams &p, const SceneView &sc, STK st
         for (uint32_t b = 0; b < p.bounces; ++b) {
             if (__ballot(active) == 0ull) break;  // whole wavefront terminated
             const bool last = (b + 1u == p.bounces);  // wave-uniform
+#if TRG_UNIFORMS_AT_USE
+            asm volatile("" : "+s"(up));   // the uniforms of this bounce's shading event are loaded after this point
+#endif
             if (b > 0) pc.bounce += wave_count(active);
             ShadeOut so; so.want_shadow = false; so.shaded = false;
             if (active) {
                 Hit h;
-                const bool found = traverse<false, COUNT, trg::kBlock, false>(sc, o, d, INFINITY, rmask, h, stk, cnt);
-                so = shade_event<TAB>(p.u, sc, h, found, b, last, hidx, o, d, thr, rad, rmask, active, light_color);
+                const bool found = traverse<false, COUNT, trg::kBlock, false>(sc, o, d, INFINITY, TRG_RMASK, h, stk, cnt);
+                uint32_t rmask = TRG_RMASK;
+                so = shade_event<TAB>(TRG_U, sc, h, found, b, last, TRG_HIDX, o, d, thr, rad, rmask, active, light_color);
+                primary_ray = rmask == 3u;
                 if (so.want_shadow) {
                     Hit sh;
                     const bool occluded = traverse<true, COUNT, trg::kBlock, false>(sc, o, so.sdir, so.smax, 1u, sh, stk, cnt);
@@ -160,12 +187,19 @@ TRG_DEV V3 path_radiance(const trg::RenderParams &p, const SceneView &sc, STK st
         // and the incoherent continuation rays give the wavefront nothing to overlap them with.)
         Hit h; h.t = -1.0f; h.prim = -1; h.u = 0.0f; h.v = 0.0f;
         bool found = false;
-        if (p.bounces > 0u && active) found = traverse<false, COUNT, trg::kBlock, true>(sc, o, d, INFINITY, rmask, h, stk, cnt);
+        if (p.bounces > 0u && active) found = traverse<false, COUNT, trg::kBlock, true>(sc, o, d, INFINITY, TRG_RMASK, h, stk, cnt);
         for (uint32_t b = 0; b < p.bounces; ++b) {
             if (__ballot(active) == 0ull) break;
             const bool last = (b + 1u == p.bounces);
+#if TRG_UNIFORMS_AT_USE
+            asm volatile("" : "+s"(up));
+#endif
             ShadeOut so; so.want_shadow = false; so.want_next = false; so.shaded = false; so.sdir = mk(0.0f, 0.0f, 1.0f); so.scol = mk(0.0f, 0.0f, 0.0f); so.smax = -1.0f;
-            if (active) so = shade_event<TAB>(p.u, sc, h, found, b, last, hidx, o, d, thr, rad, rmask, active, light_color);
+            if (active) {
+                uint32_t rmask = TRG_RMASK;
+                so = shade_event<TAB>(TRG_U, sc, h, found, b, last, TRG_HIDX, o, d, thr, rad, rmask, active, light_color);
+                primary_ray = rmask == 3u;
+            }
             pc.shaded += wave_count(so.shaded);
             pc.shadow += wave_count(so.want_shadow);
             pc.bounce += wave_count(so.want_next);
@@ -177,7 +211,7 @@ TRG_DEV V3 path_radiance(const trg::RenderParams &p, const SceneView &sc, STK st
                     path_park[0] = thr.x; path_park[trg::kBlock] = thr.y; path_park[2 * trg::kBlock] = thr.z;
                     path_park[3 * trg::kBlock] = rad.x; path_park[4 * trg::kBlock] = rad.y; path_park[5 * trg::kBlock] = rad.z;
                 }
-                traverse_pair<COUNT, trg::kBlock, true>(sc, o, so.want_shadow, so.sdir, so.smax, so.want_next, d, rmask, occluded, h, found, stk, cnt);
+                traverse_pair<COUNT, trg::kBlock, true>(sc, o, so.want_shadow, so.sdir, so.smax, so.want_next, d, TRG_RMASK, occluded, h, found, stk, cnt);
                 if (path_park) {
                     thr = mk(path_park[0], path_park[trg::kBlock], path_park[2 * trg::kBlock]);
                     rad = mk(path_park[3 * trg::kBlock], path_park[4 * trg::kBlock], path_park[5 * trg::kBlock]);
@@ -187,6 +221,9 @@ TRG_DEV V3 path_radiance(const trg::RenderParams &p, const SceneView &sc, STK st
         }
     }
     return rad;
+#undef TRG_HIDX
+#undef TRG_RMASK
+#undef TRG_U
 }
 
 // minimum waves per SIMD the register allocator must leave room for.  Scene in LDS: 8 (at most 64 VGPRs; VALU-bound,
@@ -244,14 +281,13 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES : TRG_EXP_WA
     const V3 light_color = mk(p.u.light_color[0], p.u.light_color[1], p.u.light_color[2]);
 
     for (uint32_t f = p.frame_begin; f < p.frame_begin + p.spp; ++f) {
-        const uint32_t hidx = offset + f;  // Raytracing.metal:67: offset + uniforms.frameIndex (wraps mod 2^32)
         // the lane index is re-read every frame (an opaque v_mbcnt pair): otherwise LICM hoists the pixel coordinates and
         // raygen's per-pixel products out of the frame loop, values that then live in VGPRs across every traversal of every
         // frame and were spilled to scratch at 8 waves/SIMD (profiles/r01: 13 scratch stores per pixel = the 3.4x write
         // amplification, 8 scratch reloads per frame).  Recomputing them costs a dozen VALU instructions per frame.
         const uint32_t lane_f = lane_id_opaque();
         const uint32_t xf = x0 + (lane_f & 7), yf = y0 + (lane_f >> 3);
-        const V3 rad = path_radiance<LDS_SCENE, COUNT>(p, sc, stk, xf, yf, hidx, valid, light_color, pc, cnt, path_park);
+        const V3 rad = path_radiance<LDS_SCENE, COUNT>(p, sc, stk, xf, yf, offset, f, valid, light_color, pc, cnt, path_park);
         if (PARK) acc = mk(park[0], park[trg::kBlock], park[2 * trg::kBlock]);
         // Accumulate.metal:19-39
         if (f == 0) {
@@ -342,8 +378,7 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES_FP : TRG_EXP
         for (uint32_t r = 0; r < p.fp_rounds; ++r) {
             const uint64_t i = rel + (uint64_t)r * F + fl;
             if (i >= p.spp) break;   // wave-uniform
-            const uint32_t hidx = offset + p.frame_begin + (uint32_t)i;  // Raytracing.metal:67
-            const V3 rad = path_radiance<LDS_SCENE, COUNT>(p, sc, stk, x, y, hidx, valid, light_color, pc, cnt);
+            const V3 rad = path_radiance<LDS_SCENE, COUNT>(p, sc, stk, x, y, offset, p.frame_begin + (uint32_t)i, valid, light_color, pc, cnt);
             float *slot = park + (size_t)(r * F + fl) * 3u * npx + mypx;
             slot[0] = rad.x; slot[npx] = rad.y; slot[2u * npx] = rad.z;
         }
