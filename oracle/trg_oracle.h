@@ -6,15 +6,18 @@
  * and bench.py's cpu_baseline leg may load this library; the product path
  * (toyraygun_amd/csrc) never links, includes or calls it.
  *
- * PARITY STATUS: "parity unpinned".
+ * PARITY STATUS: geometry pinned, arithmetic "parity unpinned".
  *   The reference has no tests, golden vectors or CPU render path,
  *   its intersector is closed vendor code (MPS / DXR) and four bx matrix
  *   functions exist only as prebuilt Mach-O / COFF objects.  The reference's own
  *   shader sources are MSL and need <metal_stdlib>/<simd/simd.h>, which this image
  *   lacks; building them would need stand-in headers, so there is no oracle/_ref.
  *   Every function below cites the reference file:line it restates.  The only
- *   reference OUTPUT available is img/screenshot_metal.png (a weak visual pin,
- *   see tests/test_screenshot_pin.py).
+ *   reference OUTPUTS are its two README screenshots: tests/test_screenshot_pin.py
+ *   pins this restatement's camera, scene matrices, flattening, raygen and image
+ *   orientation against both to 0.5 pixel on ~110 step edges (and fails on a 0.5 %
+ *   field-of-view error); the intersector's arithmetic, sin/cos rounding and the
+ *   shading values have no reference vector and stay unpinned.
  *
  * Floating-point contract of this restatement: IEEE binary32, round-to-nearest,
  * NO contraction (built with -ffp-contract=off), expressions evaluated exactly
