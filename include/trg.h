@@ -91,6 +91,11 @@ enum trg_option {
                                  streams (at most 16): the automatic frame split then favours throughput (the overlap hides a launch's tail).
                                  Per-launch scratch is keyed on the stream (trg_set_stream), so launches on different streams never share
                                  any, in whatever order the streams are used; at most 15 streams besides the context's own */
+    TRG_OPT_TAIL_BOUNCE = 9,  /* TRG_KERNEL_DIRECT on a scene staged in LDS: K > 0 = the megakernel stops after bounce K-1, the paths that go on are
+                                 compacted into per-wavefront queues in HBM (ballot / prefix, no atomics) and a second launch runs bounces
+                                 K.. with every lane live again (same result bit for bit; pays when paths die over many bounces: C3).
+                                 0 = never; -1 (default) = K = 2 when the launch has 4 bounces or more */
+    TRG_OPT_TAIL_LEVELS = 10, /* 0 (default): the tail launches re-compact every second bounce after K; 1: one compaction at K only */
     TRG_OPT_FRAME_SPLIT = 7   /* TRG_KERNEL_DIRECT only: frame lanes per workgroup. 1: a pixel's frames run one after the other in one
                                  lane; 2 or 4: that many wavefronts share a pixel's frames (same result bit for bit; fills the chip
                                  when the pixel grid alone does not -- small windows, row bands of a multi-GPU job);

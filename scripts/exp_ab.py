@@ -3,7 +3,8 @@ python scripts/exp_ab.py <config: c2|c3|c4|c2b8> <variant|shipped> ...  -> launc
 step with four frames in flight, rays from the in-kernel counters."""
 import os, sys, time, subprocess
 sys.path.insert(0, ".")
-CFG = {"c2": (1920, 1080, 16, 3, "box"), "c3": (1920, 1080, 64, 8, "box"), "c4": (1920, 1080, 16, 3, "lattice"), "c2b8": (1920, 1080, 16, 8, "box")}
+CFG = {"c2": (1920, 1080, 16, 3, "box"), "c3": (1920, 1080, 64, 8, "box"), "c4": (1920, 1080, 16, 3, "lattice"), "c2b8": (1920, 1080, 16, 8, "box"),
+       "c2b4": (1920, 1080, 16, 4, "box"), "c2b5": (1920, 1080, 16, 5, "box"), "c2b6": (1920, 1080, 16, 6, "box")}
 if sys.argv[1].startswith("--one="):
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     from toyraygun_amd import capi

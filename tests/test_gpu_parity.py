@@ -1315,3 +1315,49 @@ def test_textured_scene_parity(capi, O, nu, nv, in_lds):
     finally:
         O.set_trig_mode(O.TRIG_LIBM)
         c.close()
+
+
+@pytest.mark.parametrize("k,bounces,spp", [(1, 4, 5), (3, 8, 37), (2, 15, 3), (7, 8, 18)])
+def test_tail_compaction_is_bit_exact(capi, O, cornell, k, bounces, spp):
+    """TRG_OPT_TAIL_BOUNCE (trg_tail.inc.h): the megakernel stops after bounce K-1, live paths are compacted into per-wavefront
+    queues (ballot / prefix) and a second launch runs the deeper bounces with every lane live.  Same arithmetic per path in the same
+    order: the strict build equals the oracle and the plain direct kernel bit for bit -- for frame counts that do not fill the
+    16-frame chunks, for a launch continued from an earlier average, for row bands, with textures absent -- and counts the same rays."""
+    w, h = 200, 150
+    off = O.pixel_offsets(w, h)
+    O.set_trig_mode(O.TRIG_PORTABLE)
+    ref, rst = O.render(cornell, w, h, spp, bounces, offsets=off)
+    O.set_trig_mode(O.TRIG_LIBM)
+    c = make_ctx(O, cornell, w, h, offsets=off)
+    try:
+        c.set_option(capi.OPT_STRICT, 1)
+        c.set_option(capi.OPT_TAIL_BOUNCE, k)
+        c.reset_stats()
+        c.render(0, spp, bounces)
+        st = c.stats()
+        assert np.array_equal(_bits(c.read_accum()), _bits(ref)) and st.rays == rst.rays and st.shaded_hits == rst.shaded_hits
+        # continuation + bands: frames [0, a) on the whole image, then [a, spp) in three bands
+        a = max(1, spp // 3)
+        c.render(0, a, bounces)
+        for r0, n in ((0, 50), (50, 63), (113, 37)):
+            c.render(a, spp - a, bounces, r0, n)
+        assert np.array_equal(_bits(c.read_accum()), _bits(ref))
+        # off = the plain kernel; auto picks it for deep paths only
+        c.set_option(capi.OPT_TAIL_BOUNCE, 0)
+        c.render(0, spp, bounces)
+        assert np.array_equal(_bits(c.read_accum()), _bits(ref))
+        c.set_option(capi.OPT_TAIL_BOUNCE, -1)
+        c.render(0, spp, bounces)
+        assert np.array_equal(_bits(c.read_accum()), _bits(ref))
+        # shipped build: within tolerance of the libm oracle
+        ref_lib, _ = O.render(cornell, w, h, spp, bounces, offsets=off)
+        c.set_option(capi.OPT_STRICT, 0)
+        c.set_option(capi.OPT_TAIL_BOUNCE, k)
+        c.render(0, spp, bounces)
+        rmse, frac_ok, worst = image_metrics(c.read_accum(), ref_lib)
+        assert rmse <= TOL_RMSE and frac_ok >= TOL_FRAC, (rmse, frac_ok, worst)
+        with pytest.raises(capi.TrgError):
+            c.set_option(capi.OPT_TAIL_BOUNCE, 99)
+    finally:
+        O.set_trig_mode(O.TRIG_LIBM)
+        c.close()

@@ -73,6 +73,13 @@ struct RenderParams {
                                    // render_fp_kernel: byte offset of the parked per-frame radiances
     TexDesc tex;
     uint32_t acc_off;              // render_kernel on an HBM-resident scene: byte offset of the parked running average (3 x kBlock floats)
+    // tail compaction (trg_tail.inc.h): bounces >= tail_k of the frames of a chunk run in a second launch on compacted paths
+    uint32_t tail_k, tail_k_end, tail_cap, tail_band_pixels;   // this launch runs bounces [tail_k, tail_k_end) (the head: [0, tail_k))
+    void *tail_queue;              // float4[3] x tail_cap entries per head wavefront: the queue this launch reads (tail) / writes (head)
+    uint32_t *tail_count;          // entries per head wavefront
+    void *tail_queue_out;          // a tail launch that stops before the last bounce compacts its survivors into this queue
+    uint32_t *tail_count_out;
+    void *tail_radbuf;             // float4 [frames of the chunk][pixels of the band]
     uint32_t fsplit, fp_rounds;    // render_fp_kernel: frame lanes per workgroup (2 or 4), rounds parked per fold
     StackDesc stack;
 };
@@ -140,6 +147,9 @@ static_assert(!(kSignedLds || kWideLds) || kWideHbm, "the LDS node layouts repla
                                         size_t lds_bytes, hipStream_t s);                                        \
     hipError_t launch_render_fp_##SFX(const RenderParams &p, bool lds_scene, bool counters, uint32_t grid,       \
                                       size_t lds_bytes, hipStream_t s);                                          \
+    hipError_t launch_render_head_##SFX(const RenderParams &p, bool counters, uint32_t grid, size_t lds_bytes, hipStream_t s); \
+    hipError_t launch_render_tail_##SFX(const RenderParams &p, bool counters, uint32_t grid, size_t lds_bytes, hipStream_t s); \
+    hipError_t launch_tail_accumulate_##SFX(const RenderParams &p, hipStream_t s);                               \
     hipError_t launch_wf_raygen_##SFX(const WfParams &p, hipStream_t s);                                         \
     hipError_t launch_wf_trace_##SFX(const WfParams &p, bool lds_scene, bool counters, uint32_t grid, size_t lds_bytes, \
                                      hipStream_t s);                                                             \

@@ -611,6 +611,7 @@ __global__ __launch_bounds__(trg::kBlock) void render_pool_kernel(const trg::Ren
 }
 
 #include "trg_wavefront.inc.h"
+#include "trg_tail.inc.h"
 
 // ---- a7 / a12 in isolation: one ray per thread ----
 template <bool LDS_SCENE, bool ANY>
@@ -750,6 +751,20 @@ hipError_t SFX(launch_render_fp)(const RenderParams &p, bool lds_scene, bool cou
     return launch_big_lds(render_fp_kernel<false, false>, p, grid, lds_bytes, s);
 }
 
+hipError_t SFX(launch_render_head)(const RenderParams &p, bool counters, uint32_t grid, size_t lds_bytes, hipStream_t s) {
+    if (counters) hipLaunchKernelGGL((render_head_kernel<true>), dim3(grid), dim3(kBlock), lds_bytes, s, p);
+    else hipLaunchKernelGGL((render_head_kernel<false>), dim3(grid), dim3(kBlock), lds_bytes, s, p);
+    return hipGetLastError();
+}
+hipError_t SFX(launch_render_tail)(const RenderParams &p, bool counters, uint32_t grid, size_t lds_bytes, hipStream_t s) {
+    if (counters) hipLaunchKernelGGL((render_tail_kernel<true>), dim3(grid), dim3(kBlock), lds_bytes, s, p);
+    else hipLaunchKernelGGL((render_tail_kernel<false>), dim3(grid), dim3(kBlock), lds_bytes, s, p);
+    return hipGetLastError();
+}
+hipError_t SFX(launch_tail_accumulate)(const RenderParams &p, hipStream_t s) {
+    hipLaunchKernelGGL(tail_accumulate_kernel, dim3((p.tail_band_pixels + 255u) / 256u), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
 hipError_t SFX(launch_wf_raygen)(const WfParams &p, hipStream_t s) {
     hipLaunchKernelGGL(wf_raygen_kernel, dim3((p.nb + 255u) / 256u), dim3(256), 0, s, p);
     return hipGetLastError();
