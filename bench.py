@@ -268,7 +268,8 @@ def main():
                        "rays_per_step": rays_total / args.steps, "sharding": "row bands + RCCL all-gather (gather of step k overlaps the renders that follow)" if distributed else "none",
                        "pipeline": ("%d frames in flight on alternating streams: later steps fill the CUs the tail of step k leaves idle "
                                     "(roofline.kernel_ms = average launch duration while they overlap; kernel_alone_ms = one launch by itself)" % len(r.render_streams)) if getattr(r, "_overlap", False) else "serial launches",
-                       "kernel": ("render_kernel" if st.last_frame_split <= 1 else "render_fp_kernel, %d frame lanes" % st.last_frame_split) + ("<LDS scene>" if in_lds else "<HBM scene, quantised 4-wide BVH>") + " (fast build)",
+                       "kernel": ("render_kernel" if st.last_frame_split <= 1 else "render_fp_kernel, %d frame lanes" % st.last_frame_split) + ("<LDS scene>" if in_lds else "<HBM scene, quantised 4-wide BVH>") +
+                                 (" + tail compaction from bounce %d (render_head / render_tail kernels)" % st.last_tail_bounce if st.last_tail_bounce else "") + " (fast build)",
                        "triangles": int(len(buffers["material_ids"])), "scene_bytes": int(cst.scene_bytes)},
             "roofline": rf,
         }

@@ -78,6 +78,8 @@ typedef struct trg_stats {
     double last_build_ms;   /* acceleration-structure build of the last trg_load_scene: host wall time, or HIP-event time when built on the GPU */
     uint32_t gpu_built, bvh_nodes4, bvh_depth4;
     uint32_t last_frame_split; /* frame lanes the last trg_render used (TRG_OPT_FRAME_SPLIT; 1 = render_kernel, 2/4 = render_fp_kernel) */
+    uint32_t last_tail_bounce; /* K of the tail compaction the last trg_render used (TRG_OPT_TAIL_BOUNCE), 0 = none */
+    uint32_t last_kernel;      /* enum trg_kernel the last trg_render resolved to */
 } trg_stats;
 
 enum trg_option {

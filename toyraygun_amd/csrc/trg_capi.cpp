@@ -753,6 +753,8 @@ int trg_get_stats(trg_ctx *c, trg_stats *out) {
     out->last_build_ms = c->last_build_ms; out->gpu_built = c->gpu_built ? 1u : 0u;
     out->bvh_nodes4 = c->bvh_nodes4; out->bvh_depth4 = c->bvh_depth4;
     out->last_frame_split = c->last_fsplit;
+    out->last_tail_bounce = c->last_tail_k;
+    out->last_kernel = c->last_kernel;
     if (c->scene_loaded) {
         LdsPlan plan;
         if (plan_lds(c, plan, c->opt_kernel == TRG_KERNEL_POOL) == TRG_OK) { out->scene_in_lds = plan.lds_scene ? 1u : 0u; out->lds_bytes = plan.total; }
