@@ -13,9 +13,10 @@ OUT=$PWD/gpurun_out/profiles; mkdir -p "$OUT"
 WHAT="${*:-c2 c4}"
 C2="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline"
 C4="python3 bench.py --config c4 --steps 5 --warmup 1 --no-cpu-baseline"
+C3="python3 bench.py --config c3 --steps 3 --warmup 1 --no-cpu-baseline"
 run() { name=$1; shift; rm -rf "$OUT/$name"; rocprofv3 "$@" > "$OUT/$name.log" 2>&1 || { echo "FAILED $name"; tail -5 "$OUT/$name.log"; }; }
 for cfg in $WHAT; do
-  if [ "$cfg" = c2 ]; then CMD=$C2; else CMD=$C4; fi
+  if [ "$cfg" = c2 ]; then CMD=$C2; elif [ "$cfg" = c3 ]; then CMD=$C3; else CMD=$C4; fi
   run ${cfg}_trace --kernel-trace --stats --output-format csv -d "$OUT/${cfg}_trace" -- $CMD
   run ${cfg}_fetch --pmc FETCH_SIZE --output-format csv -d "$OUT/${cfg}_fetch" -- $CMD
   run ${cfg}_write --pmc WRITE_SIZE --output-format csv -d "$OUT/${cfg}_write" -- $CMD
