@@ -27,7 +27,8 @@ for cfg in cfgs:
             if "render" in k and "_kernel<" in k:
                 agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
         for (k, c), v in agg.items():
-            counters.setdefault(k, {})[c] = {"launches": len(v), "mean": sum(v) / len(v)}
+            vs = sorted(v)
+            counters.setdefault(k, {})[c] = {"launches": len(v), "mean": sum(v) / len(v), "median": vs[len(vs) // 2]}
     stats = []
     for f in glob.glob(f"{out}/{cfg}_trace/*/*_kernel_stats.csv"):
         stats = [r for r in csv.DictReader(open(f))][:4]
@@ -53,7 +54,9 @@ for cfg in cfgs:
     # the kernel bench.py times = the one with the most launches
     if counters:
         kname = max(counters, key=lambda k: max(v["launches"] for v in counters[k].values()))
-        c = {n: v["mean"] for n, v in counters[kname].items()}
+        # medians: a launch that overlaps another stream's fill / copy occasionally reports that traffic too (one C2 launch in 15
+        # showed 208 MB of writes beside fourteen at 32.7 MB)
+        c = {n: v["median"] for n, v in counters[kname].items()}
         # FETCH_SIZE: rocprofv3 reports KiB and, on gfx950, tallies every 128-byte memory-side read request at 64 bytes
         # (TCC_BUBBLE reads 0): profiles/r02/fetch_calibration.md -- x2 for every access shape.  WRITE_SIZE is exact.
         fetch_raw = c.get("FETCH_SIZE", 0.0) * 1024.0
