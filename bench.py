@@ -177,6 +177,11 @@ def main():
     r.ctx.set_option(capi.OPT_COUNTERS, 0)
 
     gather = distributed or bool(os.environ.get("TRG_FORCE_GATHER"))
+    # untimed priming: one step per render stream, so that every stream's per-launch scratch (traversal-stack overflow, tail-compaction
+    # queues) exists before anything is timed -- the first use of a stream allocates it behind a device synchronise
+    for _ in range(len(r.render_streams)):
+        r.render(0, SPP, BOUNCES, gather=False)
+    sync_all()
     for _ in range(args.warmup):
         r.render(0, SPP, BOUNCES, gather=gather)
     sync_all()
