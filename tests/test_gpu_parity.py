@@ -1361,3 +1361,29 @@ def test_tail_compaction_is_bit_exact(capi, O, cornell, k, bounces, spp):
     finally:
         O.set_trig_mode(O.TRIG_LIBM)
         c.close()
+
+
+def test_async_frames_keep_their_uniforms(capi, O, cornell):
+    """The asynchronous renderFrame() lets frames wait for a later launch while the device is busy.  Frames accepted before a
+    camera move must still be rendered with the camera they were requested with (setCameraPosition is a non-virtual base-class
+    setter, so the backend compares uniform snapshots): the result equals two explicit launches through the C ABI, bit for bit."""
+    from toyraygun_amd import host
+    w, h, fa, fb, bnc = 640, 480, 9, 7, 3
+    eye_b = (0.3, 1.1, 3.0)
+    got, launches = host.async_camera_move(w, h, fa, fb, eye_b, bnc)
+    assert 2 <= launches <= fa + fb
+    c = capi.Context(w, h)
+    try:
+        b = host.Scene.cornell_box().buffers()
+        c.load_scene(b["positions"], b["normals"], b["colors"], b["indices"], b["material_ids"])
+        c.set_pixel_offsets_seed()
+        c.set_uniforms(host.uniforms(w, h)[0])
+        c.render(0, fa, bnc)
+        c.set_uniforms(host.uniforms(w, h, eye=eye_b)[0])
+        c.render(fa, fb, bnc)
+        assert np.array_equal(_bits(got), _bits(c.read_accum()))
+        # and it differs from rendering all frames with either camera
+        c.render(0, fa + fb, bnc)
+        assert not np.array_equal(_bits(got), _bits(c.read_accum()))
+    finally:
+        c.close()

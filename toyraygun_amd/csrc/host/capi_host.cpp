@@ -142,6 +142,29 @@ void trh_random_texture(int w, int h, uint32_t seed, uint32_t *out) {
     t.destroy();
 }
 
+// ---- asynchronous frame loop with a camera move in the middle: framesA x renderFrame(), setCameraPosition(eyeB), framesB x
+//      renderFrame(), read back.  Frames queued before the move must be rendered with the old camera. ----
+int trh_async_camera_move(int w, int h, int framesA, int framesB, const float *eyeB3, int bounces, int device, float *accumOut, unsigned int *launchesOut) {
+    Engine *engine = Engine::instance();
+    engine->setDevice(device);
+    engine->init(w, h);
+    HipRenderer r;
+    if (!r.init()) return -3;
+    r.setCameraPosition(bx::Vec3(0.0f, 1.0f, 3.38f));
+    r.setCameraLookAt(bx::Vec3(0.0f, 1.0f, -1.0f));
+    Scene *scene = createCornellBoxScene();
+    r.loadScene(scene);
+    delete scene;
+    r.setBounces((unsigned int)bounces);
+    for (int i = 0; i < framesA; ++i) r.renderFrame();
+    r.setCameraPosition(bx::Vec3(eyeB3[0], eyeB3[1], eyeB3[2]));   // a base-class setter: the backend cannot intercept it
+    for (int i = 0; i < framesB; ++i) r.renderFrame();
+    if (r.getFrameIndex() != framesA + framesB) return -4;
+    if (!r.readAccumulation(accumOut)) return -5;
+    if (launchesOut) *launchesOut = r.getLaunchCount();
+    return 0;
+}
+
 // ---- the reference app's call sequence (main.cpp:21-95), headless ----
 // returns 0 on success; negative = the step that failed
 int trh_run_app(int w, int h, int frames, int bounces, int batch, int device, float *accumOut, const char *pngPath,

@@ -16,7 +16,7 @@ _lib = None
 SYMBOL_NAMES = ["trh_scene_new", "trh_scene_cornell", "trh_scene_lattice", "trh_scene_free", "trh_scene_add", "trh_scene_add_mesh", "trh_scene_add_mesh_colors", "trh_scene_add_obj", "trh_texture_load", "trh_texture_from_rgba",
                 "trh_texture_info", "trh_texture_copy", "trh_texture_free", "trh_scene_add_textured_mesh", "trh_scene_add_obj_textured", "trh_scene_copy_textures",
                 "trh_scene_counts", "trh_scene_copy", "trh_mtx_srt", "trh_mtx_inverse", "trh_uniforms",
-                "trh_random_texture", "trh_run_app"]
+                "trh_random_texture", "trh_run_app", "trh_async_camera_move"]
 
 
 def load():
@@ -58,6 +58,8 @@ def load():
         L.trh_run_app.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, F, C.c_char_p,
                                   C.POINTER(C.c_double), C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint)]
         L.trh_run_app.restype = C.c_int
+        L.trh_async_camera_move.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, F, C.c_int, C.c_int, F, C.POINTER(C.c_uint)]
+        L.trh_async_camera_move.restype = C.c_int
         _lib = L
     return _lib
 
@@ -221,6 +223,17 @@ def random_texture(w, h, seed=capi.SEED_OFFSETS):
     out = np.zeros(w * h, np.uint32)
     load().trh_random_texture(w, h, seed, out.ctypes.data)
     return out
+
+
+def async_camera_move(w, h, frames_a, frames_b, eye_b, bounces=3, device=0):
+    """HipRenderer: frames_a x renderFrame(), setCameraPosition(eye_b), frames_b x renderFrame(); returns (accum, launches)."""
+    acc = np.zeros((h, w, 4), np.float32)
+    e = _f32(eye_b)
+    n = C.c_uint()
+    rc = load().trh_async_camera_move(w, h, frames_a, frames_b, e.ctypes.data, bounces, device, acc.ctypes.data, C.byref(n))
+    if rc != 0:
+        raise RuntimeError("trh_async_camera_move failed at step %d" % rc)
+    return acc, n.value
 
 
 def run_app(w, h, frames, bounces=3, batch=False, device=0, png_path=None, want_launches=False):
