@@ -87,7 +87,9 @@ enum trg_option {
     TRG_OPT_COUNTERS = 2,     /* 1: count node fetches / triangle tests (slower) */
     TRG_OPT_FORCE_GLOBAL = 3, /* 1: keep the scene in HBM even if it would fit in LDS */
     TRG_OPT_TIMING = 4,       /* 1 (default): bracket trg_render with HIP events (forces a stream sync) */
-    TRG_OPT_GPU_BUILD = 6,    /* 1: the next trg_load_scene builds the BVH on the GPU (LBVH, 4-wide, HBM traversal only); 0 (default): host SAH build */
+    TRG_OPT_GPU_BUILD = 6,    /* the next trg_load_scene builds the BVH on the GPU (4-wide, HBM traversal only): 1 = binned SAH, one tree level per
+                                 round (the host builder's split rule), 2 = Morton order + Karras LBVH hierarchy (fastest build), 3 = Morton
+                                 order + PLOC merges by surface area; 0 (default): host SAH build */
     TRG_OPT_KERNEL = 5,       /* which megakernel trg_render launches: TRG_KERNEL_DIRECT (default) or TRG_KERNEL_POOL */
     TRG_OPT_LAUNCHES_IN_FLIGHT = 8, /* hint, default 1: how many trg_render launches of this context the caller keeps in flight on different
                                  streams (at most 16): the automatic frame split then favours throughput (the overlap hides a launch's tail).

@@ -9,6 +9,7 @@ F="-O3 -std=c++17 -fPIC -fno-slp-vectorize -fvisibility=hidden -Iinclude -I/root
 hipcc $F -DTRG_STRICT=0 "$@" -c $C/trg_kernels.hip -o $out/kf.o &
 hipcc $F -DTRG_STRICT=1 -ffp-contract=off "$@" -c $C/trg_kernels.hip -o $out/ks.o &
 hipcc $F -x hip "$@" -c $C/trg_capi.cpp -o $out/capi.o &
+hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden -Iinclude -I/root/repo/toyraygun_amd/csrc --offload-arch=gfx950 "$@" -c $C/trg_build.hip -o $out/build.o &
 wait
-hipcc -shared -fPIC --offload-arch=gfx950 -o $out/libtoyraygun_hip.so $out/kf.o $out/ks.o $out/capi.o toyraygun_amd/build/bvh_build.o toyraygun_amd/build/trg_build.o toyraygun_amd/build/trg_group.o -ldl -lpthread
+hipcc -shared -fPIC --offload-arch=gfx950 -o $out/libtoyraygun_hip.so $out/kf.o $out/ks.o $out/capi.o toyraygun_amd/build/bvh_build.o $out/build.o toyraygun_amd/build/trg_group.o -ldl -lpthread
 echo built $out

@@ -235,10 +235,10 @@ def test_c4_million_triangle_scene_parity(capi, O):
         c.close()
 
 
-@pytest.mark.parametrize("n", [0, 3, 7])
-def test_gpu_built_bvh_gives_identical_images(capi, O, n):
-    """with TRG_OPT_GPU_BUILD the acceleration structure is an LBVH built on the device (Morton sort +
-    Karras hierarchy + atomic refit, emitted 4-wide).  Traversal results do not depend on the tree, so the strict
+@pytest.mark.parametrize("n,builder", [(0, 1), (3, 1), (7, 1), (0, 2), (7, 2), (0, 3), (7, 3)])
+def test_gpu_built_bvh_gives_identical_images(capi, O, n, builder):
+    """with TRG_OPT_GPU_BUILD the acceleration structure is built on the device (binned SAH by
+    levels, Karras LBVH or PLOC on the Morton order; atomic refit, emitted 4-wide).  Traversal results do not depend on the tree, so the strict
     image must still equal the oracle's bit for bit, for both megakernels; so must the intersector's records."""
     scene = O.OracleScene.cornell_lattice(n) if n else O.OracleScene.cornell_box()
     b = scene.buffers()
@@ -249,7 +249,7 @@ def test_gpu_built_bvh_gives_identical_images(capi, O, n):
     O.set_trig_mode(O.TRIG_LIBM)
     c = capi.Context(w, h)
     try:
-        c.set_option(capi.OPT_GPU_BUILD, 1)
+        c.set_option(capi.OPT_GPU_BUILD, builder)     # 1 = binned SAH by levels, 2 = Karras LBVH, 3 = PLOC merges
         c.load_scene(b["positions"], b["normals"], b["colors"], b["indices"], b["material_ids"])
         st = c.stats()
         assert st.gpu_built == 1 and st.scene_in_lds == 0 and st.bvh_nodes4 >= 1 and st.last_build_ms > 0
@@ -292,8 +292,34 @@ def _random_soup(O, n, seed):
     return s
 
 
+@pytest.mark.parametrize("ntris", [2, 3, 4])
+@pytest.mark.parametrize("builder", [1, 2, 3])
+def test_gpu_build_of_a_handful_of_triangles(capi, O, ntris, builder):
+    """The device builders' smallest inputs (a root with two leaves; an odd triangle out): records identical to brute force."""
+    rng = np.random.default_rng(ntris)
+    s = O.OracleScene()
+    eye = np.eye(4, dtype=np.float32)
+    for k in range(ntris):
+        tri = (rng.uniform([-0.8, 0.2, -0.8], [0.8, 1.8, 0.8], (1, 3)) + rng.normal(0, 0.4, (3, 3))).astype(np.float32)
+        s.add_geometry(tri, [0, 1, 2], eye, (0.5, 0.5, 0.5), 1)
+    b = s.buffers()
+    c = capi.Context(16, 16)
+    try:
+        c.set_option(capi.OPT_GPU_BUILD, builder)
+        c.load_scene(b["positions"], b["normals"], b["colors"], b["indices"], b["material_ids"])
+        assert c.stats().gpu_built == 1
+        c.set_option(capi.OPT_STRICT, 1)
+        rays = _rays(O, 20000, 77 + ntris, hi=(0.95, 1.9, 0.95))
+        ref = O.intersect_nearest(s, rays, brute=True)
+        assert np.array_equal(c.trace(rays).view(np.uint8), ref.view(np.uint8))
+        assert (ref["distance"] >= 0).sum() > 100
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("scale,shift,gpu_build", [(100.0, (5000.0, -3000.0, 800.0), 0), (0.01, (-7.0, 3.0, 11.0), 0),
-                                                   (100.0, (5000.0, -3000.0, 800.0), 1)])
+                                                   (100.0, (5000.0, -3000.0, 800.0), 1), (100.0, (5000.0, -3000.0, 800.0), 2),
+                                                   (100.0, (5000.0, -3000.0, 800.0), 3)])
 def test_intersector_far_from_the_origin(capi, O, scale, shift, gpu_build):
     """Quantised wide nodes (8-bit child boxes against the node box) and the LBVH on geometry that is large / tiny and far
     from the origin: nearest and any-hit queries stay bit-identical to the oracle, whose own tree uses float boxes."""
@@ -375,7 +401,7 @@ def test_lds_resident_soup_parity(capi, O, n, seed):
             c.close()
 
 
-@pytest.mark.parametrize("n,seed,gpu_build", [(300, 1, 0), (300, 2, 1), (3000, 3, 0), (3000, 4, 1)])
+@pytest.mark.parametrize("n,seed,gpu_build", [(300, 1, 0), (300, 2, 1), (3000, 3, 0), (3000, 4, 1), (3000, 5, 2), (3000, 6, 3), (2, 7, 1), (5, 8, 1)])
 def test_random_triangle_soup_parity(capi, O, n, seed, gpu_build):
     """Fuzz: the intersector and the whole path on random, partly degenerate geometry -- strict build bit-exact against
     the oracle's brute force / BVH, host-built and GPU-built trees, both megakernels."""

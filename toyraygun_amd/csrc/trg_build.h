@@ -7,7 +7,7 @@ namespace trg {
 
 hipError_t gpu_build_lbvh(const float *d_pos, const uint32_t *d_idx, const uint32_t *d_masks, uint32_t ntris,
                           const float scene_lo[3], const float scene_hi[3], float pad, float4 *d_nodes4, float4 *d_tris,
-                          uint32_t *n_nodes4, uint32_t *depth4, hipStream_t s);
+                          uint32_t *n_nodes4, uint32_t *depth4, hipStream_t s, int mode);   // mode: 0 = Karras LBVH hierarchy, 1 = binned SAH by levels, 2 = PLOC merges
 
 // float 4-wide nodes (8 float4 each) -> quantised 64-byte nodes (q4node.h); d_out holds n_nodes4 * 64 bytes
 hipError_t gpu_quantize_nodes4(const float4 *d_nodes4, uint32_t n_nodes4, void *d_out, hipStream_t s);

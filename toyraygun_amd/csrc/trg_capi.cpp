@@ -52,7 +52,7 @@ struct trg_ctx {
     int opt_kernel = TRG_KERNEL_AUTO;
     uint32_t last_kernel = TRG_KERNEL_DIRECT;
     uint32_t last_tail_k = 0;
-    bool opt_gpu_build = false;
+    int opt_gpu_build = 0;   // TRG_OPT_GPU_BUILD: 0 host SAH, 1 device binned SAH, 2 device LBVH (Karras), 3 device PLOC
     int opt_fsplit = 0;  // 0 = auto
     int opt_tail = -1;   // TRG_OPT_TAIL_BOUNCE: -1 auto, 0 off, K
     int opt_tail_levels = 0;   // TRG_OPT_TAIL_LEVELS: 0 = re-compact every second bounce after K, 1 = once at K only
@@ -241,7 +241,7 @@ static int load_scene_gpu_build(trg_ctx *c, const float *pos, const float *nrm, 
     uint32_t n4 = 0, depth4 = 0;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     hipError_t e = gpu_build_lbvh((const float *)d_pos.p, (const uint32_t *)d_idx.p, (const uint32_t *)d_mat.p, n_tris, lo, hi, pad,
-                                  (float4 *)d_nodes4.p, (float4 *)d_tris.p, &n4, &depth4, c->stream);
+                                  (float4 *)d_nodes4.p, (float4 *)d_tris.p, &n4, &depth4, c->stream, c->opt_gpu_build == 2 ? 0 : c->opt_gpu_build == 3 ? 2 : 1);
     if (e != hipSuccess) return fail(c, TRG_ERR_DEVICE, "GPU BVH build failed: %s", hipGetErrorString(e));
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     HIPCHK(c, hipEventSynchronize(c->ev1));
@@ -778,7 +778,10 @@ int trg_set_option(trg_ctx *c, int option, int64_t value) {
     case TRG_OPT_COUNTERS: c->opt_counters = value != 0; break;
     case TRG_OPT_FORCE_GLOBAL: c->opt_force_global = value != 0; break;
     case TRG_OPT_TIMING: c->opt_timing = value != 0; break;
-    case TRG_OPT_GPU_BUILD: c->opt_gpu_build = value != 0; break;
+    case TRG_OPT_GPU_BUILD:
+        if (value < 0 || value > 3) return fail(c, TRG_ERR_INVALID, "trg_set_option: GPU build must be 0 (host SAH), 1 (device SAH), 2 (device LBVH) or 3 (device PLOC)");
+        c->opt_gpu_build = (int)value;
+        break;
     case TRG_OPT_FRAME_SPLIT:
         if (value != 0 && value != 1 && value != 2 && value != 4) return fail(c, TRG_ERR_INVALID, "trg_set_option: frame split must be 0 (auto), 1, 2 or 4");
         c->opt_fsplit = (int)value;
