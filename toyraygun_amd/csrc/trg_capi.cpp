@@ -139,6 +139,8 @@ static bool plan_lds_as(const trg_ctx *c, LdsPlan &p, bool lds_scene, bool pool,
     } else {
         levels = kWideHbm ? 3 * c->bvh_depth4 + 3 : c->bvh_depth + 3;  // the sentinel at level 0; 4-wide: up to three pending entries per level
         p.klds = std::min(levels, kStackLdsLevels);
+        // quad tracer (render_kernel): the same LDS holds 64 stacks of 4 * klds - 1 entries, which must cover the whole depth
+        if (TRG_QUAD && kWideHbm && !pool && !fp_slots && park) p.klds = std::max(p.klds, (3u * c->bvh_depth4 + 3u + 3u) / 4u);
     }
     p.overflow_levels = levels - p.klds;
     // the pool kernel does not use the Halton group tables at the end of the staged region: it stages (and pays for) less
@@ -154,7 +156,7 @@ static bool plan_lds_as(const trg_ctx *c, LdsPlan &p, bool lds_scene, bool pool,
     // render_kernel on an HBM-resident scene parks the running average in LDS between frames (three VGPRs less across every
     // traversal; an LDS-resident scene has neither the room -- 8 workgroups of 20 KB per CU -- nor the need: it is spill-free)
     p.acc_off = 0;
-    if (park && !p.lds_scene && !pool && !fp_slots) { p.acc_off = p.total; p.total += (uint32_t)kBlock * (TRG_PARK_PATH ? 36u : 12u); }
+    if (park && !p.lds_scene && !pool && !fp_slots) { p.acc_off = p.total; p.total += (uint32_t)kBlock * (TRG_QUAD ? 32u : (TRG_PARK_PATH ? 36u : 12u)); }   // quad tracer: 5 result words per thread behind the average
     limit = (pool || fp_slots) ? 160u * 1024u : 64u * 1024u;  // above 64 KB the launcher opts in per kernel
     return p.total <= limit;
 }

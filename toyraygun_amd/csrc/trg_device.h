@@ -968,6 +968,8 @@ TRG_DEV void traverse_pair(const SceneView &sc, V3 org, bool has_shadow, V3 sdir
     }
 }
 
+#include "trg_quad.inc.h"
+
 // ---------------------------------------------------------------------------------------------
 // Queue-draining tracer for the path-pool megakernel (render_pool_kernel).
 //

@@ -28,6 +28,11 @@ constexpr uint32_t kMaxLdsScene = 40u * 1024u;  // scenes up to this size are st
 #ifndef TRG_STACK_LDS_LEVELS
 #define TRG_STACK_LDS_LEVELS 12
 #endif
+// render_kernel on an HBM-resident scene: four lanes per ray (trg_quad.inc.h).  The quads' stacks use the LDS of the per-lane stack
+// levels (4 * klds - 1 entries per quad) and the result slots the LDS of the parked path state.
+#ifndef TRG_QUAD
+#define TRG_QUAD 0
+#endif
 #ifndef TRG_POOL_S
 #define TRG_POOL_S 2
 #endif

@@ -124,9 +124,9 @@ TRG_DEV ShadeOut shade_event(const trg_uniforms &u, const SceneView &sc, const H
 struct PathCounters { uint32_t primary, bounce, shadow, shaded; };
 TRG_DEV uint32_t wave_count(bool pred) { return (uint32_t)__popcll(__ballot(pred)); }
 typedef __attribute__((address_space(3))) float lds_float_t;
-template <bool LDS_SCENE, bool COUNT, typename STK>
+template <bool LDS_SCENE, bool COUNT, bool QUAD = false, typename STK>
 TRG_DEV V3 path_radiance(const trg::RenderParams &p, const SceneView &sc, STK stk, uint32_t x, uint32_t y, uint32_t offset, uint32_t frame, bool valid,
-                         V3 light_color, PathCounters &pc, Counters &cnt, lds_float_t *path_park = nullptr) {
+                         V3 light_color, PathCounters &pc, Counters &cnt, lds_float_t *path_park = nullptr, QuadLds ql = QuadLds()) {
     // Halton index of this pixel-sample (Raytracing.metal:67: offset + uniforms.frameIndex, wraps mod 2^32).  `frame` is wave-uniform:
     // the sum is re-formed where it is used instead of living in a VGPR of its own across the traversals.
 #define TRG_HIDX (offset + frame)
@@ -187,7 +187,12 @@ TRG_DEV V3 path_radiance(const trg::RenderParams &p, const SceneView &sc, STK st
         // and the incoherent continuation rays give the wavefront nothing to overlap them with.)
         Hit h; h.t = -1.0f; h.prim = -1; h.u = 0.0f; h.v = 0.0f;
         bool found = false;
-        if (p.bounces > 0u && active) found = traverse<false, COUNT, trg::kBlock, true>(sc, o, d, INFINITY, TRG_RMASK, h, stk, cnt);
+        if (QUAD) {
+            bool occ0;
+            traverse_quads<COUNT, trg::kBlock>(sc, ql, o, false, d, -1.0f, p.bounces > 0u && active, d, TRG_RMASK, occ0, h, found, cnt);
+        } else {
+            if (p.bounces > 0u && active) found = traverse<false, COUNT, trg::kBlock, true>(sc, o, d, INFINITY, TRG_RMASK, h, stk, cnt);
+        }
         for (uint32_t b = 0; b < p.bounces; ++b) {
             if (__ballot(active) == 0ull) break;
             const bool last = (b + 1u == p.bounces);
@@ -211,7 +216,8 @@ TRG_DEV V3 path_radiance(const trg::RenderParams &p, const SceneView &sc, STK st
                     path_park[0] = thr.x; path_park[trg::kBlock] = thr.y; path_park[2 * trg::kBlock] = thr.z;
                     path_park[3 * trg::kBlock] = rad.x; path_park[4 * trg::kBlock] = rad.y; path_park[5 * trg::kBlock] = rad.z;
                 }
-                traverse_pair<COUNT, trg::kBlock, true>(sc, o, so.want_shadow, so.sdir, so.smax, so.want_next, d, TRG_RMASK, occluded, h, found, stk, cnt);
+                if (QUAD) traverse_quads<COUNT, trg::kBlock>(sc, ql, o, so.want_shadow, so.sdir, so.smax, so.want_next, d, TRG_RMASK, occluded, h, found, cnt);
+                else traverse_pair<COUNT, trg::kBlock, true>(sc, o, so.want_shadow, so.sdir, so.smax, so.want_next, d, TRG_RMASK, occluded, h, found, stk, cnt);
                 if (path_park) {
                     thr = mk(path_park[0], path_park[trg::kBlock], path_park[2 * trg::kBlock]);
                     rad = mk(path_park[3 * trg::kBlock], path_park[4 * trg::kBlock], path_park[5 * trg::kBlock]);
@@ -265,6 +271,16 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES : TRG_EXP_WA
     constexpr bool PARK = !LDS_SCENE;
     lds_float_t *park = (lds_float_t *)(reinterpret_cast<float *>(smem + p.acc_off) + threadIdx.x);
     lds_float_t *path_park = (PARK && TRG_PARK_PATH) ? park + 3 * trg::kBlock : nullptr;
+    QuadLds ql; ql.stack = 0u; ql.res = 0u;
+#if TRG_QUAD
+    static_assert(!TRG_PARK_PATH, "the quad tracer's result slots use the LDS of the parked path state");
+    if (!LDS_SCENE) {
+        const uint32_t stride = 4u * p.stack.klds - 1u;   // ints per quad, level 0 = the sentinel
+        ql.stack = (uint32_t)(uintptr_t)(lds_int_t *)(reinterpret_cast<int *>(smem + p.stack_off) + (threadIdx.x >> 2) * stride);
+        ql.res = (uint32_t)(uintptr_t)(lds_int_t *)(reinterpret_cast<int *>(smem + p.acc_off) + 3 * trg::kBlock + (threadIdx.x & ~63u));
+        lds_st(ql.stack, kNodeDone);
+    }
+#endif
     V3 acc = mk(0.0f, 0.0f, 0.0f);
     {
         const uint32_t lane = lane_id();
@@ -287,7 +303,7 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES : TRG_EXP_WA
         // amplification, 8 scratch reloads per frame).  Recomputing them costs a dozen VALU instructions per frame.
         const uint32_t lane_f = lane_id_opaque();
         const uint32_t xf = x0 + (lane_f & 7), yf = y0 + (lane_f >> 3);
-        const V3 rad = path_radiance<LDS_SCENE, COUNT>(p, sc, stk, xf, yf, offset, f, valid, light_color, pc, cnt, path_park);
+        const V3 rad = path_radiance<LDS_SCENE, COUNT, TRG_QUAD && !LDS_SCENE>(p, sc, stk, xf, yf, offset, f, valid, light_color, pc, cnt, path_park, ql);
         if (PARK) acc = mk(park[0], park[trg::kBlock], park[2 * trg::kBlock]);
         // Accumulate.metal:19-39
         if (f == 0) {
