@@ -32,6 +32,13 @@ public:
     bool setDevices(const int *devices, int count);
     int getDeviceCount() const { return m_deviceCount; }
 
+    // ---- the acceleration structure: the reference rebuilds it on the GPU at loadScene (MPSTriangleAccelerationStructure rebuild,
+    //      MetalRenderer.mm:272-279).  0 (default): the host's binned-SAH builder; 1: the same split rule on the device, level by
+    //      level (a million triangles in ~20 ms); 2: Karras LBVH; 3: PLOC (TRG_OPT_GPU_BUILD, include/trg.h).  Scenes small enough
+    //      to be staged in LDS are always built on the host.  Takes effect at the next loadScene().
+    bool setDeviceBuild(int builder);
+    int getDeviceBuild() const { return m_deviceBuild; }
+
     // ---- beyond the reference: batch rendering and read-back for headless use ----
     void setBounces(unsigned int bounces);              // reference hard-codes 3 (MetalRenderer.mm:426)
     unsigned int getBounces() const { return m_bounces; }
@@ -57,6 +64,7 @@ protected:
     int m_devices[16];
     int m_deviceCount;
     unsigned int m_bounces;
+    int m_deviceBuild;
     uint32_t m_offsetSeed;
     bool m_sceneLoaded;
     bool m_synchronous;

@@ -1186,6 +1186,26 @@ def test_subdivided_cornell_renders_the_c2_image(capi, O, cornell):
         c.close()
 
 
+def test_plugin_device_build(capi, O):
+    """HipRenderer::setDeviceBuild: the acceleration structure of the next loadScene is built on the device (the reference rebuilds
+    its MPS structure on the GPU, MetalRenderer.mm:272-279).  The image does not depend on the builder -- host SAH, device SAH,
+    LBVH and PLOC give the same accumulation buffer bit for bit (shipped build) -- and a scene that fits LDS ignores the option."""
+    from toyraygun_amd import host
+    w, h = 160, 120
+    scene = host.Scene.cornell_lattice(12)     # 20,772 triangles: lives in HBM
+    ref, ms_host = host.render_scene(scene, w, h, 4, 3, device_build=0)
+    assert np.isfinite(ref).all() and ref[..., :3].max() > 0
+    for builder in (1, 2, 3):
+        got, ms_dev = host.render_scene(scene, w, h, 4, 3, device_build=builder)
+        assert np.array_equal(_bits(got), _bits(ref)), builder
+    box = host.Scene.cornell_box()
+    a, _ = host.render_scene(box, w, h, 4, 3, device_build=0)
+    b, _ = host.render_scene(box, w, h, 4, 3, device_build=1)
+    assert np.array_equal(_bits(a), _bits(b))
+    with pytest.raises(RuntimeError):
+        host.render_scene(box, w, h, 1, 3, device_build=4)
+
+
 def test_async_render_frame_loop(capi, O):
     """VERDICT r01 missing #3 / next #7: HipRenderer::renderFrame() is fire-and-forget like the reference's (MetalRenderer.mm:33,
     377,385-387: three frames in flight behind a semaphore) -- no host sync per frame; consecutive frames with the same

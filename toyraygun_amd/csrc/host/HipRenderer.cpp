@@ -13,7 +13,7 @@
 namespace toyraygun {
 
 HipRenderer::HipRenderer()
-    : m_ctx(nullptr), m_group(nullptr), m_deviceCount(0), m_bounces(3), m_offsetSeed(0x5EED0001u), m_sceneLoaded(false), m_synchronous(false), m_pending(0), m_pendingFirst(0),
+    : m_ctx(nullptr), m_group(nullptr), m_deviceCount(0), m_bounces(3), m_deviceBuild(0), m_offsetSeed(0x5EED0001u), m_sceneLoaded(false), m_synchronous(false), m_pending(0), m_pendingFirst(0),
       m_launches(0) {
     memset(&m_pendingUniforms, 0, sizeof(m_pendingUniforms));
 }
@@ -84,6 +84,10 @@ void HipRenderer::loadScene(Scene *scene) {
     const float *col = nVerts ? &scene->m_colorBuffer[0].x : nullptr;
     const uint32_t *idx = nVerts ? &scene->m_indexBuffer[0] : nullptr;
     const uint32_t *mat = nTris ? &scene->m_materialIDBuffer[0] : nullptr;
+    // a device-built tree is traversed in HBM: scenes of a few hundred triangles are staged in LDS and keep the host builder
+    const int builder = nTris >= 1024u ? m_deviceBuild : 0;
+    if (m_group) trg_group_set_option(m_group, TRG_OPT_GPU_BUILD, builder);
+    else trg_set_option(m_ctx, TRG_OPT_GPU_BUILD, builder);
     const int rc = m_group ? trg_group_load_scene(m_group, pos, nrm, col, idx, mat, nVerts, nTris)
                            : trg_load_scene(m_ctx, pos, nrm, col, idx, mat, nVerts, nTris);
     if (rc != TRG_OK) {
@@ -200,6 +204,11 @@ void HipRenderer::setSynchronous(bool on) {
 }
 
 void HipRenderer::setBounces(unsigned int bounces) { flush(); m_bounces = bounces; }
+bool HipRenderer::setDeviceBuild(int builder) {
+    if (builder < 0 || builder > 3) return false;
+    m_deviceBuild = builder;
+    return true;
+}
 bool HipRenderer::finish() { return m_ctx && flush() && (m_group ? trg_group_sync(m_group) : trg_sync(m_ctx)) == TRG_OK; }
 void HipRenderer::setOffsetSeed(uint32_t seed) {
     flush();

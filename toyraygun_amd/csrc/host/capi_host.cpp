@@ -165,6 +165,25 @@ int trh_async_camera_move(int w, int h, int framesA, int framesB, const float *e
     return 0;
 }
 
+// ---- HipRenderer on a caller-built Scene: init, setDeviceBuild, loadScene, `frames` samples, read back ----
+int trh_render_scene(void *scene, int w, int h, int frames, int bounces, int deviceBuild, int device, float *accumOut, double *loadMsOut) {
+    Engine *engine = Engine::instance();
+    engine->setDevice(device);
+    engine->init(w, h);
+    HipRenderer r;
+    if (!r.init()) return -3;
+    if (!r.setDeviceBuild(deviceBuild)) return -2;
+    r.setCameraPosition(bx::Vec3(0.0f, 1.0f, 3.38f));
+    r.setCameraLookAt(bx::Vec3(0.0f, 1.0f, -1.0f));
+    const auto t0 = std::chrono::steady_clock::now();
+    r.loadScene(static_cast<Scene *>(scene));
+    if (loadMsOut) *loadMsOut = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    r.setBounces((unsigned int)bounces);
+    if (!r.renderFrames((unsigned int)frames)) return -4;
+    if (!r.readAccumulation(accumOut)) return -5;
+    return 0;
+}
+
 // ---- the reference app's call sequence (main.cpp:21-95), headless ----
 // returns 0 on success; negative = the step that failed
 int trh_run_app(int w, int h, int frames, int bounces, int batch, int device, float *accumOut, const char *pngPath,
