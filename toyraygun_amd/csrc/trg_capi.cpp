@@ -156,7 +156,7 @@ static bool plan_lds_as(const trg_ctx *c, LdsPlan &p, bool lds_scene, bool pool,
     // render_kernel on an HBM-resident scene parks the running average in LDS between frames (three VGPRs less across every
     // traversal; an LDS-resident scene has neither the room -- 8 workgroups of 20 KB per CU -- nor the need: it is spill-free)
     p.acc_off = 0;
-    if (park && !p.lds_scene && !pool && !fp_slots) { p.acc_off = p.total; p.total += (uint32_t)kBlock * (TRG_QUAD ? 32u : (TRG_PARK_PATH ? 36u : 12u)); }   // quad tracer: 5 result words per thread behind the average
+    if (park && !p.lds_scene && !pool && !fp_slots) { p.acc_off = p.total; p.total += (uint32_t)kBlock * (TRG_QUAD ? 32u : (TRG_PARK_PATH ? (TRG_PARK_OFFSET ? 40u : 36u) : 12u)); }   // quad tracer: 5 result words per thread behind the average
     limit = (pool || fp_slots) ? 160u * 1024u : 64u * 1024u;  // above 64 KB the launcher opts in per kernel
     return p.total <= limit;
 }

@@ -573,9 +573,9 @@ TRG_DEV uint32_t mbcnt64(uint64_t m) {
 struct Trav {
     V3 o, d;
     float idx, idy, idz, oix, oiy, oiz;  // reciprocal direction and origin * reciprocal direction
-    float tmax, best;
+    float best;        // the ray's maxDistance until something is hit, then the distance of the accepted hit (any-hit: of the hit that ends it)
     uint32_t rmask;
-    Hit hit;
+    Hit hit;           // prim, u, v of the accepted hit; hit.t is filled in by trav_hit() only (it is `best`)
     bool found;
     int node, sp;
     int sx, sy, sz;  // sign-ordered LDS nodes (TRG_TRAV_LDS == 4): byte offset of the slab pair to read per axis
@@ -596,7 +596,7 @@ TRG_DEV void trav_begin(Trav &tv, V3 o, V3 d, float tmax, uint32_t rmask, int sp
     tv.o = o; tv.d = d;
     tv.idx = rcp_fast(dx); tv.idy = rcp_fast(dy); tv.idz = rcp_fast(dz);
     tv.oix = o.x * tv.idx; tv.oiy = o.y * tv.idy; tv.oiz = o.z * tv.idz;
-    tv.tmax = tmax; tv.best = tmax; tv.rmask = rmask;
+    tv.best = tmax; tv.rmask = rmask;
     tv.hit.t = -1.0f; tv.hit.prim = -1; tv.hit.u = 0.0f; tv.hit.v = 0.0f;
     tv.found = false;
     tv.node = 0; tv.sp = sp0;  // sp0 = stk.first(): the empty stack
@@ -706,16 +706,24 @@ TRG_DEV bool trav_tri_math(const v4f a, const v4f b, const v4f c, Trav &tv, bool
     const bool masked_in = (((uint32_t)__float_as_int(b.w)) & tv.rmask) != 0u;
     if (COUNT) { if (masked_in) cnt.tris++; if (mbcnt64(__ballot(1)) == 0) cnt.wtris++; }
     float t, u, v;
-    const bool ok = tri_test(a, b, c, tv.o, tv.d, tv.tmax, t, u, v) && masked_in;
+    // t is tested against `best` instead of the ray's own maxDistance: best <= maxDistance, and a triangle between the two could not
+    // change anything (something nearer is already held, so `found` is set and `take` would be false) -- one register less per ray
+    const bool ok = tri_test(a, b, c, tv.o, tv.d, tv.best, t, u, v) && masked_in;
     const int prim = __float_as_int(a.w);
     const bool take = ok && (any || !tv.found || t < tv.best || (t == tv.best && prim < tv.hit.prim));
     tv.found = tv.found || ok;
-    tv.best = (take && !any) ? t : tv.best;
-    tv.hit.t = take ? t : tv.hit.t;
+    tv.best = take ? t : tv.best;   // (an any-hit query ends with this triangle: its distance may overwrite the limit)
     tv.hit.prim = take ? prim : tv.hit.prim;
     tv.hit.u = take ? u : tv.hit.u;
     tv.hit.v = take ? v : tv.hit.v;
     return any && ok;
+}
+
+// the hit record of a finished traversal
+TRG_DEV Hit trav_hit(const Trav &tv) {
+    Hit h = tv.hit;
+    h.t = tv.found ? tv.best : -1.0f;
+    return h;
 }
 
 // One leaf: test its 1..8 triangles.  ~node = (first << 3) | (count - 1).  Pops the next node (the sentinel kNodeDone when
@@ -784,7 +792,8 @@ TRG_DEV void trav_node4_math(const v4f q0, const v4f q1, const v4f q2, const v4f
     int c0 = __float_as_int(ch.x), c1 = __float_as_int(ch.y), c2 = __float_as_int(ch.z), c3 = __float_as_int(ch.w);
     const float ax = q0.w * tv.idx, ay = q2.z * tv.idy, az = q2.w * tv.idz;
     const float bx = q0.x * tv.idx - tv.oix, by = q0.y * tv.idy - tv.oiy, bz = q0.z * tv.idz - tv.oiz;
-    const bool negx = tv.sx != 0, negy = tv.sy != 32, negz = tv.sz != 64;
+    // direction signs off the reciprocals (1 / d keeps the sign of d): nothing to keep in registers for them
+    const bool negx = (__float_as_uint(tv.idx) >> 31) != 0u, negy = (__float_as_uint(tv.idy) >> 31) != 0u, negz = (__float_as_uint(tv.idz) >> 31) != 0u;
     const uint32_t lox = __float_as_uint(q1.x), hix = __float_as_uint(q1.y), loy = __float_as_uint(q1.z), hiy = __float_as_uint(q1.w);
     const uint32_t loz = __float_as_uint(q2.x), hiz = __float_as_uint(q2.y);
     const uint32_t nx = negx ? hix : lox, fx = negx ? lox : hix;
@@ -926,7 +935,7 @@ TRG_DEV bool traverse(const SceneView &sc, V3 o, V3 d, float tmax_ray, uint32_t 
             if (tv.node == kNodeDone) break;
         }
     }
-    hit = tv.hit;
+    hit = trav_hit(tv);
     return tv.found;
 }
 
@@ -961,7 +970,7 @@ TRG_DEV void traverse_pair(const SceneView &sc, V3 org, bool has_shadow, V3 sdir
                 phase = has_next ? 1 : 2;
                 if (phase == 1) trav_begin(tv, org, ndir, INFINITY, nmask, stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED && TRG_TRAV_LDS == 5);
             } else {
-                nhit = tv.hit; nfound = tv.found;
+                nhit = trav_hit(tv); nfound = tv.found;
                 phase = 2;
             }
         }
@@ -1050,7 +1059,7 @@ TRG_DEV void trace_queue(const SceneView &sc, const PoolView pv, const unsigned 
                     if (tv.found) { v4f sh = pv.SH[slot]; sh.w = -1.0f; pv.SH[slot] = sh; }
                 } else {
                     v4f h;
-                    h.x = tv.found ? tv.hit.t : -1.0f; h.y = __int_as_float(tv.hit.prim); h.z = tv.hit.u; h.w = tv.hit.v;
+                    h.x = tv.found ? tv.best : -1.0f; h.y = __int_as_float(tv.hit.prim); h.z = tv.hit.u; h.w = tv.hit.v;
                     pv.H[slot] = h;
                 }
                 busy = false;

@@ -25,6 +25,9 @@ constexpr uint32_t kMaxLdsScene = 40u * 1024u;  // scenes up to this size are st
 #ifndef TRG_PARK_PATH
 #define TRG_PARK_PATH 1
 #endif
+#ifndef TRG_PARK_OFFSET
+#define TRG_PARK_OFFSET 1   // ... and the pixel's Halton offset behind them (one more word per thread)
+#endif
 #ifndef TRG_STACK_LDS_LEVELS
 #define TRG_STACK_LDS_LEVELS 12
 #endif

@@ -129,7 +129,8 @@ TRG_DEV V3 path_radiance(const trg::RenderParams &p, const SceneView &sc, STK st
                          V3 light_color, PathCounters &pc, Counters &cnt, lds_float_t *path_park = nullptr, QuadLds ql = QuadLds()) {
     // Halton index of this pixel-sample (Raytracing.metal:67: offset + uniforms.frameIndex, wraps mod 2^32).  `frame` is wave-uniform:
     // the sum is re-formed where it is used instead of living in a VGPR of its own across the traversals.
-#define TRG_HIDX (offset + frame)
+    // (HBM scenes: the offset itself is parked in LDS behind the path state and read back where the index is formed)
+#define TRG_HIDX ((TRG_PARK_OFFSET && path_park ? (uint32_t)__float_as_int(path_park[6 * trg::kBlock]) : offset) + frame)
     V3 o, d;
     constexpr bool TAB = LDS_SCENE && !TRG_STRICT && TRG_HALTON_TABLES;  // Halton group tables staged with the scene
     // The 176-byte uniform block is read from the kernel-argument segment WHERE IT IS USED (scalar loads, cached) through a pointer
@@ -290,6 +291,7 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES : TRG_EXP_WA
         if (valid) offset = p.offsets[pix];
         if (valid && p.frame_begin > 0) { const v4f a = accum[pix]; acc = mk(a.x, a.y, a.z); }
         if (PARK) { park[0] = acc.x; park[trg::kBlock] = acc.y; park[2 * trg::kBlock] = acc.z; }
+        if (TRG_PARK_OFFSET && path_park) { path_park[6 * trg::kBlock] = __int_as_float((int)offset); offset = 0u; }
     }
 
     PathCounters pc; pc.primary = 0; pc.bounce = 0; pc.shadow = 0; pc.shaded = 0;

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(trg::kBlock, 8) void wf_trace_kernel(const trg::WfP
                     if (tv.found) reinterpret_cast<float *>(&w.sh[pid])[3] = -1.0f;   // occluded: nothing to add
                 } else {
                     v4f h;
-                    h.x = tv.found ? tv.hit.t : -1.0f; h.y = __int_as_float(tv.hit.prim); h.z = tv.hit.u; h.w = tv.hit.v;
+                    h.x = tv.found ? tv.best : -1.0f; h.y = __int_as_float(tv.hit.prim); h.z = tv.hit.u; h.w = tv.hit.v;
                     wf_st(&w.hit[pid], h);
                 }
                 busy = false;
