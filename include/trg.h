@@ -80,6 +80,7 @@ typedef struct trg_stats {
     uint32_t last_frame_split; /* frame lanes the last trg_render used (TRG_OPT_FRAME_SPLIT; 1 = render_kernel, 2/4 = render_fp_kernel) */
     uint32_t last_tail_bounce; /* K of the tail compaction the last trg_render used (TRG_OPT_TAIL_BOUNCE), 0 = none */
     uint32_t last_kernel;      /* enum trg_kernel the last trg_render resolved to */
+    uint32_t last_regen;       /* 1: the last trg_render ran the path-regeneration megakernel (TRG_OPT_REGEN) */
 } trg_stats;
 
 enum trg_option {
@@ -100,6 +101,11 @@ enum trg_option {
                                  K.. with every lane live again (same result bit for bit; pays when paths die over many bounces: C3).
                                  0 = never; -1 (default) = K = 2 when the launch has 4 bounces or more */
     TRG_OPT_TAIL_LEVELS = 10, /* 0 (default): the tail launches re-compact every second bounce after K; 1: one compaction at K only */
+    TRG_OPT_REGEN = 11,       /* TRG_KERNEL_DIRECT on a scene in HBM (frame-serial launches): 1 or -1 (default) = path regeneration -- every
+                                 wavefront works through the (pixel, frame) jobs of its 8x8 tile as a pool, each lane at its own pace
+                                 (a lane that has finished a path takes the next job instead of waiting for the slowest lane of its
+                                 wavefront); the frames go through a radiance buffer that is folded in frame order, so the result is
+                                 bit-identical; 0 = one pixel per lane in lock step */
     TRG_OPT_FRAME_SPLIT = 7   /* TRG_KERNEL_DIRECT only: frame lanes per workgroup. 1: a pixel's frames run one after the other in one
                                  lane; 2 or 4: that many wavefronts share a pixel's frames (same result bit for bit; fills the chip
                                  when the pixel grid alone does not -- small windows, row bands of a multi-GPU job);

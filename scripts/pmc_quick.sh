@@ -13,7 +13,7 @@ import csv, glob, sys, collections
 agg = collections.defaultdict(list)
 for f in glob.glob(sys.argv[1] + "/*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "render_kernel" in r["Kernel_Name"]:
+        if "render_" in r["Kernel_Name"] and "_kernel<" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in sorted(agg):
     v = sorted(agg[k]); print("%-24s %.4g" % (k, v[len(v) // 2]))

@@ -1186,6 +1186,53 @@ def test_subdivided_cornell_renders_the_c2_image(capi, O, cornell):
         c.close()
 
 
+def test_path_regeneration_is_bit_exact(capi, O):
+    """TRG_OPT_REGEN (default on for HBM-resident scenes): every wavefront works through the (pixel, frame) jobs of its tile as a
+    pool, each lane at its own pace, the frames folded in order from a radiance buffer.  Same image and same ray counts as the
+    lock-step kernel bit for bit -- odd sizes (partial tiles), several 16-frame chunks, 0..8 bounces, continuation, row bands --
+    and the strict build equals the oracle."""
+    scene = O.OracleScene.cornell_lattice(6)
+    b = scene.buffers()
+    for (w, h, spp, bounces) in ((97, 45, 5, 3), (64, 64, 33, 2), (40, 24, 3, 8), (33, 17, 2, 0), (16, 16, 1, 1)):
+        off = O.pixel_offsets(w, h)
+        c = capi.Context(w, h)
+        try:
+            c.load_scene(b["positions"], b["normals"], b["colors"], b["indices"], b["material_ids"])
+            c.set_uniforms(O.uniforms_bytes(O.make_uniforms(w, h)))
+            c.set_pixel_offsets(off)
+            c.set_option(capi.OPT_FRAME_SPLIT, 1)
+            imgs = {}
+            for strict in (1, 0):
+                c.set_option(capi.OPT_STRICT, strict)
+                for regen in (0, 1):
+                    c.set_option(capi.OPT_REGEN, regen)
+                    c.reset_stats()
+                    c.render(0, spp, bounces)
+                    st = c.stats()
+                    assert st.last_regen == regen and st.scene_in_lds == 0
+                    imgs[(strict, regen)] = (c.read_accum().copy(), st.rays)
+                assert np.array_equal(_bits(imgs[(strict, 0)][0]), _bits(imgs[(strict, 1)][0])), (w, h, spp, bounces, strict)
+                assert imgs[(strict, 0)][1] == imgs[(strict, 1)][1]
+            if spp <= 5:
+                O.set_trig_mode(O.TRIG_PORTABLE)
+                try:
+                    ref, rst = O.render(scene, w, h, spp, bounces, offsets=off)
+                finally:
+                    O.set_trig_mode(O.TRIG_LIBM)
+                assert np.array_equal(_bits(imgs[(1, 1)][0]), _bits(ref)) and imgs[(1, 1)][1] == rst.rays
+            # continuation (frames 0..spp-1, then spp..2spp-1) and two row bands give the image of one launch
+            c.set_option(capi.OPT_STRICT, 1); c.set_option(capi.OPT_REGEN, 1)
+            c.render(0, 2 * spp, bounces)
+            whole = c.read_accum().copy()
+            c.render(0, spp, bounces); c.render(spp, spp, bounces)
+            assert np.array_equal(_bits(c.read_accum()), _bits(whole))
+            if h >= 16:
+                c.render(0, 2 * spp, bounces, 0, h // 3); c.render(0, 2 * spp, bounces, h // 3, h - h // 3)
+                assert np.array_equal(_bits(c.read_accum()), _bits(whole))
+        finally:
+            c.close()
+
+
 def test_plugin_device_build(capi, O):
     """HipRenderer::setDeviceBuild: the acceleration structure of the next loadScene is built on the device (the reference rebuilds
     its MPS structure on the GPU, MetalRenderer.mm:272-279).  The image does not depend on the builder -- host SAH, device SAH,

@@ -55,6 +55,8 @@ struct trg_ctx {
     int opt_gpu_build = 0;   // TRG_OPT_GPU_BUILD: 0 host SAH, 1 device binned SAH, 2 device LBVH (Karras), 3 device PLOC
     int opt_fsplit = 0;  // 0 = auto
     int opt_tail = -1;   // TRG_OPT_TAIL_BOUNCE: -1 auto, 0 off, K
+    int opt_regen = -1;        // TRG_OPT_REGEN: -1 / 1 = path regeneration for HBM-resident scenes (direct kernel, frame-serial), 0 = the lock-step kernel
+    uint32_t last_regen = 0;
     int opt_tail_levels = 0;   // TRG_OPT_TAIL_LEVELS: 0 = re-compact every second bounce after K, 1 = once at K only
     int opt_in_flight = 1;  // launches of this context the caller keeps in flight (TRG_OPT_LAUNCHES_IN_FLIGHT)
     double last_build_ms = 0.0;
@@ -702,6 +704,41 @@ int trg_render(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces,
     }
     c->last_tail_k = 0;
 
+    // ---- path regeneration (trg_regen.inc.h): scene in HBM, frame-serial direct kernel.  The frames go in chunks through a
+    //      radiance buffer [frame in chunk][pixel in band] that tail_accumulate_kernel folds in frame order.
+    const bool regen = c->opt_regen != 0 && !pool && fsplit == 1 && !plan.lds_scene && plan.acc_off != 0;
+    c->last_regen = regen ? 1u : 0u;
+    if (regen) {
+        const uint32_t fc = std::min<uint32_t>(std::max<uint32_t>(spp, 1u), kTailChunkFrames);
+        const uint64_t band_pixels = (uint64_t)c->w * rows;
+        const size_t rad_bytes = (size_t)(band_pixels * fc * 16u);
+        if (rad_bytes > c->wf_bytes[slot]) {
+            if (c->wf_mem[slot]) { (void)hipDeviceSynchronize(); (void)hipFree(c->wf_mem[slot]); c->wf_mem[slot] = nullptr; c->wf_bytes[slot] = 0; }
+            hipError_t me = hipMalloc((void **)&c->wf_mem[slot], rad_bytes);
+            if (me != hipSuccess) return fail(c, TRG_ERR_NOMEM, "radiance buffer hipMalloc(%zu) failed: %s", rad_bytes, hipGetErrorString(me));
+            c->wf_bytes[slot] = rad_bytes;
+        }
+        p.tail_band_pixels = (uint32_t)band_pixels;
+        p.tail_radbuf = c->wf_mem[slot];
+        if (c->opt_timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+        for (uint32_t f0 = 0; f0 < spp; f0 += fc) {
+            p.frame_begin = frame_begin + f0; p.spp = std::min(fc, spp - f0);
+            hipError_t te = c->opt_strict ? launch_render_regen_strict(p, c->opt_counters, grid, plan.total, c->stream)
+                                          : launch_render_regen_fast(p, c->opt_counters, grid, plan.total, c->stream);
+            if (te == hipSuccess) te = c->opt_strict ? launch_tail_accumulate_strict(p, c->stream) : launch_tail_accumulate_fast(p, c->stream);
+            if (te != hipSuccess) return fail(c, TRG_ERR_DEVICE, "trg_render: regeneration launch failed: %s", hipGetErrorString(te));
+        }
+        c->renders++; c->launches++; c->last_fsplit = 1;
+        if (c->opt_timing) {
+            HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+            HIPCHK(c, hipEventSynchronize(c->ev1));
+            float ms = 0.f;
+            HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+            c->last_ms = ms; c->total_ms += ms;
+        }
+        return TRG_OK;
+    }
+
     if (c->opt_timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     hipError_t e;
     if (pool)
@@ -757,6 +794,7 @@ int trg_get_stats(trg_ctx *c, trg_stats *out) {
     out->last_frame_split = c->last_fsplit;
     out->last_tail_bounce = c->last_tail_k;
     out->last_kernel = c->last_kernel;
+    out->last_regen = c->last_regen;
     if (c->scene_loaded) {
         LdsPlan plan;
         if (plan_lds(c, plan, c->opt_kernel == TRG_KERNEL_POOL) == TRG_OK) { out->scene_in_lds = plan.lds_scene ? 1u : 0u; out->lds_bytes = plan.total; }
@@ -794,6 +832,10 @@ int trg_set_option(trg_ctx *c, int option, int64_t value) {
         break;
     case TRG_OPT_TAIL_LEVELS:
         c->opt_tail_levels = value == 1 ? 1 : 0;
+        break;
+    case TRG_OPT_REGEN:
+        if (value < -1 || value > 1) return fail(c, TRG_ERR_INVALID, "trg_set_option: regeneration must be -1 (auto), 0 (off) or 1 (on)");
+        c->opt_regen = (int)value;
         break;
     case TRG_OPT_LAUNCHES_IN_FLIGHT:
         if (value < 1 || value > 16) return fail(c, TRG_ERR_INVALID, "trg_set_option: launches in flight must be 1..16");

@@ -345,6 +345,8 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES : TRG_EXP_WA
     }
 }
 
+#include "trg_regen.inc.h"
+
 // ---------------------------------------------------------------------------------------------
 // render_fp_kernel: the frame-parallel schedule of the same megakernel, for launches whose pixel grid alone does
 // not fill the chip (a row band of a multi-GPU job, a small window).  render_kernel gives a pixel to ONE lane that
@@ -736,6 +738,12 @@ hipError_t SFX(launch_render)(const RenderParams &p, bool lds_scene, bool counte
         if (counters) hipLaunchKernelGGL((render_kernel<false, true>), dim3(grid), dim3(kBlock), lds_bytes, s, p);
         else hipLaunchKernelGGL((render_kernel<false, false>), dim3(grid), dim3(kBlock), lds_bytes, s, p);
     }
+    return hipGetLastError();
+}
+
+hipError_t SFX(launch_render_regen)(const RenderParams &p, bool counters, uint32_t grid, size_t lds_bytes, hipStream_t s) {
+    if (counters) hipLaunchKernelGGL((render_regen_kernel<true>), dim3(grid), dim3(kBlock), lds_bytes, s, p);
+    else hipLaunchKernelGGL((render_regen_kernel<false>), dim3(grid), dim3(kBlock), lds_bytes, s, p);
     return hipGetLastError();
 }
 

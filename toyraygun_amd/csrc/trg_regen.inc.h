@@ -1,0 +1,210 @@
+// trg_regen.inc.h -- path regeneration: the megakernel for HBM-resident scenes with every lane running its own schedule.
+// Included by trg_kernels.hip after path_radiance / shade_event.
+//
+// render_kernel walks a wavefront's 64 pixels in lock step: every trace call ends when its slowest lane does, and on the
+// million-triangle scene 16 of the 64 lanes do useful work per instruction (profiles/r02).  Here a wavefront owns the same 8x8 pixels
+// and the chunk's frames of them as a POOL of path jobs (job j = frame j / 64 of pixel j % 64), and every lane works through jobs
+// at its own pace: a lane whose rays are finished waits only until enough lanes are in the same situation (the same bounce to
+// shade, or a path to close and a new job to take), then those lanes run that block together while the others keep traversing.
+// Neither the spread of ray lengths inside a trace call nor the spread of cost between the pixels of a tile leaves lanes idle:
+// what is left is the end of the pool.  Path state never leaves the lane (registers plus a few LDS words), jobs are handed out
+// with a wave-level counter and a ballot prefix -- no queue in memory, no atomic, no barrier.
+//
+// A finished path's radiance goes to radbuf[frame in chunk][pixel in band]; tail_accumulate_kernel folds the chunk into the running
+// average in frame order with Accumulate.metal's arithmetic, so the image is bit-identical to render_kernel's (and to the oracle's
+// in the strict build).
+//
+// Lane states: TRAVERSING (phase 0: the shadow ray, phase 1: the nearest-hit ray) or WAITING (phase 2) for one of these blocks:
+//   class 0      close the path that just ended (fold the last shadow ray, store the radiance) and take the next job of the pool
+//   class 1 + b  shading event number b of the current path (uniform b: the per-bounce Halton dimensions stay a scalar branch)
+// A block runs when at least TRG_REGEN_MIN lanes wait for it (TRG_REGEN_MIN0 for class 0), when more than TRG_REGEN_MAX_WAIT lanes
+// wait for anything, or when nobody is traversing; the class is taken from a waiting lane picked round robin, and the waiting lanes
+// are looked at every TRG_REGEN_PERIOD-th iteration only.  Measured on C4 (scripts/exp_ab.py, ms alone / per step in the pipeline;
+// the lock-step kernel: 25.9 / 22.6): thresholds 16 / 16 / 40 every iteration 33.6 / 30.1 WITHOUT the pool (a lane kept its pixel:
+// the spread between the pixels of a tile stayed), 8 / 8 / 16 every 2nd 23.4 / 20.9, 8 / 2 / 16 every 4th 22.5 / 20.5 (default),
+// 16 / 16 / 32 every 4th 24.5 / 21.9; letting leaf lanes wait until 8-16 of them can share the triangle half of the step: +1.5-2.5 ms.
+#pragma once
+
+#ifndef TRG_REGEN_MIN
+#define TRG_REGEN_MIN 8
+#endif
+#ifndef TRG_REGEN_MAX_WAIT
+#define TRG_REGEN_MAX_WAIT 16
+#endif
+#ifndef TRG_REGEN_MIN0
+#define TRG_REGEN_MIN0 2   // class 0 -- closing a path and taking a job -- costs a fifth of a shading event: a lower threshold
+#endif
+#ifndef TRG_REGEN_PERIOD
+#define TRG_REGEN_PERIOD 4   // the waiting lanes are looked at every PERIOD-th iteration (a power of two)
+#endif
+
+static_assert(TRG_PARK_PATH, "render_regen_kernel keeps nine words of path state per thread in the LDS render_kernel parks its path in");
+template <bool COUNT>
+__global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_kernel(const trg::RenderParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    SceneView sc = scene_view<false>(p.sc, smem);
+    sc.tex = p.tex;
+    LdsStackT<trg::kBlock, true> stk;
+    stk.set(smem, p.stack_off, p.stack.overflow, p.stack.klds);
+
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t tiles_y = gridDim.x / p.tiles_x;
+    const uint32_t crank = blockIdx.x / tiles_y, by = blockIdx.x % tiles_y;
+    const uint32_t cleft = (p.tiles_x - 1u) / 2u;
+    const uint32_t bx = (crank & 1u) ? cleft + 1u + crank / 2u : cleft - crank / 2u;
+    const uint32_t x0 = bx * trg::kTileW + (wave % (trg::kTileW / 8)) * 8;           // wave-uniform
+    const uint32_t y0 = p.row0 + by * trg::kTileH + (wave / (trg::kTileW / 8)) * 8;  // wave-uniform
+    v4f *radbuf = reinterpret_cast<v4f *>(p.tail_radbuf);
+    // per thread in LDS ([word][thread]): pixel-in-band of the current job (0), its Halton offset (1), throughput (3..5), radiance (6..8)
+    lds_float_t *park = (lds_float_t *)(reinterpret_cast<float *>(smem + p.acc_off) + threadIdx.x);
+#define TRG_RG_HIDX ((uint32_t)__float_as_int(park[trg::kBlock]) + p.frame_begin + (job >> 6))
+    typedef const __attribute__((address_space(4))) trg_uniforms cu_t;
+    cu_t *up = (cu_t *)__builtin_amdgcn_kernarg_segment_ptr();   // RenderParams::u is the first member
+#define TRG_RG_U (*(const trg_uniforms *)up)
+
+    PathCounters pc; pc.primary = 0; pc.bounce = 0; pc.shadow = 0; pc.shaded = 0;
+    Counters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.wnodes = 0; cnt.wtris = 0;
+    const V3 light_color = mk(p.u.light_color[0], p.u.light_color[1], p.u.light_color[2]);
+    const uint32_t n_jobs = 64u * p.spp;   // wave-uniform
+    uint32_t next_job = 0u;                // wave-uniform: the first job nobody has taken yet
+
+    uint32_t job = 0u;            // the path this lane is working on: frame job / 64 of the chunk, pixel job % 64 of the 8x8 tile
+    uint32_t b = 0;               // shading events of its current path so far
+    bool running = p.spp > 0u;
+    bool fresh = true;            // no path yet: the first class-0 block only takes a job
+    bool job_valid = false;       // the job's pixel lies inside the image / the band
+    bool active = false, primary_ray = true;
+    bool has_shadow = false, occluded = false, pending_next = false;
+    int phase = 2;
+    V3 dnext = mk(0.0f, 0.0f, 1.0f), scol = mk(0.0f, 0.0f, 0.0f);
+    Trav tv;
+    trav_begin(tv, mk(0.0f, 0.0f, 0.0f), mk(0.0f, 0.0f, 1.0f), 0.0f, 0u, stk.first());
+    tv.node = kNodeDone;
+    uint32_t rot = 0, it = 0;
+#ifdef TRG_REGEN_GUARD
+    uint32_t guard = 0;
+#endif
+
+    for (;;) {
+#ifdef TRG_REGEN_GUARD
+        if (++guard > (1u << 24)) break;   // bring-up only
+#endif
+        const bool waiting = running && phase == 2;
+        const uint64_t wmask = __ballot(waiting);
+        const uint64_t tmask = __ballot(phase < 2);
+        if ((wmask | tmask) == 0ull) break;
+        if (wmask != 0ull && (tmask == 0ull || ((++it) & (uint32_t)(TRG_REGEN_PERIOD - 1)) == 0u)) {
+            const uint32_t cls = (fresh || !active || b >= p.bounces) ? 0u : 1u + b;
+            // the class of a waiting lane, round robin over the lanes so that no class starves
+            rot = (rot + 7u) & 63u;
+            const uint64_t rolled = (wmask >> rot) | (rot ? (wmask << (64u - rot)) : 0ull);
+            const int pick = (int)((uint32_t)(__ffsll((long long)rolled) - 1) + rot) & 63;
+            const uint32_t csel = (uint32_t)__builtin_amdgcn_readlane((int)cls, pick);
+            const bool mine = waiting && cls == csel;
+            const uint32_t n_mine = (uint32_t)__popcll(__ballot(mine));
+            if (n_mine >= (csel == 0u ? (uint32_t)TRG_REGEN_MIN0 : (uint32_t)TRG_REGEN_MIN) || (uint32_t)__popcll(wmask) > (uint32_t)TRG_REGEN_MAX_WAIT || tmask == 0ull) {
+                asm volatile("" : "+s"(up));   // the uniforms this block needs are loaded after this point
+                if (csel == 0u) {
+                    if (mine) {
+                        if (!fresh && job_valid) {
+                            // the path has ended: Raytracing.metal:240-241 for its last shadow ray; the frame's texel goes to the chunk buffer
+                            V3 rad = mk(park[6 * trg::kBlock], park[7 * trg::kBlock], park[8 * trg::kBlock]);
+                            if (has_shadow && !occluded) rad = rad + scol;
+                            v4f r4; r4.x = rad.x; r4.y = rad.y; r4.z = rad.z; r4.w = 1.0f;
+                            radbuf[(size_t)(job >> 6) * p.tail_band_pixels + (uint32_t)__float_as_int(park[0])] = r4;
+                        }
+                    }
+                    {
+                        // the next jobs of the pool, in order, to the lanes of this block
+                        const uint64_t mm = __ballot(mine);
+                        const uint32_t rank = mbcnt64(mm);
+                        if (mine) job = next_job + rank;
+                        next_job += (uint32_t)__popcll(mm);
+                    }
+                    if (mine) {
+                        fresh = false; has_shadow = false; active = false; job_valid = false;
+                        if (job < n_jobs) {
+                            const uint32_t pl = job & 63u;
+                            const uint32_t x = x0 + (pl & 7u), y = y0 + (pl >> 3);
+                            job_valid = (x < p.u.width) && (y < p.row0 + p.rows) && (y < p.u.height);
+                            if (job_valid) {
+                                park[0] = __int_as_float((int)((y - p.row0) * p.u.width + x));
+                                park[trg::kBlock] = __int_as_float((int)p.offsets[y * p.u.width + x]);
+                                V3 o, d;
+                                raygen<false>(TRG_RG_U, x, y, TRG_RG_HIDX, o, d, nullptr);
+                                park[3 * trg::kBlock] = 1.0f; park[4 * trg::kBlock] = 1.0f; park[5 * trg::kBlock] = 1.0f;   // ray.color
+                                park[6 * trg::kBlock] = 0.0f; park[7 * trg::kBlock] = 0.0f; park[8 * trg::kBlock] = 0.0f;   // the frame's texel
+                                primary_ray = true; b = 0u;
+                                active = p.bounces > 0u;   // with no bounce to trace the path is over as it starts
+                                if (active) { trav_begin(tv, o, d, INFINITY, 3u, stk.first()); phase = 1; pending_next = false; }
+                            }
+                        } else {
+                            running = false;
+                        }
+                    }
+                    pc.primary += wave_count(mine && running && job_valid);
+                } else {
+                    const uint32_t bb = csel - 1u;                 // wave-uniform
+                    const bool last = (bb + 1u == p.bounces);      // wave-uniform
+                    ShadeOut so; so.want_shadow = false; so.want_next = false; so.shaded = false;
+                    if (mine) {
+                        V3 thr = mk(park[3 * trg::kBlock], park[4 * trg::kBlock], park[5 * trg::kBlock]);
+                        V3 rad = mk(park[6 * trg::kBlock], park[7 * trg::kBlock], park[8 * trg::kBlock]);
+                        if (has_shadow && !occluded) rad = rad + scol;
+                        const Hit h = trav_hit(tv);
+                        V3 o = tv.o, d = tv.d;
+                        uint32_t rmask = primary_ray ? 3u : 1u;
+                        so = shade_event<false>(TRG_RG_U, sc, h, tv.found, bb, last, TRG_RG_HIDX, o, d, thr, rad, rmask, active, light_color);
+                        primary_ray = rmask == 3u;
+                        b = bb + 1u;
+                        park[3 * trg::kBlock] = thr.x; park[4 * trg::kBlock] = thr.y; park[5 * trg::kBlock] = thr.z;
+                        park[6 * trg::kBlock] = rad.x; park[7 * trg::kBlock] = rad.y; park[8 * trg::kBlock] = rad.z;
+                        has_shadow = so.want_shadow; scol = so.scol;
+                        if (so.want_shadow) {
+                            trav_begin(tv, o, so.sdir, so.smax, 1u, stk.first());
+                            phase = 0; pending_next = so.want_next; dnext = d;
+                        } else if (so.want_next) {
+                            trav_begin(tv, o, d, INFINITY, rmask, stk.first());
+                            phase = 1; pending_next = false;
+                        }
+                        // neither: the path is over (last bounce, light, miss) and the lane waits for class 0
+                    }
+                    pc.shaded += wave_count(so.shaded);
+                    pc.shadow += wave_count(so.want_shadow);
+                    pc.bounce += wave_count(so.want_next);
+                }
+            }
+        }
+        if (phase < 2) {
+            trav_step_wide<COUNT, trg::kBlock>(sc, tv, phase == 0, stk, cnt);
+            if (tv.node == kNodeDone) {
+                if (phase == 0) {
+                    occluded = tv.found;
+                    if (pending_next) { trav_begin(tv, tv.o, dnext, INFINITY, primary_ray ? 3u : 1u, stk.first()); phase = 1; pending_next = false; }
+                    else phase = 2;
+                } else {
+                    phase = 2;
+                }
+            }
+        }
+    }
+#undef TRG_RG_HIDX
+#undef TRG_RG_U
+
+    const uint32_t lane = lane_id_opaque();
+    uint32_t vals[8] = { pc.primary, pc.bounce, pc.shadow, pc.shaded, cnt.nodes, cnt.tris, cnt.wnodes, cnt.wtris };
+    uint32_t *red = reinterpret_cast<uint32_t *>(smem + p.red_off);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (!COUNT && k >= 4) break;
+        const uint32_t s = k < 4 ? vals[k] : wave_sum(vals[k]);
+        if (lane == 0) red[wave * 8 + k] = s;
+    }
+    __syncthreads();
+    if (wave == 0 && lane < (COUNT ? 8u : 4u)) {
+        const uint32_t k = lane;
+        unsigned long long s = 0;
+        for (int wv = 0; wv < trg::kWaves; ++wv) s += red[wv * 8 + k];
+        if (s) atomicAdd(&p.counters[(blockIdx.x % trg::kCounterSlots) * trg::kCounterWords + k], s);
+    }
+}
