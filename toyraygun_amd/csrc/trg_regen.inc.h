@@ -2,13 +2,13 @@
 // Included by trg_kernels.hip after path_radiance / shade_event.
 //
 // render_kernel walks a wavefront's 64 pixels in lock step: every trace call ends when its slowest lane does, and on the
-// million-triangle scene 16 of the 64 lanes do useful work per instruction (profiles/r02).  Here a wavefront owns the same 8x8 pixels
-// and the chunk's frames of them as a POOL of path jobs (job j = frame j / 64 of pixel j % 64), and every lane works through jobs
-// at its own pace: a lane whose rays are finished waits only until enough lanes are in the same situation (the same bounce to
+// million-triangle scene 16 of the 64 lanes do useful work per instruction (profiles/r02).  Here a workgroup owns the same 16x16 pixels
+// and the chunk's frames of them as a POOL of path jobs (job j = frame j / 256 of tile pixel j % 256), and every lane of its four
+// wavefronts works through jobs at its own pace: a lane whose rays are finished waits only until enough lanes are in the same situation (the same bounce to
 // shade, or a path to close and a new job to take), then those lanes run that block together while the others keep traversing.
 // Neither the spread of ray lengths inside a trace call nor the spread of cost between the pixels of a tile leaves lanes idle:
 // what is left is the end of the pool.  Path state never leaves the lane (registers plus a few LDS words), jobs are handed out
-// with a wave-level counter and a ballot prefix -- no queue in memory, no atomic, no barrier.
+// with one LDS counter per workgroup and a ballot prefix (one LDS atomic per block of lanes) -- no queue in memory, no barrier.
 //
 // A finished path's radiance goes to radbuf[frame in chunk][pixel in band]; tail_accumulate_kernel folds the chunk into the running
 // average in frame order with Accumulate.metal's arithmetic, so the image is bit-identical to render_kernel's (and to the oracle's
@@ -52,12 +52,16 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
     const uint32_t crank = blockIdx.x / tiles_y, by = blockIdx.x % tiles_y;
     const uint32_t cleft = (p.tiles_x - 1u) / 2u;
     const uint32_t bx = (crank & 1u) ? cleft + 1u + crank / 2u : cleft - crank / 2u;
-    const uint32_t x0 = bx * trg::kTileW + (wave % (trg::kTileW / 8)) * 8;           // wave-uniform
-    const uint32_t y0 = p.row0 + by * trg::kTileH + (wave / (trg::kTileW / 8)) * 8;  // wave-uniform
+    const uint32_t x0 = bx * trg::kTileW, y0 = p.row0 + by * trg::kTileH;   // the workgroup's 16x16 tile
     v4f *radbuf = reinterpret_cast<v4f *>(p.tail_radbuf);
     // per thread in LDS ([word][thread]): pixel-in-band of the current job (0), its Halton offset (1), throughput (3..5), radiance (6..8)
     lds_float_t *park = (lds_float_t *)(reinterpret_cast<float *>(smem + p.acc_off) + threadIdx.x);
-#define TRG_RG_HIDX ((uint32_t)__float_as_int(park[trg::kBlock]) + p.frame_begin + (job >> 6))
+    // the pool counter of the workgroup: the spare word [2] of thread 0
+    lds_int_t *pool_next = (lds_int_t *)(reinterpret_cast<int *>(smem + p.acc_off) + 2 * trg::kBlock);
+    if (threadIdx.x == 0) *pool_next = 0;
+    __syncthreads();
+#define TRG_RG_FRAME(j) ((j) / (uint32_t)trg::kBlock)
+#define TRG_RG_HIDX ((uint32_t)__float_as_int(park[trg::kBlock]) + p.frame_begin + TRG_RG_FRAME(job))
     typedef const __attribute__((address_space(4))) trg_uniforms cu_t;
     cu_t *up = (cu_t *)__builtin_amdgcn_kernarg_segment_ptr();   // RenderParams::u is the first member
 #define TRG_RG_U (*(const trg_uniforms *)up)
@@ -65,10 +69,9 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
     PathCounters pc; pc.primary = 0; pc.bounce = 0; pc.shadow = 0; pc.shaded = 0;
     Counters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.wnodes = 0; cnt.wtris = 0;
     const V3 light_color = mk(p.u.light_color[0], p.u.light_color[1], p.u.light_color[2]);
-    const uint32_t n_jobs = 64u * p.spp;   // wave-uniform
-    uint32_t next_job = 0u;                // wave-uniform: the first job nobody has taken yet
+    const uint32_t n_jobs = (uint32_t)trg::kBlock * p.spp;   // jobs of the workgroup's pool: frame j / 256 of tile pixel j % 256
 
-    uint32_t job = 0u;            // the path this lane is working on: frame job / 64 of the chunk, pixel job % 64 of the 8x8 tile
+    uint32_t job = 0u;            // the path this lane is working on
     uint32_t b = 0;               // shading events of its current path so far
     bool running = p.spp > 0u;
     bool fresh = true;            // no path yet: the first class-0 block only takes a job
@@ -111,21 +114,24 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
                             V3 rad = mk(park[6 * trg::kBlock], park[7 * trg::kBlock], park[8 * trg::kBlock]);
                             if (has_shadow && !occluded) rad = rad + scol;
                             v4f r4; r4.x = rad.x; r4.y = rad.y; r4.z = rad.z; r4.w = 1.0f;
-                            radbuf[(size_t)(job >> 6) * p.tail_band_pixels + (uint32_t)__float_as_int(park[0])] = r4;
+                            radbuf[(size_t)TRG_RG_FRAME(job) * p.tail_band_pixels + (uint32_t)__float_as_int(park[0])] = r4;
                         }
                     }
                     {
                         // the next jobs of the pool, in order, to the lanes of this block
                         const uint64_t mm = __ballot(mine);
                         const uint32_t rank = mbcnt64(mm);
-                        if (mine) job = next_job + rank;
-                        next_job += (uint32_t)__popcll(mm);
+                        int base = 0;
+                        if (mine && rank == 0u) base = atomicAdd((int *)pool_next, (int)__popcll(mm));   // one LDS atomic per block
+                        base = __builtin_amdgcn_readlane(base, __ffsll((long long)mm) - 1);
+                        if (mine) job = (uint32_t)base + rank;
                     }
                     if (mine) {
                         fresh = false; has_shadow = false; active = false; job_valid = false;
                         if (job < n_jobs) {
-                            const uint32_t pl = job & 63u;
-                            const uint32_t x = x0 + (pl & 7u), y = y0 + (pl >> 3);
+                            // consecutive jobs = the pixels of one 8x8 sub-tile, sub-tile after sub-tile, frame after frame
+                            const uint32_t pl = job % (uint32_t)trg::kBlock, sub = pl >> 6;
+                            const uint32_t x = x0 + (sub % (trg::kTileW / 8)) * 8u + (pl & 7u), y = y0 + (sub / (trg::kTileW / 8)) * 8u + ((pl >> 3) & 7u);
                             job_valid = (x < p.u.width) && (y < p.row0 + p.rows) && (y < p.u.height);
                             if (job_valid) {
                                 park[0] = __int_as_float((int)((y - p.row0) * p.u.width + x));
@@ -189,6 +195,7 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
         }
     }
 #undef TRG_RG_HIDX
+#undef TRG_RG_FRAME
 #undef TRG_RG_U
 
     const uint32_t lane = lane_id_opaque();
