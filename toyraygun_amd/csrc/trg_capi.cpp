@@ -710,22 +710,20 @@ int trg_render(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces,
     c->last_regen = regen ? 1u : 0u;
     if (regen) {
         const uint32_t fc = std::min<uint32_t>(std::max<uint32_t>(spp, 1u), kTailChunkFrames);
-        const uint64_t band_pixels = (uint64_t)c->w * rows;
-        const size_t rad_bytes = (size_t)(band_pixels * fc * 16u);
+        const size_t rad_bytes = (size_t)grid * kBlock * fc * 16u;   // one log of 256 x fc records per workgroup
         if (rad_bytes > c->wf_bytes[slot]) {
             if (c->wf_mem[slot]) { (void)hipDeviceSynchronize(); (void)hipFree(c->wf_mem[slot]); c->wf_mem[slot] = nullptr; c->wf_bytes[slot] = 0; }
             hipError_t me = hipMalloc((void **)&c->wf_mem[slot], rad_bytes);
             if (me != hipSuccess) return fail(c, TRG_ERR_NOMEM, "radiance buffer hipMalloc(%zu) failed: %s", rad_bytes, hipGetErrorString(me));
             c->wf_bytes[slot] = rad_bytes;
         }
-        p.tail_band_pixels = (uint32_t)band_pixels;
         p.tail_radbuf = c->wf_mem[slot];
         if (c->opt_timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
         for (uint32_t f0 = 0; f0 < spp; f0 += fc) {
             p.frame_begin = frame_begin + f0; p.spp = std::min(fc, spp - f0);
             hipError_t te = c->opt_strict ? launch_render_regen_strict(p, c->opt_counters, grid, plan.total, c->stream)
                                           : launch_render_regen_fast(p, c->opt_counters, grid, plan.total, c->stream);
-            if (te == hipSuccess) te = c->opt_strict ? launch_tail_accumulate_strict(p, c->stream) : launch_tail_accumulate_fast(p, c->stream);
+            if (te == hipSuccess) te = c->opt_strict ? launch_regen_accumulate_strict(p, grid, c->stream) : launch_regen_accumulate_fast(p, grid, c->stream);
             if (te != hipSuccess) return fail(c, TRG_ERR_DEVICE, "trg_render: regeneration launch failed: %s", hipGetErrorString(te));
         }
         c->renders++; c->launches++; c->last_fsplit = 1;

@@ -152,6 +152,7 @@ static_assert(!(kSignedLds || kWideLds) || kWideHbm, "the LDS node layouts repla
     hipError_t launch_render_##SFX(const RenderParams &p, bool lds_scene, bool counters, uint32_t grid,          \
                                    size_t lds_bytes, hipStream_t s);                                             \
     hipError_t launch_render_regen_##SFX(const RenderParams &p, bool counters, uint32_t grid, size_t lds_bytes, hipStream_t s); \
+    hipError_t launch_regen_accumulate_##SFX(const RenderParams &p, uint32_t grid, hipStream_t s);               \
     hipError_t launch_render_pool_##SFX(const RenderParams &p, bool lds_scene, bool counters, uint32_t grid,     \
                                         size_t lds_bytes, hipStream_t s);                                        \
     hipError_t launch_render_fp_##SFX(const RenderParams &p, bool lds_scene, bool counters, uint32_t grid,       \

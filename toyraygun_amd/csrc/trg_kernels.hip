@@ -747,6 +747,11 @@ hipError_t SFX(launch_render_regen)(const RenderParams &p, bool counters, uint32
     return hipGetLastError();
 }
 
+hipError_t SFX(launch_regen_accumulate)(const RenderParams &p, uint32_t grid, hipStream_t s) {
+    hipLaunchKernelGGL(regen_accumulate_kernel, dim3(grid), dim3(kBlock), (size_t)p.spp * kBlock * 16u, s, p);
+    return hipGetLastError();
+}
+
 template <typename K>
 static hipError_t launch_big_lds(K kernel, const RenderParams &p, uint32_t grid, size_t lds_bytes, hipStream_t s) {
     // more than 64 KB of dynamic LDS has to be opted into per kernel (gfx950 has 160 KB per CU)

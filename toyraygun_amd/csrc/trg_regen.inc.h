@@ -10,9 +10,12 @@
 // what is left is the end of the pool.  Path state never leaves the lane (registers plus a few LDS words), jobs are handed out
 // with one LDS counter per workgroup and a ballot prefix (one LDS atomic per block of lanes) -- no queue in memory, no barrier.
 //
-// A finished path's radiance goes to radbuf[frame in chunk][pixel in band]; tail_accumulate_kernel folds the chunk into the running
-// average in frame order with Accumulate.metal's arithmetic, so the image is bit-identical to render_kernel's (and to the oracle's
-// in the strict build).
+// A finished path's radiance is APPENDED to the workgroup's log in HBM -- (radiance, frame-in-chunk << 8 | pixel-in-tile), 16 bytes,
+// the lanes of a block write consecutive records -- and regen_accumulate_kernel sorts a tile's log by (frame, pixel) in LDS and
+// folds the chunk into the running average in frame order with Accumulate.metal's arithmetic, so the image is bit-identical to
+// render_kernel's (and to the oracle's in the strict build).  (Writing each radiance to its [frame][pixel] slot instead cost 142
+// bytes of memory-side write traffic per 16-byte store -- 4.7 GB per C4 launch: the eight pixels of a 128-byte line finish tens of
+// microseconds apart and L2 evicts the partial line in between.)
 //
 // Lane states: TRAVERSING (phase 0: the shadow ray, phase 1: the nearest-hit ray) or WAITING (phase 2) for one of these blocks:
 //   class 0      close the path that just ended (fold the last shadow ray, store the radiance) and take the next job of the pool
@@ -38,6 +41,23 @@
 #define TRG_REGEN_PERIOD 4   // the waiting lanes are looked at every PERIOD-th iteration (a power of two)
 #endif
 
+constexpr uint32_t kRegenStage = 32u;
+typedef __attribute__((address_space(3))) v4f regen_rec_t;
+// the wavefront's staged records -> the workgroup's log: one LDS atomic reserves the range, lanes 0..cnt-1 write consecutive records
+TRG_DEV void regen_flush(const regen_rec_t *stage, uint32_t cnt, v4f *rlog, lds_int_t *pool_done) {
+    if (cnt == 0u) return;
+    const uint32_t lane = lane_id();
+    int base = 0;
+    if (lane == 0u) base = atomicAdd((int *)pool_done, (int)cnt);
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (lane < cnt) rlog[(uint32_t)base + lane] = stage[lane];
+}
+
+TRG_DEV void regen_count(lds_int_t *wred, int k, bool pred) {
+    const uint32_t n = wave_count(pred);
+    if (n != 0u && lane_id() == 0u) wred[k] = wred[k] + (int)n;
+}
+
 static_assert(TRG_PARK_PATH, "render_regen_kernel keeps nine words of path state per thread in the LDS render_kernel parks its path in");
 template <bool COUNT>
 __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_kernel(const trg::RenderParams p) {
@@ -53,12 +73,16 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
     const uint32_t cleft = (p.tiles_x - 1u) / 2u;
     const uint32_t bx = (crank & 1u) ? cleft + 1u + crank / 2u : cleft - crank / 2u;
     const uint32_t x0 = bx * trg::kTileW, y0 = p.row0 + by * trg::kTileH;   // the workgroup's 16x16 tile
-    v4f *radbuf = reinterpret_cast<v4f *>(p.tail_radbuf);
-    // per thread in LDS ([word][thread]): pixel-in-band of the current job (0), its Halton offset (1), throughput (3..5), radiance (6..8)
+    v4f *rlog = reinterpret_cast<v4f *>(p.tail_radbuf) + (size_t)blockIdx.x * trg::kBlock * p.spp;   // this workgroup's log: 256 x spp records
+    // per thread in LDS ([word][thread]): the Halton offset of the current job's pixel (1), throughput (3..5), radiance (6..8)
     lds_float_t *park = (lds_float_t *)(reinterpret_cast<float *>(smem + p.acc_off) + threadIdx.x);
     // the pool counter of the workgroup: the spare word [2] of thread 0
     lds_int_t *pool_next = (lds_int_t *)(reinterpret_cast<int *>(smem + p.acc_off) + 2 * trg::kBlock);
-    if (threadIdx.x == 0) *pool_next = 0;
+    lds_int_t *pool_done = pool_next + 1;   // records in the workgroup's log so far (word [2] of thread 1)
+    if (threadIdx.x < 2) pool_next[threadIdx.x] = 0;
+    // staging area of this wavefront: 32 records in the spare words [0] (waves 0, 1) and [9] (waves 2, 3) of the parked state
+    regen_rec_t *stage = (regen_rec_t *)(reinterpret_cast<float *>(smem + p.acc_off) + (wave >> 1) * 9u * trg::kBlock) + (wave & 1u) * kRegenStage;
+    uint32_t stage_cnt = 0u;   // wave-uniform
     __syncthreads();
 #define TRG_RG_FRAME(j) ((j) / (uint32_t)trg::kBlock)
 #define TRG_RG_HIDX ((uint32_t)__float_as_int(park[trg::kBlock]) + p.frame_begin + TRG_RG_FRAME(job))
@@ -66,7 +90,10 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
     cu_t *up = (cu_t *)__builtin_amdgcn_kernarg_segment_ptr();   // RenderParams::u is the first member
 #define TRG_RG_U (*(const trg_uniforms *)up)
 
-    PathCounters pc; pc.primary = 0; pc.bounce = 0; pc.shadow = 0; pc.shaded = 0;
+    // the ray counters (primary, bounce, shadow, shaded) are kept in the wavefront's row of the LDS reduction scratch, not in registers:
+    // the blocks below run under conditions the compiler does not see as wave-uniform, where a loop-carried sum becomes a VGPR
+    lds_int_t *wred = (lds_int_t *)(reinterpret_cast<int *>(smem + p.red_off) + wave * 8u);
+    if (lane_id() < 4u) wred[lane_id()] = 0;
     Counters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.wnodes = 0; cnt.wtris = 0;
     const V3 light_color = mk(p.u.light_color[0], p.u.light_color[1], p.u.light_color[2]);
     const uint32_t n_jobs = (uint32_t)trg::kBlock * p.spp;   // jobs of the workgroup's pool: frame j / 256 of tile pixel j % 256
@@ -96,10 +123,11 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
         const uint64_t wmask = __ballot(waiting);
         const uint64_t tmask = __ballot(phase < 2);
         if ((wmask | tmask) == 0ull) break;
-        if (wmask != 0ull && (tmask == 0ull || ((++it) & (uint32_t)(TRG_REGEN_PERIOD - 1)) == 0u)) {
+        it = (uint32_t)__builtin_amdgcn_readfirstlane((int)(it + 1u));   // (readfirstlane: keeps the loop's wave-uniform counters in SGPRs)
+        if (wmask != 0ull && (tmask == 0ull || (it & (uint32_t)(TRG_REGEN_PERIOD - 1)) == 0u)) {
             const uint32_t cls = (fresh || !active || b >= p.bounces) ? 0u : 1u + b;
             // the class of a waiting lane, round robin over the lanes so that no class starves
-            rot = (rot + 7u) & 63u;
+            rot = (uint32_t)__builtin_amdgcn_readfirstlane((int)((rot + 7u) & 63u));
             const uint64_t rolled = (wmask >> rot) | (rot ? (wmask << (64u - rot)) : 0ull);
             const int pick = (int)((uint32_t)(__ffsll((long long)rolled) - 1) + rot) & 63;
             const uint32_t csel = (uint32_t)__builtin_amdgcn_readlane((int)cls, pick);
@@ -108,13 +136,31 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
             if (n_mine >= (csel == 0u ? (uint32_t)TRG_REGEN_MIN0 : (uint32_t)TRG_REGEN_MIN) || (uint32_t)__popcll(wmask) > (uint32_t)TRG_REGEN_MAX_WAIT || tmask == 0ull) {
                 asm volatile("" : "+s"(up));   // the uniforms this block needs are loaded after this point
                 if (csel == 0u) {
-                    if (mine) {
-                        if (!fresh && job_valid) {
-                            // the path has ended: Raytracing.metal:240-241 for its last shadow ray; the frame's texel goes to the chunk buffer
-                            V3 rad = mk(park[6 * trg::kBlock], park[7 * trg::kBlock], park[8 * trg::kBlock]);
-                            if (has_shadow && !occluded) rad = rad + scol;
-                            v4f r4; r4.x = rad.x; r4.y = rad.y; r4.z = rad.z; r4.w = 1.0f;
-                            radbuf[(size_t)TRG_RG_FRAME(job) * p.tail_band_pixels + (uint32_t)__float_as_int(park[0])] = r4;
+                    {
+                        // the paths that have ended: Raytracing.metal:240-241 for their last shadow ray; the frame's texel goes to the log,
+                        // through the wavefront's 32-record staging area in LDS so that the log is written 512 bytes at a time
+                        const bool done = mine && !fresh && job_valid;
+                        const uint64_t dm = __ballot(done);
+                        const uint32_t n_done = (uint32_t)__popcll(dm);
+                        if (n_done != 0u) {
+                            if (stage_cnt + n_done > kRegenStage) { regen_flush(stage, stage_cnt, rlog, pool_done); stage_cnt = 0u; }
+                            v4f r4; r4.x = 0.0f; r4.y = 0.0f; r4.z = 0.0f; r4.w = 0.0f;
+                            if (done) {
+                                V3 rad = mk(park[6 * trg::kBlock], park[7 * trg::kBlock], park[8 * trg::kBlock]);
+                                if (has_shadow && !occluded) rad = rad + scol;
+                                r4.x = rad.x; r4.y = rad.y; r4.z = rad.z;
+                                r4.w = __int_as_float((int)((TRG_RG_FRAME(job) << 8) | (job % (uint32_t)trg::kBlock)));
+                            }
+                            const uint32_t drank = mbcnt64(dm);
+                            if (n_done > kRegenStage) {   // more than the stage holds at once (a whole wavefront finishing together): straight to the log
+                                int dbase = 0;
+                                if (done && drank == 0u) dbase = atomicAdd((int *)pool_done, (int)n_done);
+                                dbase = __builtin_amdgcn_readlane(dbase, __ffsll((long long)dm) - 1);
+                                if (done) rlog[(uint32_t)dbase + drank] = r4;
+                            } else {
+                                if (done) stage[stage_cnt + drank] = r4;
+                                stage_cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)(stage_cnt + n_done));
+                            }
                         }
                     }
                     {
@@ -134,7 +180,6 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
                             const uint32_t x = x0 + (sub % (trg::kTileW / 8)) * 8u + (pl & 7u), y = y0 + (sub / (trg::kTileW / 8)) * 8u + ((pl >> 3) & 7u);
                             job_valid = (x < p.u.width) && (y < p.row0 + p.rows) && (y < p.u.height);
                             if (job_valid) {
-                                park[0] = __int_as_float((int)((y - p.row0) * p.u.width + x));
                                 park[trg::kBlock] = __int_as_float((int)p.offsets[y * p.u.width + x]);
                                 V3 o, d;
                                 raygen<false>(TRG_RG_U, x, y, TRG_RG_HIDX, o, d, nullptr);
@@ -148,7 +193,7 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
                             running = false;
                         }
                     }
-                    pc.primary += wave_count(mine && running && job_valid);
+                    regen_count(wred, 0, mine && running && job_valid);
                 } else {
                     const uint32_t bb = csel - 1u;                 // wave-uniform
                     const bool last = (bb + 1u == p.bounces);      // wave-uniform
@@ -175,9 +220,9 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
                         }
                         // neither: the path is over (last bounce, light, miss) and the lane waits for class 0
                     }
-                    pc.shaded += wave_count(so.shaded);
-                    pc.shadow += wave_count(so.want_shadow);
-                    pc.bounce += wave_count(so.want_next);
+                    regen_count(wred, 3, so.shaded);
+                    regen_count(wred, 2, so.want_shadow);
+                    regen_count(wred, 1, so.want_next);
                 }
             }
         }
@@ -194,18 +239,19 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
             }
         }
     }
+    regen_flush(stage, stage_cnt, rlog, pool_done);
 #undef TRG_RG_HIDX
 #undef TRG_RG_FRAME
 #undef TRG_RG_U
 
     const uint32_t lane = lane_id_opaque();
-    uint32_t vals[8] = { pc.primary, pc.bounce, pc.shadow, pc.shaded, cnt.nodes, cnt.tris, cnt.wnodes, cnt.wtris };
+    uint32_t vals[4] = { cnt.nodes, cnt.tris, cnt.wnodes, cnt.wtris };
     uint32_t *red = reinterpret_cast<uint32_t *>(smem + p.red_off);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        if (!COUNT && k >= 4) break;
-        const uint32_t s = k < 4 ? vals[k] : wave_sum(vals[k]);
-        if (lane == 0) red[wave * 8 + k] = s;
+    for (int k = 0; k < 4; ++k) {
+        if (!COUNT) break;
+        const uint32_t s = wave_sum(vals[k]);
+        if (lane == 0) red[wave * 8 + 4 + k] = s;
     }
     __syncthreads();
     if (wave == 0 && lane < (COUNT ? 8u : 4u)) {
@@ -214,4 +260,46 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
         for (int wv = 0; wv < trg::kWaves; ++wv) s += red[wv * 8 + k];
         if (s) atomicAdd(&p.counters[(blockIdx.x % trg::kCounterSlots) * trg::kCounterWords + k], s);
     }
+}
+
+// ---- sort a tile's log by (frame, pixel) in LDS and fold the chunk into the running average in frame order (Accumulate.metal:19-39) ----
+__global__ __launch_bounds__(trg::kBlock) void regen_accumulate_kernel(const trg::RenderParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    v4f *stage = reinterpret_cast<v4f *>(smem);   // [frame in chunk][pixel in tile]
+    const uint32_t tiles_y = gridDim.x / p.tiles_x;
+    const uint32_t crank = blockIdx.x / tiles_y, by = blockIdx.x % tiles_y;
+    const uint32_t cleft = (p.tiles_x - 1u) / 2u;
+    const uint32_t bx = (crank & 1u) ? cleft + 1u + crank / 2u : cleft - crank / 2u;
+    const uint32_t pl = threadIdx.x, sub = pl >> 6;
+    const uint32_t x = bx * trg::kTileW + (sub % (trg::kTileW / 8)) * 8u + (pl & 7u);
+    const uint32_t y = p.row0 + by * trg::kTileH + (sub / (trg::kTileW / 8)) * 8u + ((pl >> 3) & 7u);
+    const bool valid = (x < p.u.width) && (y < p.row0 + p.rows) && (y < p.u.height);
+    const uint32_t n_rec = (uint32_t)__syncthreads_count(valid ? 1 : 0) * p.spp;   // every valid pixel logged every frame of the chunk
+    const v4f *rlog = reinterpret_cast<const v4f *>(p.tail_radbuf) + (size_t)blockIdx.x * trg::kBlock * p.spp;
+    for (uint32_t i = threadIdx.x; i < n_rec; i += trg::kBlock) {
+        const v4f r = rlog[i];
+        const uint32_t code = (uint32_t)__float_as_int(r.w);
+        stage[(code >> 8) * trg::kBlock + (code & 255u)] = r;
+    }
+    __syncthreads();
+    if (!valid) return;
+    v4f *accum = reinterpret_cast<v4f *>(p.accum);
+    const uint32_t pix = y * p.u.width + x;
+    V3 acc = mk(0.0f, 0.0f, 0.0f);
+    if (p.frame_begin > 0) { const v4f a = accum[pix]; acc = mk(a.x, a.y, a.z); }
+    for (uint32_t fl = 0; fl < p.spp; ++fl) {
+        const v4f r4 = stage[fl * trg::kBlock + pl];
+        const V3 rad = mk(r4.x, r4.y, r4.z);
+        const uint32_t f = p.frame_begin + fl;
+        if (f == 0) {
+            acc = rad;
+        } else {
+            const V3 prev = acc * (float)f;
+            const V3 c = rad + prev;
+            const float f1 = (float)(f + 1u);
+            acc = mk(c.x / f1, c.y / f1, c.z / f1);
+        }
+    }
+    v4f outv; outv.x = acc.x; outv.y = acc.y; outv.z = acc.z; outv.w = 1.0f;
+    accum[pix] = outv;
 }
