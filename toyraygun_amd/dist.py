@@ -105,7 +105,7 @@ class DistributedRenderer:
             # of workgroups) needs more to fill it at all.  4 is never worse than 2 (C2 ms per step, 2 -> 4 in flight: full
             # frame 2.05 -> 2.05, 1/4 0.52 -> 0.50, 1/8 0.31 -> 0.27), costs three more 33 MB buffers and, with the
             # communication stream, the context's and torch's, still fits the 8 hardware queues bench.py asks for.
-            depth = 4
+            depth = int(os.environ.get("TRG_PIPE_DEPTH", "4"))   # (the environment variable is for measurements)
         torch.cuda.set_device(self.device)
         self.ctx = capi.Context(width, height, device=device_index)
         # torch owns the frames (so RCCL can see them); the kernel writes into them through trg_bind_accum
