@@ -71,7 +71,7 @@ TRG_DEV uint32_t wave_sum(uint32_t v) {
 struct ShadeOut { bool want_shadow, want_next, shaded; V3 sdir, scol; float smax; };
 template <bool TAB = false>
 TRG_DEV ShadeOut shade_event(const trg_uniforms &u, const SceneView &sc, const Hit &h, bool found, uint32_t b, bool last, uint32_t hidx,
-                             V3 &o, V3 &d, V3 &thr, V3 &rad, uint32_t &rmask, bool &active, V3 light_color) {
+                             V3 &o, V3 &d, V3 &thr, V3 &rad, uint32_t &rmask, bool &active, V3 light_color, const float *rpre = nullptr) {
     ShadeOut out;
     out.want_shadow = false; out.want_next = false; out.shaded = false; out.sdir = mk(0.0f, 0.0f, 1.0f); out.scol = mk(0.0f, 0.0f, 0.0f); out.smax = -1.0f;
     if (!found) {
@@ -93,7 +93,9 @@ TRG_DEV ShadeOut shade_event(const trg_uniforms &u, const SceneView &sc, const H
         uint32_t hi = hidx;
         asm volatile("" : "+v"(hi));
         r[2] = 0.0f; r[3] = 0.0f;
-        if (last) halton2<TAB>(hi, b, r, sc.htab); else halton4<TAB>(hi, b, r, sc.htab);
+        if (rpre) { r[0] = rpre[0]; r[1] = rpre[1]; r[2] = rpre[2]; r[3] = rpre[3]; }   // the caller evaluated this bounce's dimensions
+        else if (last) halton2<TAB>(hi, b, r, sc.htab);
+        else halton4<TAB>(hi, b, r, sc.htab);
         const LightSample ls = sample_area_light(u, r[0], r[1], P, nrm);
         thr = thr * vcol;
         o = P + nrm * 1e-3f;  // origin of both the shadow ray and the continuation ray

@@ -17,9 +17,10 @@
 // bytes of memory-side write traffic per 16-byte store -- 4.7 GB per C4 launch: the eight pixels of a 128-byte line finish tens of
 // microseconds apart and L2 evicts the partial line in between.)
 //
-// Lane states: TRAVERSING (phase 0: the shadow ray, phase 1: the nearest-hit ray) or WAITING (phase 2) for one of these blocks:
+// Lane states: TRAVERSING (the shadow ray, then the nearest-hit ray) or WAITING for one of these blocks:
 //   class 0      close the path that just ended (fold the last shadow ray, store the radiance) and take the next job of the pool
-//   class 1 + b  shading event number b of the current path (uniform b: the per-bounce Halton dimensions stay a scalar branch)
+//   class 1      a shading event (the Halton dimensions of bounce b have compile-time bases: they are evaluated bounce by bounce for
+//                the lanes at that bounce, a scalar branch each; the rest of the event runs once for all lanes of the block)
 // A block runs when at least TRG_REGEN_MIN lanes wait for it (TRG_REGEN_MIN0 for class 0), when more than TRG_REGEN_MAX_WAIT lanes
 // wait for anything, or when nobody is traversing; the class is taken from a waiting lane picked round robin, and the waiting lanes
 // are looked at every TRG_REGEN_PERIOD-th iteration only.  Measured on C4 (scripts/exp_ab.py, ms alone / per step in the pipeline;
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
     uint32_t stage_cnt = 0u;   // wave-uniform
     __syncthreads();
 #define TRG_RG_FRAME(j) ((j) / (uint32_t)trg::kBlock)
-#define TRG_RG_HIDX ((uint32_t)__float_as_int(park[trg::kBlock]) + p.frame_begin + TRG_RG_FRAME(job))
+#define TRG_RG_HIDX ((uint32_t)__float_as_int(park[trg::kBlock]) + p.frame_begin + TRG_RG_FRAME(TRG_RG_JOB))
     typedef const __attribute__((address_space(4))) trg_uniforms cu_t;
     cu_t *up = (cu_t *)__builtin_amdgcn_kernarg_segment_ptr();   // RenderParams::u is the first member
 #define TRG_RG_U (*(const trg_uniforms *)up)
@@ -98,14 +99,15 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
     const V3 light_color = mk(p.u.light_color[0], p.u.light_color[1], p.u.light_color[2]);
     const uint32_t n_jobs = (uint32_t)trg::kBlock * p.spp;   // jobs of the workgroup's pool: frame j / 256 of tile pixel j % 256
 
-    uint32_t job = 0u;            // the path this lane is working on
-    uint32_t b = 0;               // shading events of its current path so far
+    uint32_t jobb = 0u;           // the path this lane is working on (bits 0..23: its job) and the shading events it has had so far (bits 24..31)
+#define TRG_RG_JOB (jobb & 0xFFFFFFu)
+#define TRG_RG_B (jobb >> 24)
     bool running = p.spp > 0u;
     bool fresh = true;            // no path yet: the first class-0 block only takes a job
     bool job_valid = false;       // the job's pixel lies inside the image / the band
     bool active = false, primary_ray = true;
     bool has_shadow = false, occluded = false, pending_next = false;
-    int phase = 2;
+    bool in_shadow = false, in_next = false;   // traversing the shadow ray / the nearest-hit ray (neither: waiting); lane masks, not a VGPR
     V3 dnext = mk(0.0f, 0.0f, 1.0f), scol = mk(0.0f, 0.0f, 0.0f);
     Trav tv;
     trav_begin(tv, mk(0.0f, 0.0f, 0.0f), mk(0.0f, 0.0f, 1.0f), 0.0f, 0u, stk.first());
@@ -119,13 +121,13 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
 #ifdef TRG_REGEN_GUARD
         if (++guard > (1u << 24)) break;   // bring-up only
 #endif
-        const bool waiting = running && phase == 2;
+        const bool waiting = running && !in_shadow && !in_next;
         const uint64_t wmask = __ballot(waiting);
-        const uint64_t tmask = __ballot(phase < 2);
+        const uint64_t tmask = __ballot(in_shadow || in_next);
         if ((wmask | tmask) == 0ull) break;
         it = (uint32_t)__builtin_amdgcn_readfirstlane((int)(it + 1u));   // (readfirstlane: keeps the loop's wave-uniform counters in SGPRs)
         if (wmask != 0ull && (tmask == 0ull || (it & (uint32_t)(TRG_REGEN_PERIOD - 1)) == 0u)) {
-            const uint32_t cls = (fresh || !active || b >= p.bounces) ? 0u : 1u + b;
+            const uint32_t cls = (fresh || !active || TRG_RG_B >= p.bounces) ? 0u : 1u;
             // the class of a waiting lane, round robin over the lanes so that no class starves
             rot = (uint32_t)__builtin_amdgcn_readfirstlane((int)((rot + 7u) & 63u));
             const uint64_t rolled = (wmask >> rot) | (rot ? (wmask << (64u - rot)) : 0ull);
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
                                 V3 rad = mk(park[6 * trg::kBlock], park[7 * trg::kBlock], park[8 * trg::kBlock]);
                                 if (has_shadow && !occluded) rad = rad + scol;
                                 r4.x = rad.x; r4.y = rad.y; r4.z = rad.z;
-                                r4.w = __int_as_float((int)((TRG_RG_FRAME(job) << 8) | (job % (uint32_t)trg::kBlock)));
+                                r4.w = __int_as_float((int)((TRG_RG_FRAME(TRG_RG_JOB) << 8) | (TRG_RG_JOB % (uint32_t)trg::kBlock)));
                             }
                             const uint32_t drank = mbcnt64(dm);
                             if (n_done > kRegenStage) {   // more than the stage holds at once (a whole wavefront finishing together): straight to the log
@@ -170,13 +172,13 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
                         int base = 0;
                         if (mine && rank == 0u) base = atomicAdd((int *)pool_next, (int)__popcll(mm));   // one LDS atomic per block
                         base = __builtin_amdgcn_readlane(base, __ffsll((long long)mm) - 1);
-                        if (mine) job = (uint32_t)base + rank;
+                        if (mine) jobb = (uint32_t)base + rank;
                     }
                     if (mine) {
                         fresh = false; has_shadow = false; active = false; job_valid = false;
-                        if (job < n_jobs) {
+                        if (TRG_RG_JOB < n_jobs) {
                             // consecutive jobs = the pixels of one 8x8 sub-tile, sub-tile after sub-tile, frame after frame
-                            const uint32_t pl = job % (uint32_t)trg::kBlock, sub = pl >> 6;
+                            const uint32_t pl = TRG_RG_JOB % (uint32_t)trg::kBlock, sub = pl >> 6;
                             const uint32_t x = x0 + (sub % (trg::kTileW / 8)) * 8u + (pl & 7u), y = y0 + (sub / (trg::kTileW / 8)) * 8u + ((pl >> 3) & 7u);
                             job_valid = (x < p.u.width) && (y < p.row0 + p.rows) && (y < p.u.height);
                             if (job_valid) {
@@ -185,9 +187,9 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
                                 raygen<false>(TRG_RG_U, x, y, TRG_RG_HIDX, o, d, nullptr);
                                 park[3 * trg::kBlock] = 1.0f; park[4 * trg::kBlock] = 1.0f; park[5 * trg::kBlock] = 1.0f;   // ray.color
                                 park[6 * trg::kBlock] = 0.0f; park[7 * trg::kBlock] = 0.0f; park[8 * trg::kBlock] = 0.0f;   // the frame's texel
-                                primary_ray = true; b = 0u;
+                                primary_ray = true;   // (taking the job has reset the event count)
                                 active = p.bounces > 0u;   // with no bounce to trace the path is over as it starts
-                                if (active) { trav_begin(tv, o, d, INFINITY, 3u, stk.first()); phase = 1; pending_next = false; }
+                                if (active) { trav_begin(tv, o, d, INFINITY, 3u, stk.first()); in_next = true; pending_next = false; }
                             }
                         } else {
                             running = false;
@@ -195,28 +197,39 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
                     }
                     regen_count(wred, 0, mine && running && job_valid);
                 } else {
-                    const uint32_t bb = csel - 1u;                 // wave-uniform
-                    const bool last = (bb + 1u == p.bounces);      // wave-uniform
+                    // the Halton dimensions of a shading event depend on its bounce number (compile-time bases): they are evaluated bounce
+                    // by bounce for the lanes at that bounce; everything else of the event runs once for all lanes of the block
+                    float r4[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+                    for (uint32_t bb = 0; bb < p.bounces; ++bb) {   // wave-uniform
+                        const bool at = mine && TRG_RG_B == bb;
+                        if (__ballot(at) == 0ull) continue;
+                        if (at) {
+                            uint32_t hi = TRG_RG_HIDX;
+                            asm volatile("" : "+v"(hi));
+                            if (bb + 1u == p.bounces) halton2<false>(hi, bb, r4, nullptr); else halton4<false>(hi, bb, r4, nullptr);
+                        }
+                    }
                     ShadeOut so; so.want_shadow = false; so.want_next = false; so.shaded = false;
                     if (mine) {
+                        const bool last = (TRG_RG_B + 1u == p.bounces);
                         V3 thr = mk(park[3 * trg::kBlock], park[4 * trg::kBlock], park[5 * trg::kBlock]);
                         V3 rad = mk(park[6 * trg::kBlock], park[7 * trg::kBlock], park[8 * trg::kBlock]);
                         if (has_shadow && !occluded) rad = rad + scol;
                         const Hit h = trav_hit(tv);
                         V3 o = tv.o, d = tv.d;
                         uint32_t rmask = primary_ray ? 3u : 1u;
-                        so = shade_event<false>(TRG_RG_U, sc, h, tv.found, bb, last, TRG_RG_HIDX, o, d, thr, rad, rmask, active, light_color);
+                        so = shade_event<false>(TRG_RG_U, sc, h, tv.found, TRG_RG_B, last, TRG_RG_HIDX, o, d, thr, rad, rmask, active, light_color, r4);
                         primary_ray = rmask == 3u;
-                        b = bb + 1u;
+                        jobb += 1u << 24;
                         park[3 * trg::kBlock] = thr.x; park[4 * trg::kBlock] = thr.y; park[5 * trg::kBlock] = thr.z;
                         park[6 * trg::kBlock] = rad.x; park[7 * trg::kBlock] = rad.y; park[8 * trg::kBlock] = rad.z;
                         has_shadow = so.want_shadow; scol = so.scol;
                         if (so.want_shadow) {
                             trav_begin(tv, o, so.sdir, so.smax, 1u, stk.first());
-                            phase = 0; pending_next = so.want_next; dnext = d;
+                            in_shadow = true; pending_next = so.want_next; dnext = d;
                         } else if (so.want_next) {
                             trav_begin(tv, o, d, INFINITY, rmask, stk.first());
-                            phase = 1; pending_next = false;
+                            in_next = true; pending_next = false;
                         }
                         // neither: the path is over (last bounce, light, miss) and the lane waits for class 0
                     }
@@ -226,15 +239,16 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
                 }
             }
         }
-        if (phase < 2) {
-            trav_step_wide<COUNT, trg::kBlock>(sc, tv, phase == 0, stk, cnt);
+        if (in_shadow || in_next) {
+            tv.rmask = (in_next && primary_ray) ? 3u : 1u;   // re-formed every step from the lane masks: not a register across the loop
+            trav_step_wide<COUNT, trg::kBlock>(sc, tv, in_shadow, stk, cnt);
             if (tv.node == kNodeDone) {
-                if (phase == 0) {
+                if (in_shadow) {
                     occluded = tv.found;
-                    if (pending_next) { trav_begin(tv, tv.o, dnext, INFINITY, primary_ray ? 3u : 1u, stk.first()); phase = 1; pending_next = false; }
-                    else phase = 2;
+                    in_shadow = false;
+                    if (pending_next) { trav_begin(tv, tv.o, dnext, INFINITY, 1u, stk.first()); in_next = true; pending_next = false; }
                 } else {
-                    phase = 2;
+                    in_next = false;
                 }
             }
         }
@@ -242,6 +256,8 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
     regen_flush(stage, stage_cnt, rlog, pool_done);
 #undef TRG_RG_HIDX
 #undef TRG_RG_FRAME
+#undef TRG_RG_JOB
+#undef TRG_RG_B
 #undef TRG_RG_U
 
     const uint32_t lane = lane_id_opaque();
