@@ -24,19 +24,22 @@
 // A block runs when at least TRG_REGEN_MIN lanes wait for it (TRG_REGEN_MIN0 for class 0), when more than TRG_REGEN_MAX_WAIT lanes
 // wait for anything, or when nobody is traversing; the class is taken from a waiting lane picked round robin, and the waiting lanes
 // are looked at every TRG_REGEN_PERIOD-th iteration only.  Measured on C4 (scripts/exp_ab.py, ms alone / per step in the pipeline;
-// the lock-step kernel: 25.9 / 22.6): thresholds 16 / 16 / 40 every iteration 33.6 / 30.1 WITHOUT the pool (a lane kept its pixel:
-// the spread between the pixels of a tile stayed), 8 / 8 / 16 every 2nd 23.4 / 20.9, 8 / 2 / 16 every 4th 22.5 / 20.5 (default),
-// 16 / 16 / 32 every 4th 24.5 / 21.9; letting leaf lanes wait until 8-16 of them can share the triangle half of the step: +1.5-2.5 ms.
+// the lock-step kernel: 25.9 / 22.6), in the order built: a lane keeping its pixel, one class per bounce, thresholds 16 / 16 / 40
+// every iteration 33.6 / 30.1 (the spread between the pixels of a tile stays); jobs from a per-wavefront pool, 8 / 8 / 16 every 2nd
+// 23.4 / 20.9; 8 / 2 / 16 every 4th 22.5 / 20.5; one pool per workgroup 20.7 / 18.7; ONE shading class (per-bounce Halton inside the
+// block) 20.0 / 18.3; with that 12 / 4 / 24: 19.3 / 17.8, 16 / 4 / 32: 19.2 / 17.7 (default), 20 / 4 / 32: 19.7 / 17.9, 24 / 8 / 40:
+// 20.1 / 18.0, every 2nd iteration +0.5.  Letting lanes at a leaf wait until 8-16 of them share the triangle half of the step:
+// +1.5-2.5 ms.
 #pragma once
 
 #ifndef TRG_REGEN_MIN
-#define TRG_REGEN_MIN 8
+#define TRG_REGEN_MIN 16
 #endif
 #ifndef TRG_REGEN_MAX_WAIT
-#define TRG_REGEN_MAX_WAIT 16
+#define TRG_REGEN_MAX_WAIT 32
 #endif
 #ifndef TRG_REGEN_MIN0
-#define TRG_REGEN_MIN0 2   // class 0 -- closing a path and taking a job -- costs a fifth of a shading event: a lower threshold
+#define TRG_REGEN_MIN0 4   // class 0 -- closing a path and taking a job -- costs a fifth of a shading event: a lower threshold
 #endif
 #ifndef TRG_REGEN_PERIOD
 #define TRG_REGEN_PERIOD 4   // the waiting lanes are looked at every PERIOD-th iteration (a power of two)
