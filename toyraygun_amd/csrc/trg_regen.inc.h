@@ -97,7 +97,7 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
     // the ray counters (primary, bounce, shadow, shaded) are kept in the wavefront's row of the LDS reduction scratch, not in registers:
     // the blocks below run under conditions the compiler does not see as wave-uniform, where a loop-carried sum becomes a VGPR
     lds_int_t *wred = (lds_int_t *)(reinterpret_cast<int *>(smem + p.red_off) + wave * 8u);
-    if (lane_id() < 4u) wred[lane_id()] = 0;
+    if (lane_id() < 8u) wred[lane_id()] = 0;
     Counters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.wnodes = 0; cnt.wtris = 0;
     const V3 light_color = mk(p.u.light_color[0], p.u.light_color[1], p.u.light_color[2]);
     const uint32_t n_jobs = (uint32_t)trg::kBlock * p.spp;   // jobs of the workgroup's pool: frame j / 256 of tile pixel j % 256
@@ -128,6 +128,9 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
         const uint64_t wmask = __ballot(waiting);
         const uint64_t tmask = __ballot(in_shadow || in_next);
         if ((wmask | tmask) == 0ull) break;
+#ifdef TRG_REGEN_DIAG   // measurement build: lanes waiting / out of work / iterations, reported through the node / triangle / iteration counters
+        if (lane_id() == 0u) { wred[4] += __popcll(wmask); wred[5] += 64 - __popcll(wmask | tmask); wred[6] += 1; }
+#endif
         it = (uint32_t)__builtin_amdgcn_readfirstlane((int)(it + 1u));   // (readfirstlane: keeps the loop's wave-uniform counters in SGPRs)
         if (wmask != 0ull && (tmask == 0ull || (it & (uint32_t)(TRG_REGEN_PERIOD - 1)) == 0u)) {
             const uint32_t cls = (fresh || !active || TRG_RG_B >= p.bounces) ? 0u : 1u;
@@ -268,12 +271,19 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
     uint32_t *red = reinterpret_cast<uint32_t *>(smem + p.red_off);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+#ifdef TRG_REGEN_DIAG
+        break;
+#endif
         if (!COUNT) break;
         const uint32_t s = wave_sum(vals[k]);
         if (lane == 0) red[wave * 8 + 4 + k] = s;
     }
     __syncthreads();
+#ifdef TRG_REGEN_DIAG
+    if (wave == 0 && lane < 8u) {
+#else
     if (wave == 0 && lane < (COUNT ? 8u : 4u)) {
+#endif
         const uint32_t k = lane;
         unsigned long long s = 0;
         for (int wv = 0; wv < trg::kWaves; ++wv) s += red[wv * 8 + k];
