@@ -4,14 +4,15 @@
 // render_kernel walks a wavefront's 64 pixels in lock step: every trace call ends when its slowest lane does, and on the
 // million-triangle scene 16 of the 64 lanes do useful work per instruction (profiles/r02).  Here a workgroup owns the same 16x16 pixels
 // and the chunk's frames of them as a POOL of path jobs (job j = frame j / 256 of tile pixel j % 256), and every lane of its four
-// wavefronts works through jobs at its own pace: a lane whose rays are finished waits only until enough lanes are in the same situation (the same bounce to
-// shade, or a path to close and a new job to take), then those lanes run that block together while the others keep traversing.
+// wavefronts works through jobs at its own pace: a lane whose rays are finished waits only until enough lanes are in the same
+// situation (a shading event to run, or a path to close and a new job to take), then those lanes run that block together while the
+// others keep traversing.
 // Neither the spread of ray lengths inside a trace call nor the spread of cost between the pixels of a tile leaves lanes idle:
 // what is left is the end of the pool.  Path state never leaves the lane (registers plus a few LDS words), jobs are handed out
 // with one LDS counter per workgroup and a ballot prefix (one LDS atomic per block of lanes) -- no queue in memory, no barrier.
 //
 // A finished path's radiance is APPENDED to the workgroup's log in HBM -- (radiance, frame-in-chunk << 8 | pixel-in-tile), 16 bytes,
-// the lanes of a block write consecutive records -- and regen_accumulate_kernel sorts a tile's log by (frame, pixel) in LDS and
+// staged 32 records at a time per wavefront in LDS and written 512 bytes at a time -- and regen_accumulate_kernel sorts a tile's log by (frame, pixel) in LDS and
 // folds the chunk into the running average in frame order with Accumulate.metal's arithmetic, so the image is bit-identical to
 // render_kernel's (and to the oracle's in the strict build).  (Writing each radiance to its [frame][pixel] slot instead cost 142
 // bytes of memory-side write traffic per 16-byte store -- 4.7 GB per C4 launch: the eight pixels of a 128-byte line finish tens of
