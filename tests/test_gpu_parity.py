@@ -1284,7 +1284,8 @@ def test_async_render_frame_loop(capi, O):
         c.close()
 
 
-def test_device_group_c_abi(capi, O, cornell):
+@pytest.mark.parametrize("force_global", [0, 1])
+def test_device_group_c_abi(capi, O, cornell, force_global):
     """trg_group_* (multi-GPU behind the C ABI) on the devices that are here: with one device the group path (padded
     frame buffer bound as the accumulation target, band arithmetic, per-device host thread, stats reduction) must reproduce the
     plain context bit for bit for every gather mode; with two or more visible devices the RCCL exchange runs and every device
@@ -1295,9 +1296,11 @@ def test_device_group_c_abi(capi, O, cornell):
     ref_ctx = make_ctx(O, cornell, w, h)
     try:
         ref_ctx.set_option(capi.OPT_STRICT, 1)
+        ref_ctx.set_option(capi.OPT_FORCE_GLOBAL, force_global)   # 1: the scene stays in HBM -- the path-regeneration kernel per band
         ref_ctx.reset_stats()
         ref_ctx.render(0, spp, bnc)
         ref, rst = ref_ctx.read_accum(), ref_ctx.stats()
+        assert rst.scene_in_lds == 1 - force_global
     finally:
         ref_ctx.close()
     b = cornell.buffers()
@@ -1310,6 +1313,7 @@ def test_device_group_c_abi(capi, O, cornell):
             g.set_uniforms(O.uniforms_bytes(O.make_uniforms(w, h)))
             g.set_pixel_offsets_seed()
             g.set_option(capi.OPT_STRICT, 1)
+            g.set_option(capi.OPT_FORCE_GLOBAL, force_global)
             for mode, root in ((capi.GATHER_ALL, 0), (capi.GATHER_ROOT, n - 1), (capi.GATHER_NONE, 0)):
                 g.render(0, spp, bnc, gather=mode, root=root)
                 g.sync()
