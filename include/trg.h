@@ -101,11 +101,12 @@ enum trg_option {
                                  K.. with every lane live again (same result bit for bit; pays when paths die over many bounces: C3).
                                  0 = never; -1 (default) = K = 2 when the launch has 4 bounces or more */
     TRG_OPT_TAIL_LEVELS = 10, /* 0 (default): the tail launches re-compact every second bounce after K; 1: one compaction at K only */
-    TRG_OPT_REGEN = 11,       /* TRG_KERNEL_DIRECT on a scene in HBM (frame-serial launches): 1 or -1 (default) = path regeneration -- every
+    TRG_OPT_REGEN = 11,       /* TRG_KERNEL_DIRECT on a scene in HBM (frame-serial launches): 1 = path regeneration -- every
                                  wavefront works through the (pixel, frame) jobs of its 8x8 tile as a pool, each lane at its own pace
                                  (a lane that has finished a path takes the next job instead of waiting for the slowest lane of its
                                  wavefront); the frames go through a radiance buffer that is folded in frame order, so the result is
-                                 bit-identical; 0 = one pixel per lane in lock step */
+                                 bit-identical; 0 = one pixel per lane in lock step; -1 (default) = regeneration for scenes of 32,768
+                                 triangles or more (below, a shading event costs as much as its rays and lock step is faster) */
     TRG_OPT_FRAME_SPLIT = 7   /* TRG_KERNEL_DIRECT only: frame lanes per workgroup. 1: a pixel's frames run one after the other in one
                                  lane; 2 or 4: that many wavefronts share a pixel's frames (same result bit for bit; fills the chip
                                  when the pixel grid alone does not -- small windows, row bands of a multi-GPU job);

@@ -1296,7 +1296,8 @@ def test_device_group_c_abi(capi, O, cornell, force_global):
     ref_ctx = make_ctx(O, cornell, w, h)
     try:
         ref_ctx.set_option(capi.OPT_STRICT, 1)
-        ref_ctx.set_option(capi.OPT_FORCE_GLOBAL, force_global)   # 1: the scene stays in HBM -- the path-regeneration kernel per band
+        ref_ctx.set_option(capi.OPT_FORCE_GLOBAL, force_global)   # 1: the scene stays in HBM ...
+        ref_ctx.set_option(capi.OPT_REGEN, 1)                      # ... and is rendered by the path-regeneration kernel (per band below)
         ref_ctx.reset_stats()
         ref_ctx.render(0, spp, bnc)
         ref, rst = ref_ctx.read_accum(), ref_ctx.stats()
@@ -1314,6 +1315,7 @@ def test_device_group_c_abi(capi, O, cornell, force_global):
             g.set_pixel_offsets_seed()
             g.set_option(capi.OPT_STRICT, 1)
             g.set_option(capi.OPT_FORCE_GLOBAL, force_global)
+            g.set_option(capi.OPT_REGEN, 1)
             for mode, root in ((capi.GATHER_ALL, 0), (capi.GATHER_ROOT, n - 1), (capi.GATHER_NONE, 0)):
                 g.render(0, spp, bnc, gather=mode, root=root)
                 g.sync()

@@ -55,7 +55,7 @@ struct trg_ctx {
     int opt_gpu_build = 0;   // TRG_OPT_GPU_BUILD: 0 host SAH, 1 device binned SAH, 2 device LBVH (Karras), 3 device PLOC
     int opt_fsplit = 0;  // 0 = auto
     int opt_tail = -1;   // TRG_OPT_TAIL_BOUNCE: -1 auto, 0 off, K
-    int opt_regen = -1;        // TRG_OPT_REGEN: -1 / 1 = path regeneration for HBM-resident scenes (direct kernel, frame-serial), 0 = the lock-step kernel
+    int opt_regen = -1;        // TRG_OPT_REGEN: 1 = path regeneration for HBM-resident scenes (direct kernel, frame-serial), -1 = from 32,768 triangles on, 0 = the lock-step kernel
     uint32_t last_regen = 0;
     int opt_tail_levels = 0;   // TRG_OPT_TAIL_LEVELS: 0 = re-compact every second bounce after K, 1 = once at K only
     int opt_in_flight = 1;  // launches of this context the caller keeps in flight (TRG_OPT_LAUNCHES_IN_FLIGHT)
@@ -124,6 +124,7 @@ constexpr uint32_t kStackLdsLevels = TRG_STACK_LDS_LEVELS;
 #ifndef TRG_TAIL_LEVEL_STEP
 #define TRG_TAIL_LEVEL_STEP 2
 #endif
+constexpr uint32_t kRegenAutoMinTris = 32768u;   // TRG_OPT_REGEN -1: path regeneration from this many triangles on
 constexpr uint32_t kTailAutoMinBounces = TRG_TAIL_AUTO_MIN_BOUNCES, kTailAutoK = TRG_TAIL_AUTO_K, kTailChunkFrames = 16, kTailLevelStep = TRG_TAIL_LEVEL_STEP;
 #ifndef TRG_WAVEFRONT_FOR_HBM
 #define TRG_WAVEFRONT_FOR_HBM 0   // what TRG_KERNEL_AUTO picks for a scene traversed from HBM (1 = the wavefront schedule)
@@ -706,7 +707,12 @@ int trg_render(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces,
 
     // ---- path regeneration (trg_regen.inc.h): scene in HBM, frame-serial direct kernel.  The frames go in chunks through a
     //      radiance buffer [frame in chunk][pixel in band] that tail_accumulate_kernel folds in frame order.
-    const bool regen = c->opt_regen != 0 && !pool && fsplit == 1 && !plan.lds_scene && plan.acc_off != 0;
+    // automatic: from kRegenAutoMinTris triangles on.  Below, a shading event costs about as much as the two rays it produces and
+    // running it for a quarter of a wavefront at a time loses (1080p, 16 spp, 3 bounces, lock step / regeneration in ms: 36 triangles
+    // 4.2 / 6.0, 2.6 K 8.1 / 9.1, 8.8 K 12.5 / 12.2, 21 K 12.9 / 13.0, 49 K 15.5 / 14.4, 96 K 17.8 / 15.5, 263 K 21.4 / 17.8, 560 K 24.0 / 18.5,
+    // 1.02 M 25.9 / 19.4: scripts/regen_crossover.py)
+    const bool regen_wanted = c->opt_regen > 0 || (c->opt_regen < 0 && c->sc.n_tris >= kRegenAutoMinTris);
+    const bool regen = regen_wanted && !pool && fsplit == 1 && !plan.lds_scene && plan.acc_off != 0;
     c->last_regen = regen ? 1u : 0u;
     if (regen) {
         const uint32_t fc = std::min<uint32_t>(std::max<uint32_t>(spp, 1u), kTailChunkFrames);
