@@ -83,6 +83,41 @@ def test_struct_layouts(built):
     assert capi.ISECT_DTYPE.itemsize == 16
 
 
+def test_python_binding_matches_the_header(built, tmp_path):
+    """The ctypes binding (toyraygun_amd/capi.py) restates enums and the trg_stats layout of include/trg.h by hand: a C probe compiled
+    against the header prints the real values, and every one the binding names must agree."""
+    import re
+    import subprocess
+    from toyraygun_amd import capi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "trg.h")).read()
+    names = sorted(set(re.findall(r"\b(TRG_(?:OPT|KERNEL|GATHER|ERR)_[A-Z_0-9]+)\b", hdr)))
+    fields = re.search(r"typedef struct trg_stats \{(.*?)\} trg_stats;", hdr, re.S).group(1)
+    fields = re.sub(r"/\*.*?\*/", "", fields, flags=re.S)
+    members = [m for decl in re.findall(r"(?:uint64_t|uint32_t|double)\s+([^;]+);", fields) for m in re.split(r"\s*,\s*", decl.strip())]
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "trg.h"', 'int main(void) {']
+    src += ['  printf("%s %%d\\n", (int)%s);' % (n, n) for n in names]
+    src += ['  printf("sizeof_stats %d\\n", (int)sizeof(trg_stats));']
+    src += ['  printf("off_%s %%d\\n", (int)offsetof(trg_stats, %s));' % (m, m) for m in members]
+    src += ['  return 0; }']
+    c_file = tmp_path / "probe.c"
+    c_file.write_text("\n".join(src))
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(root, "include"), str(c_file), "-o", str(exe)])
+    vals = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for n in names:   # e.g. TRG_OPT_REGEN <-> capi.OPT_REGEN, TRG_ERR_RANGE <-> capi.ERR_RANGE
+        py = n[4:]
+        if hasattr(capi, py):
+            assert getattr(capi, py) == int(vals[n]), n
+    for need in ("OPT_REGEN", "OPT_GPU_BUILD", "OPT_TAIL_BOUNCE", "KERNEL_WAVEFRONT", "GATHER_ROOT"):
+        assert hasattr(capi, need)
+    assert C.sizeof(capi.Stats) == int(vals["sizeof_stats"])
+    py_fields = dict((name, getattr(capi.Stats, name).offset) for name, _ in capi.Stats._fields_)
+    assert set(py_fields) == set(members)
+    for m in members:
+        assert py_fields[m] == int(vals["off_" + m]), m
+
+
 def test_host_scene_equals_oracle_scene(built, O):
     from toyraygun_amd import host
     hs, os_ = host.Scene.cornell_box().buffers(), O.OracleScene.cornell_box().buffers()
