@@ -190,6 +190,9 @@ static uint32_t choose_fsplit(const trg_ctx *c, uint32_t spp, uint32_t rows) {
     // (C2 bands, ms per step, frame-serial vs 4 lanes: 1/4 frame 0.56 vs 0.63 at k = 2; 1/8 frame 0.375 vs 0.314 at
     // k = 2, 0.295 vs 0.312 at k = 3, 0.273 vs 0.311 at k = 4)
     if (c->opt_in_flight >= 2 ? groups * (uint64_t)c->opt_in_flight >= 2ull * kResidentGroups : groups > 4ull * kResidentGroups) return 1u;
+    // a large scene in HBM has the path-regeneration kernel behind the frame-serial launch: it already wins on half a 1080p frame
+    // (C4 bands, ms alone, 4 frame lanes / regeneration: 135 rows 4.1 / 6.1, 270 rows 7.3 / 7.2, 540 rows 13.4 / 12.9; scripts/gpu_c4_bands.py)
+    if (c->opt_regen != 0 && c->sc.n_tris >= kRegenAutoMinTris && groups > 2ull * kResidentGroups) return 1u;
     return spp >= 4 ? 4u : 2u;
 }
 
