@@ -110,7 +110,8 @@ enum trg_option {
     TRG_OPT_FRAME_SPLIT = 7   /* TRG_KERNEL_DIRECT only: frame lanes per workgroup. 1: a pixel's frames run one after the other in one
                                  lane; 2 or 4: that many wavefronts share a pixel's frames (same result bit for bit; fills the chip
                                  when the pixel grid alone does not -- small windows, row bands of a multi-GPU job);
-                                 0 (default): chosen per launch from the grid size and spp */
+                                 0 (default): chosen per launch from the grid size and spp.  Scenes rendered by the path-regeneration
+                                 kernel (TRG_OPT_REGEN) take the lanes at workgroup level: that many workgroups share a tile's frames */
 };
 enum trg_kernel {
     TRG_KERNEL_DIRECT = 0,    /* one path per lane, rays traced by the lane that owns the pixel */

@@ -1,3 +1,4 @@
+"""C4 (1.02 M triangles, 1920 wide, 16 spp, 3 bounces) on row bands of a multi-GPU job / small windows: ms alone per schedule."""
 import sys; sys.path.insert(0, ".")
 from toyraygun_amd import capi, host
 W, H = 1920, 1080
@@ -5,8 +6,8 @@ b = host.Scene.cornell_lattice(44).buffers()
 c = capi.Context(W, H)
 c.load_scene(b["positions"], b["normals"], b["colors"], b["indices"], b["material_ids"])
 c.set_uniforms(host.uniforms(W, H)[0]); c.set_pixel_offsets_seed()
-for rows, row0 in ((135, 472), (270, 405), (540, 270)):
-    for name, fs, rg in (("auto", 0, -1), ("fsplit1 lock", 1, 0), ("fsplit1 regen", 1, 1), ("fsplit4", 4, 0), ("fsplit2", 2, 0)):
+for rows, row0 in ((135, 472), (270, 405), (540, 270), (1080, 0)):
+    for name, fs, rg in (("auto", 0, -1), ("fsplit1 lock", 1, 0), ("fsplit1 regen", 1, 1), ("fsplit4 lock", 4, 0), ("fsplit2 lock", 2, 0), ("fsplit2 regen", 2, 1), ("fsplit4 regen", 4, 1)):
         c.set_option(capi.OPT_FRAME_SPLIT, fs); c.set_option(capi.OPT_REGEN, rg)
         c.render(0, 16, 3, row0, rows)
         ts = []

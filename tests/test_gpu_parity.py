@@ -1213,6 +1213,14 @@ def test_path_regeneration_is_bit_exact(capi, O):
                     imgs[(strict, regen)] = (c.read_accum().copy(), st.rays)
                 assert np.array_equal(_bits(imgs[(strict, 0)][0]), _bits(imgs[(strict, 1)][0])), (w, h, spp, bounces, strict)
                 assert imgs[(strict, 0)][1] == imgs[(strict, 1)][1]
+                for lanes in (2, 4):   # frame lanes: that many workgroups share a tile's frames (small grids)
+                    c.set_option(capi.OPT_FRAME_SPLIT, lanes)
+                    c.reset_stats()
+                    c.render(0, spp, bounces)
+                    st = c.stats()
+                    assert st.last_regen == 1 and st.last_frame_split == (lanes if spp >= 2 else 1)
+                    assert np.array_equal(_bits(c.read_accum()), _bits(imgs[(strict, 0)][0])) and st.rays == imgs[(strict, 0)][1], (w, h, spp, bounces, strict, lanes)
+                c.set_option(capi.OPT_FRAME_SPLIT, 1)
             if spp <= 5:
                 O.set_trig_mode(O.TRIG_PORTABLE)
                 try:

@@ -163,6 +163,13 @@ static bool plan_lds_as(const trg_ctx *c, LdsPlan &p, bool lds_scene, bool pool,
     limit = (pool || fp_slots) ? 160u * 1024u : 64u * 1024u;  // above 64 KB the launcher opts in per kernel
     return p.total <= limit;
 }
+// the frame-serial plan without touching the context's error state: true when there is one
+static bool plan_lds_quiet(const trg_ctx *c, LdsPlan &p) {
+    const bool want_lds = !c->opt_force_global && c->sc.lds_stage_bytes != 0 && c->sc.lds_stage_bytes <= kMaxLdsScene;
+    uint32_t limit = 0;
+    if (want_lds && plan_lds_as(c, p, true, false, 0, limit, true)) return true;
+    return plan_lds_as(c, p, false, false, 0, limit, true);
+}
 static int plan_lds(trg_ctx *c, LdsPlan &p, bool pool = false, uint32_t fp_slots = 0, bool park = true) {
     const bool want_lds = !c->opt_force_global && c->sc.lds_stage_bytes != 0 && c->sc.lds_stage_bytes <= kMaxLdsScene;
     uint32_t limit = 0;
@@ -185,14 +192,16 @@ static uint32_t choose_fsplit(const trg_ctx *c, uint32_t spp, uint32_t rows) {
     if (c->opt_fsplit == 1 || spp < 2) return 1u;
     if (c->opt_fsplit == 2 || c->opt_fsplit == 4) return (uint32_t)c->opt_fsplit;
     const uint64_t groups = (uint64_t)((c->w + kTileW - 1) / kTileW) * ((rows + kTileH - 1) / kTileH);
+    // a large scene in HBM is rendered by the path-regeneration kernel, which takes the frame lanes itself (so many workgroups per
+    // tile).  One launch alone (C4, 16 spp, ms; lock step with 4 lanes / regeneration with 1, 2, 4 lanes; scripts/gpu_c4_bands.py):
+    // 135 rows 4.1 / 6.1 3.96 3.74, 270 rows 7.2 / 7.2 6.96 6.07, 540 rows 13.4 / 12.8 11.0 11.2, 1080 rows 24.1 / 20.0 19.0 19.7;
+    // four full frames in flight: 17.8, 18.4, 19.6 per step -- the overlap hides the ends of the pools better than smaller pools do
+    if (c->opt_regen != 0 && c->sc.n_tris >= kRegenAutoMinTris && c->opt_in_flight < 2) return groups > 3000ull ? 2u : (spp >= 4 ? 4u : 2u);
     // a caller that overlaps consecutive launches (k frames in flight on k streams) hides the tail by itself: then the
     // frame-serial kernel wins as soon as the launches in flight together hold about two resident sets of workgroups
     // (C2 bands, ms per step, frame-serial vs 4 lanes: 1/4 frame 0.56 vs 0.63 at k = 2; 1/8 frame 0.375 vs 0.314 at
     // k = 2, 0.295 vs 0.312 at k = 3, 0.273 vs 0.311 at k = 4)
     if (c->opt_in_flight >= 2 ? groups * (uint64_t)c->opt_in_flight >= 2ull * kResidentGroups : groups > 4ull * kResidentGroups) return 1u;
-    // a large scene in HBM has the path-regeneration kernel behind the frame-serial launch: it already wins on half a 1080p frame
-    // (C4 bands, ms alone, 4 frame lanes / regeneration: 135 rows 4.1 / 6.1, 270 rows 7.3 / 7.2, 540 rows 13.4 / 12.9; scripts/gpu_c4_bands.py)
-    if (c->opt_regen != 0 && c->sc.n_tris >= kRegenAutoMinTris && groups > 2ull * kResidentGroups) return 1u;
     return spp >= 4 ? 4u : 2u;
 }
 
@@ -629,6 +638,13 @@ int trg_render(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces,
     const bool pool = kernel == TRG_KERNEL_POOL;
     // frame lanes per workgroup (render_fp_kernel) -- see choose_fsplit
     uint32_t fsplit = pool ? 1u : choose_fsplit(c, spp, rows);
+    // a large scene in HBM: the path-regeneration kernel takes the frame lanes itself (so many workgroups per tile)
+    const bool regen_wanted = c->opt_regen > 0 || (c->opt_regen < 0 && c->sc.n_tris >= kRegenAutoMinTris);
+    uint32_t regen_lanes = 0u;
+    if (regen_wanted && !pool) {
+        LdsPlan rp;
+        if (plan_lds_quiet(c, rp) && !rp.lds_scene && rp.acc_off != 0u) { regen_lanes = fsplit; fsplit = 1u; }
+    }
     uint32_t fp_rounds = fsplit > 1 ? std::min<uint32_t>((spp + fsplit - 1) / fsplit, kFpMaxRounds) : 0u;
     LdsPlan plan;
     if (fsplit > 1 && c->opt_fsplit == 0 && plan_lds(c, plan, false, fp_rounds) != TRG_OK) { fsplit = 1u; fp_rounds = 0u; }  // auto: no room to park
@@ -651,7 +667,7 @@ int trg_render(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces,
     const uint32_t tiles_y = (rows + tile_h - 1) / tile_h;
     if ((uint64_t)p.tiles_x * tiles_y > 0x7FFFFFFFull) return fail(c, TRG_ERR_RANGE, "trg_render: grid too large");
     const uint32_t grid = p.tiles_x * tiles_y;
-    if (int rc = ensure_stack_scratch(c, plan, (uint64_t)grid * kBlock, p.stack, slot)) return rc;
+    if (int rc = ensure_stack_scratch(c, plan, (uint64_t)grid * std::max(regen_lanes, 1u) * kBlock, p.stack, slot)) return rc;
 
     // ---- tail compaction (trg_tail.inc.h): scene in LDS, frame-serial direct kernel, enough bounces for paths to die.  Measured on
     //      the Cornell box at 1080p, 16 spp, K = 2 and a re-compaction every second bounce, four frames in flight: 3 bounces 1.862 vs
@@ -710,16 +726,17 @@ int trg_render(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces,
 
     // ---- path regeneration (trg_regen.inc.h): scene in HBM, frame-serial direct kernel.  The frames go in chunks through a
     //      radiance buffer [frame in chunk][pixel in band] that tail_accumulate_kernel folds in frame order.
-    // automatic: from kRegenAutoMinTris triangles on.  Below, a shading event costs about as much as the two rays it produces and
-    // running it for a quarter of a wavefront at a time loses (1080p, 16 spp, 3 bounces, lock step / regeneration in ms: 36 triangles
-    // 4.2 / 6.0, 2.6 K 8.1 / 9.1, 8.8 K 12.5 / 12.2, 21 K 12.9 / 13.0, 49 K 15.5 / 14.4, 96 K 17.8 / 15.5, 263 K 21.4 / 17.8, 560 K 24.0 / 18.5,
-    // 1.02 M 25.9 / 19.4: scripts/regen_crossover.py)
-    const bool regen_wanted = c->opt_regen > 0 || (c->opt_regen < 0 && c->sc.n_tris >= kRegenAutoMinTris);
-    const bool regen = regen_wanted && !pool && fsplit == 1 && !plan.lds_scene && plan.acc_off != 0;
+    // automatic (regen_wanted above): from kRegenAutoMinTris triangles on.  Below, a shading event costs about as much as the two rays it
+    // produces and running it for a quarter of a wavefront at a time loses (1080p, 16 spp, 3 bounces, lock step / regeneration in ms: 36
+    // triangles 4.2 / 6.0, 2.6 K 8.1 / 9.1, 8.8 K 12.5 / 12.2, 21 K 12.9 / 13.0, 49 K 15.5 / 14.4, 96 K 17.8 / 15.5, 263 K 21.4 / 17.8,
+    // 560 K 24.0 / 18.5, 1.02 M 25.9 / 19.4: scripts/regen_crossover.py)
+    const bool regen = regen_lanes != 0u;
     c->last_regen = regen ? 1u : 0u;
     if (regen) {
         const uint32_t fc = std::min<uint32_t>(std::max<uint32_t>(spp, 1u), kTailChunkFrames);
-        const size_t rad_bytes = (size_t)grid * kBlock * fc * 16u;   // one log of 256 x fc records per workgroup
+        const uint32_t rgrid = grid * regen_lanes;
+        const size_t rad_bytes = (size_t)rgrid * kBlock * ((fc + regen_lanes - 1u) / regen_lanes) * 16u;   // one log of 256 x frames records per workgroup
+        p.fsplit = regen_lanes;
         if (rad_bytes > c->wf_bytes[slot]) {
             if (c->wf_mem[slot]) { (void)hipDeviceSynchronize(); (void)hipFree(c->wf_mem[slot]); c->wf_mem[slot] = nullptr; c->wf_bytes[slot] = 0; }
             hipError_t me = hipMalloc((void **)&c->wf_mem[slot], rad_bytes);
@@ -730,12 +747,12 @@ int trg_render(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces,
         if (c->opt_timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
         for (uint32_t f0 = 0; f0 < spp; f0 += fc) {
             p.frame_begin = frame_begin + f0; p.spp = std::min(fc, spp - f0);
-            hipError_t te = c->opt_strict ? launch_render_regen_strict(p, c->opt_counters, grid, plan.total, c->stream)
-                                          : launch_render_regen_fast(p, c->opt_counters, grid, plan.total, c->stream);
+            hipError_t te = c->opt_strict ? launch_render_regen_strict(p, c->opt_counters, rgrid, plan.total, c->stream)
+                                          : launch_render_regen_fast(p, c->opt_counters, rgrid, plan.total, c->stream);
             if (te == hipSuccess) te = c->opt_strict ? launch_regen_accumulate_strict(p, grid, c->stream) : launch_regen_accumulate_fast(p, grid, c->stream);
             if (te != hipSuccess) return fail(c, TRG_ERR_DEVICE, "trg_render: regeneration launch failed: %s", hipGetErrorString(te));
         }
-        c->renders++; c->launches++; c->last_fsplit = 1;
+        c->renders++; c->launches++; c->last_fsplit = regen_lanes;
         if (c->opt_timing) {
             HIPCHK(c, hipEventRecord(c->ev1, c->stream));
             HIPCHK(c, hipEventSynchronize(c->ev1));

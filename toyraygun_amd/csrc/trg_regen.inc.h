@@ -73,12 +73,16 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
     stk.set(smem, p.stack_off, p.stack.overflow, p.stack.klds);
 
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t tiles_y = gridDim.x / p.tiles_x;
-    const uint32_t crank = blockIdx.x / tiles_y, by = blockIdx.x % tiles_y;
+    // p.fsplit workgroups share a tile ("frame lanes", as in render_fp_kernel): lane fl takes the frames fl, fl + F, ... of the chunk, so
+    // that a launch of few tiles (a row band, a small window) still fills the chip
+    const uint32_t F = p.fsplit, tile_id = blockIdx.x / F, fl = blockIdx.x % F;   // wave-uniform
+    const uint32_t tiles_y = (gridDim.x / F) / p.tiles_x;
+    const uint32_t crank = tile_id / tiles_y, by = tile_id % tiles_y;
     const uint32_t cleft = (p.tiles_x - 1u) / 2u;
     const uint32_t bx = (crank & 1u) ? cleft + 1u + crank / 2u : cleft - crank / 2u;
     const uint32_t x0 = bx * trg::kTileW, y0 = p.row0 + by * trg::kTileH;   // the workgroup's 16x16 tile
-    v4f *rlog = reinterpret_cast<v4f *>(p.tail_radbuf) + (size_t)blockIdx.x * trg::kBlock * p.spp;   // this workgroup's log: 256 x spp records
+    const uint32_t frames_wg = p.spp > fl ? (p.spp - fl + F - 1u) / F : 0u, frames_max = (p.spp + F - 1u) / F;
+    v4f *rlog = reinterpret_cast<v4f *>(p.tail_radbuf) + (size_t)blockIdx.x * trg::kBlock * frames_max;   // this workgroup's log: 256 x frames records
     // per thread in LDS ([word][thread]): the Halton offset of the current job's pixel (1), throughput (3..5), radiance (6..8)
     lds_float_t *park = (lds_float_t *)(reinterpret_cast<float *>(smem + p.acc_off) + threadIdx.x);
     // the pool counter of the workgroup: the spare word [2] of thread 0
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
     regen_rec_t *stage = (regen_rec_t *)(reinterpret_cast<float *>(smem + p.acc_off) + (wave >> 1) * 9u * trg::kBlock) + (wave & 1u) * kRegenStage;
     uint32_t stage_cnt = 0u;   // wave-uniform
     __syncthreads();
-#define TRG_RG_FRAME(j) ((j) / (uint32_t)trg::kBlock)
+#define TRG_RG_FRAME(j) (((j) / (uint32_t)trg::kBlock) * F + fl)   /* frame of the chunk */
 #define TRG_RG_HIDX ((uint32_t)__float_as_int(park[trg::kBlock]) + p.frame_begin + TRG_RG_FRAME(TRG_RG_JOB))
     typedef const __attribute__((address_space(4))) trg_uniforms cu_t;
     cu_t *up = (cu_t *)__builtin_amdgcn_kernarg_segment_ptr();   // RenderParams::u is the first member
@@ -101,12 +105,12 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
     if (lane_id() < 8u) wred[lane_id()] = 0;
     Counters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.wnodes = 0; cnt.wtris = 0;
     const V3 light_color = mk(p.u.light_color[0], p.u.light_color[1], p.u.light_color[2]);
-    const uint32_t n_jobs = (uint32_t)trg::kBlock * p.spp;   // jobs of the workgroup's pool: frame j / 256 of tile pixel j % 256
+    const uint32_t n_jobs = (uint32_t)trg::kBlock * frames_wg;   // jobs of the workgroup's pool: its (j / 256)-th frame of tile pixel j % 256
 
     uint32_t jobb = 0u;           // the path this lane is working on (bits 0..23: its job) and the shading events it has had so far (bits 24..31)
 #define TRG_RG_JOB (jobb & 0xFFFFFFu)
 #define TRG_RG_B (jobb >> 24)
-    bool running = p.spp > 0u;
+    bool running = frames_wg > 0u;
     bool fresh = true;            // no path yet: the first class-0 block only takes a job
     bool job_valid = false;       // the job's pixel lies inside the image / the band
     bool active = false, primary_ray = true;
@@ -304,12 +308,16 @@ __global__ __launch_bounds__(trg::kBlock) void regen_accumulate_kernel(const trg
     const uint32_t x = bx * trg::kTileW + (sub % (trg::kTileW / 8)) * 8u + (pl & 7u);
     const uint32_t y = p.row0 + by * trg::kTileH + (sub / (trg::kTileW / 8)) * 8u + ((pl >> 3) & 7u);
     const bool valid = (x < p.u.width) && (y < p.row0 + p.rows) && (y < p.u.height);
-    const uint32_t n_rec = (uint32_t)__syncthreads_count(valid ? 1 : 0) * p.spp;   // every valid pixel logged every frame of the chunk
-    const v4f *rlog = reinterpret_cast<const v4f *>(p.tail_radbuf) + (size_t)blockIdx.x * trg::kBlock * p.spp;
-    for (uint32_t i = threadIdx.x; i < n_rec; i += trg::kBlock) {
-        const v4f r = rlog[i];
-        const uint32_t code = (uint32_t)__float_as_int(r.w);
-        stage[(code >> 8) * trg::kBlock + (code & 255u)] = r;
+    const uint32_t n_valid = (uint32_t)__syncthreads_count(valid ? 1 : 0);   // every valid pixel logged every frame of the chunk
+    const uint32_t F = p.fsplit, frames_max = (p.spp + F - 1u) / F;
+    for (uint32_t fl = 0; fl < F; ++fl) {   // the logs of the tile's frame lanes
+        const uint32_t n_rec = n_valid * (p.spp > fl ? (p.spp - fl + F - 1u) / F : 0u);
+        const v4f *rlog = reinterpret_cast<const v4f *>(p.tail_radbuf) + ((size_t)blockIdx.x * F + fl) * trg::kBlock * frames_max;
+        for (uint32_t i = threadIdx.x; i < n_rec; i += trg::kBlock) {
+            const v4f r = rlog[i];
+            const uint32_t code = (uint32_t)__float_as_int(r.w);
+            stage[(code >> 8) * trg::kBlock + (code & 255u)] = r;
+        }
     }
     __syncthreads();
     if (!valid) return;
