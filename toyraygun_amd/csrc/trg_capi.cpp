@@ -196,7 +196,12 @@ static uint32_t choose_fsplit(const trg_ctx *c, uint32_t spp, uint32_t rows) {
     // tile).  One launch alone (C4, 16 spp, ms; lock step with 4 lanes / regeneration with 1, 2, 4 lanes; scripts/gpu_c4_bands.py):
     // 135 rows 4.1 / 6.1 3.96 3.74, 270 rows 7.2 / 7.2 6.96 6.07, 540 rows 13.4 / 12.8 11.0 11.2, 1080 rows 24.1 / 20.0 19.0 19.7;
     // four full frames in flight: 17.8, 18.4, 19.6 per step -- the overlap hides the ends of the pools better than smaller pools do
-    if (c->opt_regen != 0 && c->sc.n_tris >= kRegenAutoMinTris && c->opt_in_flight < 2) return groups > 3000ull ? 2u : (spp >= 4 ? 4u : 2u);
+    // (row bands with four launches in flight, ms per step for 1 / 2 / 4 lanes: 135 rows 3.06 2.86 2.94, 270 rows 5.42 5.43 5.63, 540 rows
+    // 10.1 10.2 10.8: scripts/gpu_c4_bands_pipe.py)
+    if (c->opt_regen != 0 && c->sc.n_tris >= kRegenAutoMinTris) {
+        if (c->opt_in_flight < 2) return groups > 3000ull ? 2u : (spp >= 4 ? 4u : 2u);
+        return groups * (uint64_t)c->opt_in_flight < 4ull * kResidentGroups ? 2u : 1u;
+    }
     // a caller that overlaps consecutive launches (k frames in flight on k streams) hides the tail by itself: then the
     // frame-serial kernel wins as soon as the launches in flight together hold about two resident sets of workgroups
     // (C2 bands, ms per step, frame-serial vs 4 lanes: 1/4 frame 0.56 vs 0.63 at k = 2; 1/8 frame 0.375 vs 0.314 at
