@@ -81,6 +81,7 @@ typedef struct trg_stats {
     uint32_t last_tail_bounce; /* K of the tail compaction the last trg_render used (TRG_OPT_TAIL_BOUNCE), 0 = none */
     uint32_t last_kernel;      /* enum trg_kernel the last trg_render resolved to */
     uint32_t last_regen;       /* 1: the last trg_render ran the path-regeneration megakernel (TRG_OPT_REGEN) */
+    uint32_t last_tile_order;  /* the workgroup -> tile order of the last trg_render: 0 = image columns, 1/2/4/8 = XCD regions (TRG_OPT_TILE_ORDER) */
 } trg_stats;
 
 enum trg_option {
@@ -107,6 +108,12 @@ enum trg_option {
                                  wavefront); the frames go through a radiance buffer that is folded in frame order, so the result is
                                  bit-identical; 0 = one pixel per lane in lock step; -1 (default) = regeneration for scenes of 32,768
                                  triangles or more (below, a shading event costs as much as its rays and lock step is faster) */
+    TRG_OPT_TILE_ORDER = 12,  /* which tile of the launch a workgroup renders (any order gives the same image).  0: image columns from the centre
+                                 outwards; 1, 2, 4, 8: XCD-aware -- the workgroups an XCD receives (blockIdx % 8: workgroups are dealt round-robin
+                                 over the 8 XCDs, each with a private 4 MiB L2) own one of n column strips x 8/n row bands of the screen and walk
+                                 it away from the image centre, so that an L2 serves the rays of one screen region (C4: 37 % less memory-side
+                                 traffic, L2 hit rate 81 -> 86 %, but 14 % MORE time: the regions differ in cost and the dispatcher deals the
+                                 XCDs their workgroups strictly in turn); -1 (default): image columns */
     TRG_OPT_FRAME_SPLIT = 7   /* TRG_KERNEL_DIRECT only: frame lanes per workgroup. 1: a pixel's frames run one after the other in one
                                  lane; 2 or 4: that many wavefronts share a pixel's frames (same result bit for bit; fills the chip
                                  when the pixel grid alone does not -- small windows, row bands of a multi-GPU job);
@@ -252,10 +259,15 @@ TRG_API int trg_debug_build_bvh4(const float *positions3, const uint32_t *indice
 TRG_API int trg_debug_build_bvh4q(const float *positions3, const uint32_t *indices, const uint32_t *material_ids, uint32_t n_verts,
                                   uint32_t n_tris, uint32_t *nodes4q_out, uint32_t nodes4_cap, uint32_t *n_nodes4);
 
+/* which XCD runs workgroup b of a plain launch of n_blocks 256-thread workgroups: out[b] = HW_REG_XCC_ID (0..7).  The tile order above
+ * relies, for speed only, on the observed round-robin placement (b and b + 8 share an XCD); this is how the tests and profiles check it. */
+TRG_API int trg_debug_xcc_ids(trg_ctx *ctx, uint32_t n_blocks, uint32_t *out);
+
 /* host-only: byte layout of the device blob of an HBM-resident scene of n_tris triangles and n_nodes4 wide nodes, computed
  * exactly as trg_load_scene does (64-bit arithmetic).  TRG_ERR_RANGE when it does not fit the 32-bit offsets the kernels
  * use (4 GiB) -- trg_load_scene refuses such a scene before it allocates or copies anything.  offsets7 (may be NULL) =
- * nodes, records, normals, colours, material ids, wide nodes, total. */
+ * the LDS part (nodes, 48-byte records, normals, colours, material ids: all empty for a scene too large for LDS), the quantised
+ * wide nodes, the 128-byte leaf records (geometry + attributes, one cache line per triangle). */
 TRG_API int trg_debug_scene_layout(uint64_t n_tris, uint64_t n_nodes4, uint64_t *total_bytes, uint32_t *offsets7);
 
 /* --- N1: ACES tonemap + sRGB of the accumulation buffer to RGBA8 (PostProcessing.metal:44-57;

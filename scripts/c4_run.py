@@ -6,6 +6,9 @@ b = host.Scene.cornell_lattice(44).buffers()
 c = capi.Context(W, H)
 c.load_scene(b["positions"], b["normals"], b["colors"], b["indices"], b["material_ids"])
 c.set_uniforms(host.uniforms(W, H)[0]); c.set_pixel_offsets_seed()
+import os
+for k, v in [kv.split("=") for kv in os.environ.get("TRG_EXP_OPTS", "").split(",") if kv]:   # option=value pairs, as scripts/exp_ab.py
+    c.set_option(int(k), int(v))
 for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
     c.reset_stats(); c.render(0, 16, 3); st = c.stats()
     print("C4 %.2f ms %d rays %.2f Grays/s" % (st.last_render_ms, st.rays, st.rays / st.last_render_ms / 1e6))

@@ -1494,3 +1494,94 @@ def test_async_frames_keep_their_uniforms(capi, O, cornell):
         assert not np.array_equal(_bits(got), _bits(c.read_accum()))
     finally:
         c.close()
+
+
+# ------------------------------------------------------------------ round 3: tile order, leaf records
+@pytest.mark.parametrize("force_global", [0, 1])
+def test_tile_order_never_changes_the_image(capi, O, cornell, force_global):
+    """TRG_OPT_TILE_ORDER: which tile a workgroup renders is a question of time only.  The column order and every XCD-aware layout
+    (1, 2, 4, 8 column strips x 8, 4, 2, 1 row bands; the launch is padded to eight equal regions) give the strict image and the ray
+    counts of the oracle bit for bit -- partial tiles, fewer tile rows than bands, row bands of a frame, the frame-split, tail-compaction
+    and regeneration schedules included."""
+    for (w, h, spp, bounces) in ((97, 45, 3, 3), (200, 24, 4, 2), (16, 130, 2, 5), (64, 64, 5, 8)):
+        off = O.pixel_offsets(w, h)
+        O.set_trig_mode(O.TRIG_PORTABLE)
+        try:
+            ref, rst = O.render(cornell, w, h, spp, bounces, offsets=off)
+        finally:
+            O.set_trig_mode(O.TRIG_LIBM)
+        c = make_ctx(O, cornell, w, h, offsets=off)
+        try:
+            c.set_option(capi.OPT_FORCE_GLOBAL, force_global)
+            c.set_option(capi.OPT_STRICT, 1)
+            for order in (0, 1, 2, 4, 8, -1):
+                c.set_option(capi.OPT_TILE_ORDER, order)
+                for fsplit, regen in ((1, 0), (2, 0), (4, 1), (1, 1)):
+                    c.set_option(capi.OPT_FRAME_SPLIT, fsplit)
+                    c.set_option(capi.OPT_REGEN, regen)
+                    c.reset_stats()
+                    c.render(0, spp, bounces)
+                    st = c.stats()
+                    assert st.last_tile_order == max(order, 0)   # the automatic choice is the column order (measured faster on C4)
+                    assert np.array_equal(_bits(c.read_accum()), _bits(ref)) and st.rays == rst.rays, (w, h, order, fsplit, regen)
+                # two row bands of the frame
+                c.set_option(capi.OPT_FRAME_SPLIT, 0); c.set_option(capi.OPT_REGEN, -1)
+                c.render(0, spp, bounces, 0, h // 3); c.render(0, spp, bounces, h // 3, h - h // 3)
+                assert np.array_equal(_bits(c.read_accum()), _bits(ref)), (w, h, order, "bands")
+        finally:
+            c.close()
+
+
+def test_workgroups_are_dealt_round_robin_over_the_xcds(capi, O, cornell):
+    """What the XCD-aware tile order relies on for SPEED (never for results): workgroup b of a launch runs on XCD (b + k) % 8 for one k
+    per launch (MI355X_MICROARCH.md, workgroup dispatch).  Read back from HW_REG_XCC_ID.  A different placement would only cost time,
+    so a machine that places differently fails this test without failing any parity test."""
+    c = make_ctx(O, cornell, 64, 64)
+    try:
+        ids = c.xcc_ids(4096)
+        assert ids.max() <= 7 and len(set(ids.tolist())) == 8
+        k = (int(ids[0]) - 0) % 8
+        share = float((ids == (np.arange(4096) + k) % 8).mean())
+        assert share >= 0.98, (share, ids[:32])
+    finally:
+        c.close()
+
+
+def test_distance_ties_in_leaf_records_go_to_the_lower_original_index(capi, O):
+    """An HBM-resident scene names a hit by its 128-byte leaf RECORD; the contract's tie rule (equal distance -> lower original
+    primitive index) is kept by reading the held record's original index back on a tie.  Every triangle of the soup twice, the copies
+    in shuffled order: nearest hits report the lower of the two indices, exactly as the oracle's brute force does, for every builder."""
+    rng = np.random.default_rng(77)
+    bb = O.OracleScene.cornell_box().buffers()
+    nt = bb["material_ids"].shape[0]
+    perm = rng.permutation(2 * nt)
+    def dup(a):   # [3 * nt, 3] per-corner attribute -> both copies of every triangle, shuffled
+        return np.concatenate([a, a]).reshape(2 * nt, 3, 3)[perm].reshape(-1, 3)
+    pos, nrm, col = dup(bb["positions"]), dup(bb["normals"]), dup(bb["colors"])
+    mat = np.concatenate([bb["material_ids"], bb["material_ids"]])[perm]
+    idx = np.arange(pos.shape[0], dtype=np.uint32)
+    scene = O.OracleScene()
+    scene.add_raw(pos, nrm, col, mat)
+    rays = _rays(O, 20000, 5)
+    ref = O.intersect_nearest(scene, rays, brute=True)
+    hit = ref["primitiveIndex"] >= 0
+    assert hit.sum() > 5000
+    twin = np.empty(2 * nt, np.int64); inv = np.argsort(perm)
+    twin[:] = inv[(perm + nt) % (2 * nt)]   # the other copy of triangle k
+    assert (ref["primitiveIndex"][hit] < twin[ref["primitiveIndex"][hit]]).all()   # the oracle itself reports the lower copy
+    for builder in (0, 1, 2, 3):
+        c = capi.Context(32, 32)
+        try:
+            c.set_option(capi.OPT_FORCE_GLOBAL, 1)
+            c.set_option(capi.OPT_GPU_BUILD, builder)
+            c.load_scene(pos, nrm, col, idx, mat)
+            for strict in (1, 0):
+                c.set_option(capi.OPT_STRICT, strict)
+                got = c.trace(rays)
+                if strict:
+                    assert np.array_equal(got.view(np.uint8), ref.view(np.uint8)), builder
+                else:   # the shipped build may round a distance differently, never the tie rule: a reported triangle is the lower copy
+                    g = got["primitiveIndex"]
+                    assert (g[g >= 0] < twin[g[g >= 0]]).all() and (g == ref["primitiveIndex"]).mean() > 0.999, builder
+        finally:
+            c.close()

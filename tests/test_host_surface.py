@@ -37,11 +37,13 @@ def test_scene_blob_layout_is_64_bit_and_refuses_what_cannot_fit(built):
     off = (C.c_uint32 * 7)()
     assert L.trg_debug_scene_layout(1_022_244, 246_000, C.byref(total), off) == capi.OK
     o = list(off)
-    assert o[0] == 0 and o[1] == 0 and o == sorted(o) and o[6] == total.value
-    assert o[2] >= 1_022_244 * 48 and o[3] - o[2] >= 1_022_244 * 36 and o[5] % 128 == 0
-    # 30 M triangles still fit (124 B per triangle + nodes = 4.2e9 is just over; 25 M fits)
+    # a scene this size has no LDS part: the quantised wide nodes lead the blob, the 128-byte leaf records follow on their own lines
+    assert o[:6] == [0] * 6 and o[6] % 128 == 0 and o[6] >= 246_000 * 64
+    assert total.value >= o[6] + 1_022_244 * 128
+    # 25 M triangles fit (128 B per triangle + nodes = 3.6e9); 30 M (4.3e9) would not
     assert L.trg_debug_scene_layout(25_000_000, 6_000_000, C.byref(total), None) == capi.OK
-    assert total.value > 25_000_000 * 124
+    assert total.value > 25_000_000 * 128
+    assert L.trg_debug_scene_layout(30_000_000, 7_500_000, C.byref(total), None) == capi.ERR_RANGE
     # 50 M triangles: the old uint32 sums wrapped to ~2.9e9 and passed; now refused with the true size
     assert L.trg_debug_scene_layout(50_000_000, 12_000_000, C.byref(total), None) == capi.ERR_RANGE
     assert total.value > 2**32

@@ -16,7 +16,7 @@ HIP_SO = os.environ.get("TRG_HIP_SO") or os.path.join(LIB_DIR, "libtoyraygun_hip
 OK = 0
 ERR_INVALID, ERR_NOMEM, ERR_DEVICE, ERR_NODEV, ERR_RANGE = -22, -12, -5, -19, -34
 OPT_STRICT, OPT_COUNTERS, OPT_FORCE_GLOBAL, OPT_TIMING, OPT_KERNEL, OPT_GPU_BUILD, OPT_FRAME_SPLIT, OPT_LAUNCHES_IN_FLIGHT = 1, 2, 3, 4, 5, 6, 7, 8
-OPT_TAIL_BOUNCE, OPT_TAIL_LEVELS, OPT_REGEN = 9, 10, 11
+OPT_TAIL_BOUNCE, OPT_TAIL_LEVELS, OPT_REGEN, OPT_TILE_ORDER = 9, 10, 11, 12
 KERNEL_DIRECT, KERNEL_POOL, KERNEL_WAVEFRONT, KERNEL_AUTO = 0, 1, 2, -1
 MATERIAL_DEFAULT, MATERIAL_EMISSIVE = 1, 2
 MAX_BOUNCES = 15
@@ -44,7 +44,7 @@ class Stats(C.Structure):
         ("scene_bytes", C.c_uint64),
         ("last_build_ms", C.c_double),
         ("gpu_built", C.c_uint32), ("bvh_nodes4", C.c_uint32), ("bvh_depth4", C.c_uint32), ("last_frame_split", C.c_uint32),
-        ("last_tail_bounce", C.c_uint32), ("last_kernel", C.c_uint32), ("last_regen", C.c_uint32),
+        ("last_tail_bounce", C.c_uint32), ("last_kernel", C.c_uint32), ("last_regen", C.c_uint32), ("last_tile_order", C.c_uint32),
     ]
 
     @property
@@ -107,6 +107,7 @@ _SYMBOLS = [
                                       C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("trg_debug_build_bvh4", C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("trg_debug_scene_layout", C.c_int, [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), _P]),
+    ("trg_debug_xcc_ids", C.c_int, [_P, C.c_uint32, _P]),
     ("trg_debug_build_bvh4q", C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
 ]
 SYMBOL_NAMES = [s[0] for s in _SYMBOLS]
@@ -253,6 +254,12 @@ class Context:
 
     def set_stream(self, hip_stream):
         self._chk(self.L.trg_set_stream(self.h_ctx, hip_stream))
+
+    def xcc_ids(self, n_blocks):
+        """trg_debug_xcc_ids: the XCD (HW_REG_XCC_ID) every workgroup of a plain launch of n_blocks workgroups ran on."""
+        out = np.zeros(int(n_blocks), np.uint32)
+        self._chk(self.L.trg_debug_xcc_ids(self.h_ctx, int(n_blocks), _ptr(out)))
+        return out
 
     # ---- stage-level entry points ----
     def trace(self, rays, any_hit=False):

@@ -12,4 +12,8 @@ hipError_t gpu_build_lbvh(const float *d_pos, const uint32_t *d_idx, const uint3
 // float 4-wide nodes (8 float4 each) -> quantised 64-byte nodes (q4node.h); d_out holds n_nodes4 * 64 bytes
 hipError_t gpu_quantize_nodes4(const float4 *d_nodes4, uint32_t n_nodes4, void *d_out, hipStream_t s);
 
+// 48-byte geometry records (leaf order) + normals / colours in original order (9 floats per triangle) -> 128-byte leaf records
+// (trg_device.h kRecV4) at d_out
+hipError_t gpu_fatten_records(const float4 *d_tris48, const float *d_normals, const float *d_colors, uint32_t ntris, void *d_out, hipStream_t s);
+
 }  // namespace trg

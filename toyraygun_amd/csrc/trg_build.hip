@@ -733,6 +733,35 @@ hipError_t gpu_build_lbvh(const float *d_pos, const uint32_t *d_idx, const uint3
     return hipSuccess;
 }
 
+// 48-byte geometry records in leaf order + the attribute arrays in original order -> the 128-byte leaf records the HBM kernels read
+// (trg_device.h kRecV4): rows 0..2 the geometry record, floats 12..20 the triangle's normals, 21..29 its colours.  Two threads per
+// record, 64 bytes each: coalesced stores, gathered 36-byte reads.
+__global__ void fatten_records_kernel(const float4 *tris48, const float *nrm, const float *col, uint32_t n, float4 *out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = t >> 1, half = t & 1u;
+    if (i >= n) return;
+    const float4 r0 = tris48[(size_t)i * 3];
+    const uint32_t prim = __float_as_uint(r0.w);
+    const float *N = nrm + (size_t)prim * 9, *C = col + (size_t)prim * 9;
+    float4 *o = out + (size_t)i * 8;
+    if (half == 0u) {
+        o[0] = r0; o[1] = tris48[(size_t)i * 3 + 1]; o[2] = tris48[(size_t)i * 3 + 2];
+        o[3] = make_float4(N[0], N[1], N[2], N[3]);
+    } else {
+        o[4] = make_float4(N[4], N[5], N[6], N[7]);
+        o[5] = make_float4(N[8], C[0], C[1], C[2]);
+        o[6] = make_float4(C[3], C[4], C[5], C[6]);
+        o[7] = make_float4(C[7], C[8], 0.0f, 0.0f);
+    }
+}
+
+hipError_t gpu_fatten_records(const float4 *d_tris48, const float *d_normals, const float *d_colors, uint32_t ntris, void *d_out, hipStream_t s) {
+    if (ntris == 0) return hipSuccess;
+    const uint64_t threads = 2ull * ntris;
+    hipLaunchKernelGGL(fatten_records_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, d_tris48, d_normals, d_colors, ntris, static_cast<float4 *>(d_out));
+    return hipGetLastError();
+}
+
 hipError_t gpu_quantize_nodes4(const float4 *d_nodes4, uint32_t n_nodes4, void *d_out, hipStream_t s) {
     if (n_nodes4 == 0) return hipSuccess;
     hipLaunchKernelGGL(quantize_nodes4_kernel, dim3((n_nodes4 + 127) / 128), dim3(128), 0, s, d_nodes4, n_nodes4, static_cast<uint4 *>(d_out));

@@ -59,6 +59,8 @@ struct trg_ctx {
     uint32_t last_regen = 0;
     int opt_tail_levels = 0;   // TRG_OPT_TAIL_LEVELS: 0 = re-compact every second bounce after K, 1 = once at K only
     int opt_in_flight = 1;  // launches of this context the caller keeps in flight (TRG_OPT_LAUNCHES_IN_FLIGHT)
+    int opt_tile_order = -1;   // TRG_OPT_TILE_ORDER: -1 auto, 0 image columns centre-out, 1 / 2 / 4 / 8 XCD regions with that many column strips
+    uint32_t last_xcd_cols = 0;
     double last_build_ms = 0.0;
     bool gpu_built = false;
     uint32_t bvh_nodes = 0, bvh_depth = 0, bvh_leaves = 0;
@@ -91,10 +93,11 @@ static inline uint64_t align16_64(uint64_t v) { return (v + 15ull) & ~15ull; }
 
 // Byte layout of the scene blob (DESIGN.md "Data layout in HBM"), computed in 64 bits: SceneDesc keeps 32-bit offsets, so a
 // scene whose blob would not fit below 4 GiB is refused BEFORE anything is allocated or copied (the sums used to be
-// 32-bit and wrapped from about 30 M triangles on).  n_nodes = BVH2 / sign-ordered nodes kept in the blob (0 for HBM-only
-// scenes), nt_rec = triangle records, attr_tris = triangles with attributes.
+// 32-bit and wrapped from about 30 M triangles on).  The LDS part (scenes small enough to be staged; empty otherwise):
+// n_nodes BVH2 / sign-ordered nodes, nt_rec 48-byte triangle records, attr_tris triangles with attribute arrays, the Halton
+// tables.  Then, for every scene, what the HBM kernels traverse: n_nodes4 quantised wide nodes and n_fat 128-byte leaf records.
 constexpr uint64_t kBlobLimit = 0xFFFFFFF0ull;
-static bool plan_scene_layout(uint64_t n_nodes, uint32_t node_bytes, uint64_t nt_rec, uint64_t attr_tris, bool with_htab, uint64_t n_nodes4,
+static bool plan_scene_layout(uint64_t n_nodes, uint32_t node_bytes, uint64_t nt_rec, uint64_t attr_tris, bool with_htab, uint64_t n_nodes4, uint64_t n_fat,
                               SceneDesc &sc, uint64_t &total) {
     const uint64_t off_nodes = 0;
     const uint64_t off_tris = align16_64(off_nodes + n_nodes * node_bytes);
@@ -104,14 +107,32 @@ static bool plan_scene_layout(uint64_t n_nodes, uint32_t node_bytes, uint64_t nt
     const uint64_t off_htab = align16_64(off_mats + attr_tris * 4ull);
     const uint64_t stage_end = align16_64(off_htab + (with_htab ? kHtabBytes : 0u));
     const uint64_t off_nodes4 = (stage_end + 127ull) & ~127ull;  // 64-byte nodes, two per 128-byte line
-    total = off_nodes4 + n_nodes4 * kQ4NodeBytes + 128ull;
+    const uint64_t off_fat = (off_nodes4 + n_nodes4 * kQ4NodeBytes + 127ull) & ~127ull;   // one record per 128-byte line
+    total = off_fat + n_fat * kFatRecBytes + 128ull;
     if (total > kBlobLimit) return false;
     sc.off_nodes = (uint32_t)off_nodes; sc.off_tris = (uint32_t)off_tris; sc.off_normals = (uint32_t)off_normals;
     sc.off_colors = (uint32_t)off_colors; sc.off_mats = (uint32_t)off_mats; sc.off_htab = (uint32_t)off_htab;
     sc.off_nodes4 = (uint32_t)off_nodes4;
+    sc.off_fat = (uint32_t)off_fat; sc.n_fat = (uint32_t)n_fat;
     sc.lds_stage_bytes = with_htab ? (uint32_t)stage_end : 0u;
     sc.blob_bytes = (uint32_t)total;
     return true;
+}
+
+// One 128-byte leaf record (trg_device.h kRecV4): rows 0..2 = the 48-byte geometry record (v0 | original index, e1 | mask = material id,
+// e2 | 0), then the triangle's nine normal and nine colour floats (Raytracing.metal:104-108 reads them as attributes[triangle*3 + corner]).
+static void fill_fat_record(unsigned char *dst, const F4 *rec48, const float *nrm, const float *col, uint32_t n_tris) {
+    float *o = reinterpret_cast<float *>(dst);
+    memcpy(o, rec48, 48);
+    uint32_t prim;
+    memcpy(&prim, &rec48[0].w, 4);
+    if (prim < n_tris) {
+        memcpy(o + 12, nrm + (size_t)prim * 9, 36);
+        memcpy(o + 21, col + (size_t)prim * 9, 36);
+    } else {
+        memset(o + 12, 0, 72);
+    }
+    o[30] = 0.0f; o[31] = 0.0f;
 }
 
 constexpr uint32_t kStackLdsLevels = TRG_STACK_LDS_LEVELS;
@@ -126,6 +147,9 @@ constexpr uint32_t kStackLdsLevels = TRG_STACK_LDS_LEVELS;
 #endif
 constexpr uint32_t kRegenAutoMinTris = 32768u;   // TRG_OPT_REGEN -1: path regeneration from this many triangles on
 constexpr uint32_t kTailAutoMinBounces = TRG_TAIL_AUTO_MIN_BOUNCES, kTailAutoK = TRG_TAIL_AUTO_K, kTailChunkFrames = 16, kTailLevelStep = TRG_TAIL_LEVEL_STEP;
+#ifndef TRG_XCD_AUTO_COLS
+#define TRG_XCD_AUTO_COLS 0   // TRG_OPT_TILE_ORDER -1 for scenes in HBM: 0 = image columns (measured faster, see choose_xcd_cols), 2 = XCD-aware 2 x 4
+#endif
 #ifndef TRG_WAVEFRONT_FOR_HBM
 #define TRG_WAVEFRONT_FOR_HBM 0   // what TRG_KERNEL_AUTO picks for a scene traversed from HBM (1 = the wavefront schedule)
 #endif  // HBM scenes: stack levels kept in LDS (deeper ones spill to global scratch)
@@ -142,8 +166,6 @@ static bool plan_lds_as(const trg_ctx *c, LdsPlan &p, bool lds_scene, bool pool,
     } else {
         levels = kWideHbm ? 3 * c->bvh_depth4 + 3 : c->bvh_depth + 3;  // the sentinel at level 0; 4-wide: up to three pending entries per level
         p.klds = std::min(levels, kStackLdsLevels);
-        // quad tracer (render_kernel): the same LDS holds 64 stacks of 4 * klds - 1 entries, which must cover the whole depth
-        if (TRG_QUAD && kWideHbm && !pool && !fp_slots && park) p.klds = std::max(p.klds, (3u * c->bvh_depth4 + 3u + 3u) / 4u);
     }
     p.overflow_levels = levels - p.klds;
     // the pool kernel does not use the Halton group tables at the end of the staged region: it stages (and pays for) less
@@ -159,7 +181,7 @@ static bool plan_lds_as(const trg_ctx *c, LdsPlan &p, bool lds_scene, bool pool,
     // render_kernel on an HBM-resident scene parks the running average in LDS between frames (three VGPRs less across every
     // traversal; an LDS-resident scene has neither the room -- 8 workgroups of 20 KB per CU -- nor the need: it is spill-free)
     p.acc_off = 0;
-    if (park && !p.lds_scene && !pool && !fp_slots) { p.acc_off = p.total; p.total += (uint32_t)kBlock * (TRG_QUAD ? 32u : (TRG_PARK_PATH ? (TRG_PARK_OFFSET ? 40u : 36u) : 12u)); }   // quad tracer: 5 result words per thread behind the average
+    if (park && !p.lds_scene && !pool && !fp_slots) { p.acc_off = p.total; p.total += (uint32_t)kBlock * (TRG_PARK_PATH ? (TRG_PARK_OFFSET ? 40u : 36u) : 12u); }
     limit = (pool || fp_slots) ? 160u * 1024u : 64u * 1024u;  // above 64 KB the launcher opts in per kernel
     return p.total <= limit;
 }
@@ -208,6 +230,35 @@ static uint32_t choose_fsplit(const trg_ctx *c, uint32_t spp, uint32_t rows) {
     // k = 2, 0.295 vs 0.312 at k = 3, 0.273 vs 0.311 at k = 4)
     if (c->opt_in_flight >= 2 ? groups * (uint64_t)c->opt_in_flight >= 2ull * kResidentGroups : groups > 4ull * kResidentGroups) return 1u;
     return spp >= 4 ? 4u : 2u;
+}
+
+// Workgroup slots of a launch over tiles_x x tiles_y tiles (trg_kernels.hip block_tile): one per tile in the column order; in the
+// XCD-aware order 8 x the largest of the xcd_cols x (8 / xcd_cols) regions (regions differ by a row or a column of tiles at most).
+static uint64_t tile_slots(uint32_t tiles_x, uint32_t tiles_y, uint32_t xcd_cols) {
+    if (xcd_cols == 0u) return (uint64_t)tiles_x * tiles_y;
+    const uint32_t rc = xcd_cols, rq = kXcds / rc;
+    uint64_t largest = 0;
+    for (uint32_t ci = 0; ci < rc; ++ci)
+        for (uint32_t qi = 0; qi < rq; ++qi) {
+            const uint64_t W = (uint64_t)(ci + 1u) * tiles_x / rc - (uint64_t)ci * tiles_x / rc, H = (uint64_t)(qi + 1u) * tiles_y / rq - (uint64_t)qi * tiles_y / rq;
+            largest = std::max(largest, W * H);
+        }
+    return largest * kXcds;
+}
+// TRG_OPT_TILE_ORDER -1 = the column order for every scene.  Measured on C4 (1,022,244 triangles, regeneration kernel, one launch alone;
+// profiles/r03/c4_tile_order.md): the XCD-aware order with 2 x 4 regions cuts the memory-side reads from 50.4 to 32.0 GB per launch, raises the
+// L2 hit rate from 81 to 86 % and shortens the mean L1 -> L2 round trip from 245 to 199 cycles -- and takes 22.1 ms instead of 19.3: the
+// wavefronts' total lifetime (SQ_WAVE_CYCLES) stays the same, the kernel issues instructions most of the time and what it waits less for
+// memory it waits more for an issue slot, while the eight regions differ in cost and the dispatcher deals workgroups to the XCDs
+// strictly in turn, so the cheap regions' XCDs idle (1 x 8: 23.8 ms, 4 x 2: 37.5, 8 x 1: 35.9 -- the 16:9 side bars).  TRG_XCD_AUTO_COLS
+// (a build flag) would make an XCD-aware layout the automatic choice for scenes traversed from HBM.
+static uint32_t choose_xcd_cols(const trg_ctx *c, bool lds_scene, uint32_t tiles_x, uint32_t tiles_y) {
+    if (c->opt_tile_order >= 0) return (uint32_t)c->opt_tile_order;
+    if (lds_scene || TRG_XCD_AUTO_COLS == 0) return 0u;
+    uint32_t rc = TRG_XCD_AUTO_COLS;
+    while (rc < kXcds && tiles_y < kXcds / rc) rc *= 2u;   // fewer row bands for a launch of few tile rows (a row band of a multi-GPU job)
+    while (rc > 1u && tiles_x < rc) rc /= 2u;
+    return rc;
 }
 
 // global scratch for the stack levels that do not fit in LDS: overflow_levels x grid_threads ints
@@ -276,17 +327,21 @@ static int load_scene_gpu_build(trg_ctx *c, const float *pos, const float *nrm, 
     sc.n_nodes = 0; sc.n_tris = n_tris;
     sc.n_nodes4 = n4;
     uint64_t total = 0;
-    if (!plan_scene_layout(0, 64u, n_tris, n_tris, false, n4, sc, total))
+    if (!plan_scene_layout(0, 64u, 0, 0, false, n4, n_tris, sc, total))
         return fail(c, TRG_ERR_RANGE, "trg_load_scene: scene needs %llu B on the device (limit 4 GiB)", (unsigned long long)total);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->blob) { (void)hipFree(c->blob); c->blob = nullptr; c->scene_loaded = false; }
     e = hipMalloc((void **)&c->blob, sc.blob_bytes);
     if (e != hipSuccess) return fail(c, TRG_ERR_NOMEM, "trg_load_scene: hipMalloc(%u) failed: %s", sc.blob_bytes, hipGetErrorString(e));
     HIPCHK(c, hipMemsetAsync(c->blob, 0, sc.blob_bytes, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->blob + sc.off_tris, d_tris.p, (size_t)n_tris * 48, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->blob + sc.off_normals, nrm, (size_t)n_tris * 36, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->blob + sc.off_colors, col, (size_t)n_tris * 36, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->blob + sc.off_mats, mat, (size_t)n_tris * 4, hipMemcpyHostToDevice, c->stream));
+    {   // the attributes in original order, then one pass that writes the 128-byte leaf records (geometry of record i + attributes of its triangle)
+        Dev d_nrm, d_col;
+        HIPCHK(c, hipMalloc(&d_nrm.p, (size_t)n_tris * 36)); HIPCHK(c, hipMalloc(&d_col.p, (size_t)n_tris * 36));
+        HIPCHK(c, hipMemcpyAsync(d_nrm.p, nrm, (size_t)n_tris * 36, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_col.p, col, (size_t)n_tris * 36, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, gpu_fatten_records((const float4 *)d_tris.p, (const float *)d_nrm.p, (const float *)d_col.p, n_tris, c->blob + sc.off_fat, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     HIPCHK(c, gpu_quantize_nodes4((const float4 *)d_nodes4.p, n4, c->blob + sc.off_nodes4, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     sc.blob = c->blob;
@@ -343,7 +398,7 @@ static int render_wavefront(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint
             HIPCHK(c, strict ? launch_wf_trace_strict(p, plan.lds_scene, c->opt_counters, trace_grid, plan.total, c->stream)
                              : launch_wf_trace_fast(p, plan.lds_scene, c->opt_counters, trace_grid, plan.total, c->stream));
             if (b == bounces) break;   // that was the trace of the last bounce's shadow rays
-            HIPCHK(c, strict ? launch_wf_shade_strict(p, shade_grid, c->stream) : launch_wf_shade_fast(p, shade_grid, c->stream));
+            HIPCHK(c, strict ? launch_wf_shade_strict(p, plan.lds_scene, shade_grid, c->stream) : launch_wf_shade_fast(p, plan.lds_scene, shade_grid, c->stream));
         }
         HIPCHK(c, strict ? launch_wf_accumulate_strict(p, c->stream) : launch_wf_accumulate_fast(p, c->stream));
     }
@@ -425,7 +480,7 @@ int trg_load_scene(trg_ctx *c, const float *pos, const float *nrm, const float *
     {   // refuse a scene that cannot fit the 32-bit blob offsets before anything is built, allocated or copied
         SceneDesc probe{};
         uint64_t least = 0;
-        if (!plan_scene_layout(0, 64u, n_tris, n_tris, false, 0, probe, least))
+        if (!plan_scene_layout(0, 64u, 0, 0, false, 0, n_tris, probe, least))
             return fail(c, TRG_ERR_RANGE, "trg_load_scene: %u triangles need at least %llu B on the device (limit 4 GiB)", n_tris, (unsigned long long)least);
     }
     HIPCHK(c, hipSetDevice(c->device));
@@ -446,18 +501,17 @@ int trg_load_scene(trg_ctx *c, const float *pos, const float *nrm, const float *
     // (Raytracing.metal:104-108), so they are copied as they are.
     const uint32_t nt_rec = (uint32_t)(bvh.tris.size() / 3);
     const uint32_t attr_tris = std::max(n_tris, 1u);
-    // [ BVH2 nodes | triangle records | normals | colours | material ids ] [ quantised 4-wide nodes | 128 B pad ]
-    // The first bracket is what a workgroup stages into LDS when it is small enough; scenes that can only be
-    // traversed from HBM skip the BVH2 nodes when the HBM kernels use the 4-wide tree.
+    // [ LDS nodes | 48-byte triangle records | normals | colours | material ids | Halton tables ] [ quantised 4-wide nodes ] [ 128-byte leaf records ]
+    // The first bracket is what a workgroup stages into LDS; only a scene small enough for that has it.  The other two are what
+    // the HBM kernels traverse (a small scene kept in HBM -- TRG_OPT_FORCE_GLOBAL, a tree too deep for LDS stacks -- uses them too).
     const uint64_t small_bytes = (uint64_t)(kWideLds ? bvh.n_nodes4 : bvh.n_nodes) * kLdsNodeBytes + (uint64_t)nt_rec * 48u + (uint64_t)attr_tris * 76u + 64u + kHtabBytes;
     const bool lds_candidate = small_bytes <= kMaxLdsScene;
-    const bool keep_bvh2 = lds_candidate || !kWideHbm;
     SceneDesc sc{};
-    sc.n_nodes = keep_bvh2 ? ((kWideLds && lds_candidate) ? bvh.n_nodes4 : bvh.n_nodes) : 0u; sc.n_tris = n_tris;
-    const uint32_t node_bytes = lds_candidate ? kLdsNodeBytes : 64u;
-    sc.n_nodes4 = kWideHbm ? bvh.n_nodes4 : 0u;
+    sc.n_nodes = lds_candidate ? (kWideLds ? bvh.n_nodes4 : bvh.n_nodes) : 0u; sc.n_tris = n_tris;
+    const uint32_t node_bytes = kLdsNodeBytes;
+    sc.n_nodes4 = bvh.n_nodes4;
     uint64_t total = 0;
-    if (!plan_scene_layout(sc.n_nodes, node_bytes, nt_rec, attr_tris, lds_candidate, sc.n_nodes4, sc, total))
+    if (!plan_scene_layout(sc.n_nodes, node_bytes, lds_candidate ? nt_rec : 0u, lds_candidate ? attr_tris : 0u, lds_candidate, sc.n_nodes4, nt_rec, sc, total))
         return fail(c, TRG_ERR_RANGE, "trg_load_scene: scene needs %llu B on the device (limit 4 GiB)", (unsigned long long)total);
     std::vector<unsigned char> host(sc.blob_bytes, 0);
     if (sc.n_nodes && lds_candidate && kWideLds) {
@@ -504,16 +558,18 @@ int trg_load_scene(trg_ctx *c, const float *pos, const float *nrm, const float *
             memcpy(o + 28, ch, 8);
         }
     } else if (sc.n_nodes) {
+        static_assert(kSignedLds || kWideLds || kLdsNodeBytes == 64u, "plain BVH2 nodes are 64 bytes");
         memcpy(&host[sc.off_nodes], bvh.nodes.data(), (size_t)sc.n_nodes * 64u);
     }
-    memcpy(&host[sc.off_tris], bvh.tris.data(), bvh.tris.size() * sizeof(F4));
-    float *hn = reinterpret_cast<float *>(&host[sc.off_normals]);
-    float *hc = reinterpret_cast<float *>(&host[sc.off_colors]);
-    if (n_tris) {
-        memcpy(hn, nrm, (size_t)n_tris * 36);
-        memcpy(hc, col, (size_t)n_tris * 36);
-        memcpy(&host[sc.off_mats], mat, (size_t)n_tris * 4);
+    if (lds_candidate) {
+        memcpy(&host[sc.off_tris], bvh.tris.data(), bvh.tris.size() * sizeof(F4));
+        if (n_tris) {
+            memcpy(&host[sc.off_normals], nrm, (size_t)n_tris * 36);
+            memcpy(&host[sc.off_colors], col, (size_t)n_tris * 36);
+            memcpy(&host[sc.off_mats], mat, (size_t)n_tris * 4);
+        }
     }
+    for (uint32_t i = 0; i < nt_rec; ++i) fill_fat_record(&host[sc.off_fat + (size_t)i * kFatRecBytes], &bvh.tris[(size_t)i * 3], nrm, col, n_tris);
     if (lds_candidate) {  // Halton group tables (trg_kernels.h kHtab)
         float *T = reinterpret_cast<float *>(&host[sc.off_htab]);
         for (const HtabSpec &h : kHtab)
@@ -670,8 +726,12 @@ int trg_render(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces,
     const uint32_t tile_w = fsplit > 1 ? 8u * (kWaves / fsplit) : (uint32_t)kTileW, tile_h = fsplit > 1 ? 8u : (uint32_t)kTileH;
     p.tiles_x = (c->w + tile_w - 1) / tile_w;
     const uint32_t tiles_y = (rows + tile_h - 1) / tile_h;
-    if ((uint64_t)p.tiles_x * tiles_y > 0x7FFFFFFFull) return fail(c, TRG_ERR_RANGE, "trg_render: grid too large");
-    const uint32_t grid = p.tiles_x * tiles_y;
+    p.tiles_y = tiles_y;
+    p.xcd_cols = choose_xcd_cols(c, plan.lds_scene, p.tiles_x, tiles_y);
+    c->last_xcd_cols = p.xcd_cols;
+    const uint64_t slots = tile_slots(p.tiles_x, tiles_y, p.xcd_cols);
+    if (slots * std::max(regen_lanes, 1u) > 0x7FFFFFFFull) return fail(c, TRG_ERR_RANGE, "trg_render: grid too large");
+    const uint32_t grid = (uint32_t)slots;   // workgroup slots (the XCD-aware order pads the launch to 8 equal regions)
     if (int rc = ensure_stack_scratch(c, plan, (uint64_t)grid * std::max(regen_lanes, 1u) * kBlock, p.stack, slot)) return rc;
 
     // ---- tail compaction (trg_tail.inc.h): scene in LDS, frame-serial direct kernel, enough bounces for paths to die.  Measured on
@@ -824,6 +884,7 @@ int trg_get_stats(trg_ctx *c, trg_stats *out) {
     out->last_tail_bounce = c->last_tail_k;
     out->last_kernel = c->last_kernel;
     out->last_regen = c->last_regen;
+    out->last_tile_order = c->last_xcd_cols;
     if (c->scene_loaded) {
         LdsPlan plan;
         if (plan_lds(c, plan, c->opt_kernel == TRG_KERNEL_POOL) == TRG_OK) { out->scene_in_lds = plan.lds_scene ? 1u : 0u; out->lds_bytes = plan.total; }
@@ -865,6 +926,11 @@ int trg_set_option(trg_ctx *c, int option, int64_t value) {
     case TRG_OPT_REGEN:
         if (value < -1 || value > 1) return fail(c, TRG_ERR_INVALID, "trg_set_option: regeneration must be -1 (auto), 0 (off) or 1 (on)");
         c->opt_regen = (int)value;
+        break;
+    case TRG_OPT_TILE_ORDER:
+        if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
+            return fail(c, TRG_ERR_INVALID, "trg_set_option: tile order must be -1 (auto), 0 (columns) or 1, 2, 4, 8 (XCD regions: column strips)");
+        c->opt_tile_order = (int)value;
         break;
     case TRG_OPT_LAUNCHES_IN_FLIGHT:
         if (value < 1 || value > 16) return fail(c, TRG_ERR_INVALID, "trg_set_option: launches in flight must be 1..16");
@@ -989,14 +1055,26 @@ int trg_debug_build_bvh4q(const float *positions3, const uint32_t *indices, cons
     return TRG_OK;
 }
 
+int trg_debug_xcc_ids(trg_ctx *c, uint32_t n_blocks, uint32_t *out) {
+    if (!c || (n_blocks && !out) || n_blocks > (1u << 20)) return TRG_ERR_INVALID;
+    if (n_blocks == 0) return TRG_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    struct Dev { void *p = nullptr; ~Dev() { if (p) (void)hipFree(p); } } d;
+    HIPCHK(c, hipMalloc(&d.p, (size_t)n_blocks * 4));
+    HIPCHK(c, launch_xcc_probe_fast(n_blocks, (uint32_t *)d.p, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out, d.p, (size_t)n_blocks * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return TRG_OK;
+}
+
 int trg_debug_scene_layout(uint64_t n_tris, uint64_t n_nodes4, uint64_t *total_bytes, uint32_t *offsets7) {
     SceneDesc sc{};
     uint64_t total = 0;
-    const bool ok = plan_scene_layout(0, 64u, n_tris, n_tris ? n_tris : 1u, false, n_nodes4, sc, total);
+    const bool ok = plan_scene_layout(0, 64u, 0, 0, false, n_nodes4, n_tris ? n_tris : 1u, sc, total);
     if (total_bytes) *total_bytes = total;
     if (!ok) return TRG_ERR_RANGE;
     if (offsets7) {
-        const uint32_t o[7] = { sc.off_nodes, sc.off_tris, sc.off_normals, sc.off_colors, sc.off_mats, sc.off_nodes4, sc.blob_bytes };
+        const uint32_t o[7] = { sc.off_nodes, sc.off_tris, sc.off_normals, sc.off_colors, sc.off_mats, sc.off_nodes4, sc.off_fat };
         memcpy(offsets7, o, sizeof(o));
     }
     return TRG_OK;

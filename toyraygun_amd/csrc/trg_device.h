@@ -500,16 +500,23 @@ TRG_DEV void raygen(const trg_uniforms &u, uint32_t x, uint32_t y, uint32_t hidx
 // Intersector (a7 nearest, a12 any): replaces MPSRayIntersector (MetalRenderer.mm:265-279,427-437,
 // 466-475).  Contract = oracle/trg_oracle.c "INTERSECTION CONTRACT".
 // ---------------------------------------------------------------------------------------------
+// A scene staged in LDS keeps the reference's buffers: 48-byte triangle records in leaf order + normals / colours / material ids
+// in ORIGINAL order (Raytracing.metal:104-108).  A scene traversed from HBM has ONE 128-byte record per triangle, in leaf order
+// (kRecV4 float4 each, a cache line): rows 0..2 the same geometry record, rows 3..7 the nine normal and nine colour floats; the
+// material id is the mask of row 1.  A hit then names its RECORD (Hit::prim = record index), the shading event reads the line the
+// triangle test has just pulled through L1 / L2 instead of three more lines of three other arrays (two dependent round trips
+// through memory per shading event before), and the original index is only needed to break distance ties (trav_tri_math).
+constexpr int kRecV4 = 8;   // float4 per leaf record of an HBM-resident scene
 struct SceneView {
     const v4f *nodes;       // 4 per node
-    const v4f *tris;        // 3 per triangle, leaf order
-    const float *normals;   // 9 per triangle, ORIGINAL order (reference vertexNormals buffer)
-    const float *colors;    // 9 per triangle, ORIGINAL order (reference vertexColors buffer)
-    const uint32_t *mats;   // 1 per triangle, ORIGINAL order (reference triangleMasks buffer)
+    const v4f *tris;        // LDS scene: 3 per triangle; HBM scene: kRecV4 per triangle (geometry + attributes); leaf order
+    const float *normals;   // LDS scene: 9 per triangle, ORIGINAL order (reference vertexNormals buffer); HBM scene: nullptr
+    const float *colors;    // LDS scene: 9 per triangle, ORIGINAL order (reference vertexColors buffer); HBM scene: nullptr
+    const uint32_t *mats;   // LDS scene: 1 per triangle, ORIGINAL order (reference triangleMasks buffer); HBM scene: nullptr
     const float *htab;      // Halton group tables in LDS (trg_kernels.h kHtab), or nullptr
     trg::TexDesc tex;       // albedo textures in global memory (tex.uv == nullptr: none)
 };
-struct Hit { float t; int prim; float u, v; };  // u, v = Moeller-Trumbore weights of vertex 1 and 2
+struct Hit { float t; int prim; float u, v; };  // u, v = Moeller-Trumbore weights of vertex 1 and 2; prim = original index (LDS scene) or leaf record (HBM scene)
 struct Counters { uint32_t nodes, tris, wnodes, wtris; };  // per-lane work and wave-level iterations (first active lane counts)
 
 // One ray/triangle test.  Returns true when (u,v) are inside and t is in [0, tmax_ray].
@@ -701,8 +708,11 @@ TRG_DEV void trav_node_step(const SceneView &sc, Trav &tv, STK stk, Counters &cn
 }
 
 // One ray/triangle test folded into the traversal state; returns true when an any-hit query is satisfied.
-template <bool COUNT>
-TRG_DEV bool trav_tri_math(const v4f a, const v4f b, const v4f c, Trav &tv, bool any, Counters &cnt) {
+// REC (HBM scenes): the hit keeps the leaf RECORD index `rec` instead of the original primitive index.  Distance ties still go to the
+// lower ORIGINAL index (the intersection contract): only then -- two triangles at bit-equal distance, i.e. duplicates or a ray
+// through a shared edge -- is the held triangle's original index read back from its record (recs[held * kRecV4].w).
+template <bool COUNT, bool REC = false>
+TRG_DEV bool trav_tri_math(const v4f a, const v4f b, const v4f c, Trav &tv, bool any, Counters &cnt, uint32_t rec = 0u, const v4f *recs = nullptr) {
     const bool masked_in = (((uint32_t)__float_as_int(b.w)) & tv.rmask) != 0u;
     if (COUNT) { if (masked_in) cnt.tris++; if (mbcnt64(__ballot(1)) == 0) cnt.wtris++; }
     float t, u, v;
@@ -710,10 +720,16 @@ TRG_DEV bool trav_tri_math(const v4f a, const v4f b, const v4f c, Trav &tv, bool
     // change anything (something nearer is already held, so `found` is set and `take` would be false) -- one register less per ray
     const bool ok = tri_test(a, b, c, tv.o, tv.d, tv.best, t, u, v) && masked_in;
     const int prim = __float_as_int(a.w);
-    const bool take = ok && (any || !tv.found || t < tv.best || (t == tv.best && prim < tv.hit.prim));
+    bool take;
+    if (REC) {
+        take = ok && (any || !tv.found || t < tv.best);
+        if (ok && !any && tv.found && t == tv.best) take = prim < __float_as_int(recs[(size_t)(uint32_t)tv.hit.prim * kRecV4].w);
+    } else {
+        take = ok && (any || !tv.found || t < tv.best || (t == tv.best && prim < tv.hit.prim));
+    }
     tv.found = tv.found || ok;
     tv.best = take ? t : tv.best;   // (an any-hit query ends with this triangle: its distance may overwrite the limit)
-    tv.hit.prim = take ? prim : tv.hit.prim;
+    tv.hit.prim = take ? (REC ? (int)rec : prim) : tv.hit.prim;
     tv.hit.u = take ? u : tv.hit.u;
     tv.hit.v = take ? v : tv.hit.v;
     return any && ok;
@@ -845,19 +861,19 @@ TRG_DEV void trav_inner_step(const SceneView &sc, Trav &tv, STK stk, Counters &c
 }
 
 // one unit of work per lane per iteration on the 4-wide tree: a quantised node (four 16-byte loads = 64 bytes)
-// or one triangle of the current leaf (the first three of the same loads)
+// or one triangle of the current leaf (the first three 16-byte rows of its 128-byte record)
 template <bool COUNT, int BLOCK, typename STK>
 TRG_DEV void trav_step_wide(const SceneView &sc, Trav &tv, bool any, STK stk, Counters &cnt) {
     const bool inner = tv.node >= 0;
     const uint32_t code = (uint32_t)~tv.node;
     const uint32_t first = code >> 3, left = code & 7u;
-    const v4f *ptr = inner ? sc.nodes + (size_t)tv.node * 4 : sc.tris + (size_t)first * 3;
+    const v4f *ptr = inner ? sc.nodes + (size_t)tv.node * 4 : sc.tris + (size_t)first * kRecV4;
     const v4f q0 = ptr[0], q1 = ptr[1], q2 = ptr[2];
     if (inner) {
         const v4f q3 = ptr[3];
         trav_node4_math<COUNT, BLOCK>(q0, q1, q2, q3, tv, stk, cnt);
     } else {
-        const bool stop = trav_tri_math<COUNT>(q0, q1, q2, tv, any, cnt);
+        const bool stop = trav_tri_math<COUNT, true>(q0, q1, q2, tv, any, cnt, first, sc.tris);
         const bool more = left != 0u;
         const bool do_pop = !stop && !more;
         const int sp = tv.sp - (do_pop ? STK::unit : 0);
@@ -868,37 +884,11 @@ TRG_DEV void trav_step_wide(const SceneView &sc, Trav &tv, bool any, STK stk, Co
     }
 }
 
-// Unified step for scenes that live in HBM: every lane does ONE unit of work per iteration -- an inner node
-// (two boxes) or one triangle of its current leaf -- off a single group of four 16-byte loads, so there is
-// one memory round trip per iteration for the whole wavefront and no lane waits for lanes of the other
-// kind (the while-while form above serialises node and leaf phases; it is kept for LDS-resident scenes,
-// where instructions, not latency, are the cost).  A leaf is consumed by advancing its own code:
-// ~node = (first << 3) | (remaining - 1).
-template <bool COUNT, int BLOCK, typename STK>
-TRG_DEV void trav_step_unified(const SceneView &sc, Trav &tv, bool any, STK stk, Counters &cnt) {
-    const bool inner = tv.node >= 0;
-    const uint32_t code = (uint32_t)~tv.node;
-    const uint32_t first = code >> 3, left = code & 7u;
-    const v4f *ptr = inner ? sc.nodes + tv.node * 4 : sc.tris + first * 3;
-    const v4f q0 = ptr[0], q1 = ptr[1], q2 = ptr[2], q3 = ptr[3];  // a triangle record reads 16 bytes into the next one: in bounds
-    if (inner) {
-        trav_node_math<COUNT, BLOCK>(q0, q1, q2, q3, tv, stk, cnt);
-    } else {
-        const bool stop = trav_tri_math<COUNT>(q0, q1, q2, tv, any, cnt);
-        const bool more = left != 0u;
-        const bool do_pop = !stop && !more;
-        const int sp = tv.sp - (do_pop ? STK::unit : 0);
-        const int popped = stk.pop(sp);  // the sentinel at level 0 when nothing is pending
-        const int advanced = ~(int)(((first + 1u) << 3) | (left - 1u));
-        tv.node = stop ? kNodeDone : (more ? advanced : popped);
-        tv.sp = sp;
-    }
-}
-
-// traversal schedules: 0 = while-while on BVH2, 4 = while-while on sign-ordered BVH2 nodes (LDS scenes only; the host
-// stages that layout when TRG_TRAV_LDS == 4), 1 = unified step on BVH2 (node + triangle every iteration),
-// 3 = unified step on the 4-wide tree (the host uploads 4-wide nodes for HBM scenes when TRG_TRAV_HBM == 3).  (A third schedule,
-// one block kind per iteration chosen by a lane-count vote, measured no better on C4 and 9 % worse on C2.)
+// traversal schedules.  LDS-resident scenes (TRG_TRAV_LDS): 0 = while-while on BVH2, 4 = while-while on sign-ordered BVH2 nodes
+// (default), 5 = sign-ordered 4-wide float nodes.  HBM-resident scenes (TRG_TRAV_HBM): 3 = the unified step on the quantised
+// 4-wide tree -- one unit of work per lane per iteration, a node or one triangle, off one group of loads (the only one left: the
+// unified step on BVH2 nodes of round 1 and a schedule with one block kind per iteration chosen by a lane-count vote measured
+// no better on C4 and 9 % worse on C2).
 #ifndef TRG_TRAV_LDS
 #define TRG_TRAV_LDS 4
 #endif
@@ -925,8 +915,6 @@ TRG_DEV bool traverse(const SceneView &sc, V3 o, V3 d, float tmax_ray, uint32_t 
     constexpr int mode = UNIFIED ? TRG_TRAV_HBM : TRG_TRAV_LDS;
     if (mode == 3) {
         while (tv.node != kNodeDone) trav_step_wide<COUNT, BLOCK>(sc, tv, ANY, stk, cnt);
-    } else if (mode == 1) {
-        while (tv.node != kNodeDone) trav_step_unified<COUNT, BLOCK>(sc, tv, ANY, stk, cnt);
     } else {
         for (;;) {
             while (tv.node >= 0) trav_inner_step<COUNT, BLOCK, (mode >= 4 ? mode : 0)>(sc, tv, stk, cnt);
@@ -958,8 +946,6 @@ TRG_DEV void traverse_pair(const SceneView &sc, V3 org, bool has_shadow, V3 sdir
         const bool any = phase == 0;
         if (mode == 3) {
             trav_step_wide<COUNT, BLOCK>(sc, tv, any, stk, cnt);
-        } else if (mode == 1) {
-            trav_step_unified<COUNT, BLOCK>(sc, tv, any, stk, cnt);
         } else {
             while (tv.node >= 0) trav_inner_step<COUNT, BLOCK, (mode >= 4 ? mode : 0)>(sc, tv, stk, cnt);
             if (tv.node != kNodeDone && trav_leaf_step<COUNT, BLOCK>(sc, tv, any, stk, cnt)) tv.node = kNodeDone;
@@ -976,8 +962,6 @@ TRG_DEV void traverse_pair(const SceneView &sc, V3 org, bool has_shadow, V3 sdir
         }
     }
 }
-
-#include "trg_quad.inc.h"
 
 // ---------------------------------------------------------------------------------------------
 // Queue-draining tracer for the path-pool megakernel (render_pool_kernel).
@@ -1043,8 +1027,6 @@ TRG_DEV void trace_queue(const SceneView &sc, const PoolView pv, const unsigned 
             for (;;) {
                 if (mode == 3) {
                     trav_step_wide<COUNT, BLOCK>(sc, tv, any, stk, cnt);
-                } else if (mode == 1) {
-                    trav_step_unified<COUNT, BLOCK>(sc, tv, any, stk, cnt);
                 } else {
                     while (tv.node >= 0) trav_inner_step<COUNT, BLOCK, (mode >= 4 ? mode : 0)>(sc, tv, stk, cnt);
                     if (tv.node == kNodeDone) break;
@@ -1105,6 +1087,44 @@ TRG_DEV V3 texture_albedo(const trg::TexDesc &tex, int prim, float cx, float cy,
     const uint32_t texel = tex.texels[t[0] + y * w + x];
     const V3 c = mk(div_fast((float)(texel & 255u), 255.0f), div_fast((float)((texel >> 8) & 255u), 255.0f), div_fast((float)((texel >> 16) & 255u), 255.0f));
     return vcol * c;
+}
+
+// The surface a shading event reads at its hit (Raytracing.metal:150-163: material id, interpolated colour and normal).
+// FAT = the scene is traversed from HBM and `ref` is the leaf record of the hit: the material id (the mask of row 1) and the five
+// rows of attributes are loaded TOGETHER, before anything branches on the material -- one trip to a line the triangle test has
+// just touched, instead of material id -> branch -> colours + normals from three more arrays.  !FAT (scene in LDS): `ref` is the
+// original primitive index and the reference's three buffers are read as before.  Same arithmetic either way (interp_attr).
+template <bool FAT>
+struct Surf { uint32_t mat; int ref; v4f r3, r4, r5, r6, r7; };
+template <bool FAT>
+TRG_DEV Surf<FAT> surf_fetch(const SceneView &sc, int ref) {
+    Surf<FAT> s;
+    s.ref = ref;
+    if (FAT) {
+        const v4f *rec = sc.tris + (size_t)(uint32_t)ref * kRecV4;
+        s.mat = (uint32_t)__float_as_int(rec[1].w);
+        s.r3 = rec[3]; s.r4 = rec[4]; s.r5 = rec[5]; s.r6 = rec[6]; s.r7 = rec[7];
+    } else {
+        s.mat = sc.mats[ref];
+    }
+    return s;
+}
+// interpolated vertex colour (times the albedo texel, if the scene has textures) and the un-normalised interpolated normal
+template <bool FAT>
+TRG_DEV void surf_interp(const SceneView &sc, const Surf<FAT> &s, float cx, float cy, V3 &vcol, V3 &nraw) {
+    int prim = s.ref;
+    if (FAT) {
+        const float cz = 1.0f - cx - cy;
+        const V3 N0 = mk(s.r3.x, s.r3.y, s.r3.z), N1 = mk(s.r3.w, s.r4.x, s.r4.y), N2 = mk(s.r4.z, s.r4.w, s.r5.x);
+        const V3 C0 = mk(s.r5.y, s.r5.z, s.r5.w), C1 = mk(s.r6.x, s.r6.y, s.r6.z), C2 = mk(s.r6.w, s.r7.x, s.r7.y);
+        vcol = cx * C0 + cy * C1 + cz * C2;
+        nraw = cx * N0 + cy * N1 + cz * N2;
+        if (sc.tex.uv) prim = __float_as_int(sc.tris[(size_t)(uint32_t)s.ref * kRecV4].w);   // textures are addressed by the original index
+    } else {
+        vcol = interp_attr(sc.colors, prim, cx, cy);
+        nraw = interp_attr(sc.normals, prim, cx, cy);
+    }
+    if (sc.tex.uv) vcol = texture_albedo(sc.tex, prim, cx, cy, vcol);   // wave-uniform test: scenes without textures skip it
 }
 
 // ACES + sRGB (N1): common.h:36-43,163-171

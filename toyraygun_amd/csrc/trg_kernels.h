@@ -31,19 +31,15 @@ constexpr uint32_t kMaxLdsScene = 40u * 1024u;  // scenes up to this size are st
 #ifndef TRG_STACK_LDS_LEVELS
 #define TRG_STACK_LDS_LEVELS 12
 #endif
-// render_kernel on an HBM-resident scene: four lanes per ray (trg_quad.inc.h).  The quads' stacks use the LDS of the per-lane stack
-// levels (4 * klds - 1 entries per quad) and the result slots the LDS of the parked path state.
-#ifndef TRG_QUAD
-#define TRG_QUAD 0
-#endif
 #ifndef TRG_POOL_S
 #define TRG_POOL_S 2
 #endif
 constexpr int kPoolS = TRG_POOL_S;           // frames (path slots per thread) a pool workgroup keeps in flight
 constexpr uint32_t kPoolSlotBytes = 64u;      // R0, R1, SH, H: four float4 per slot
 
-// The scene lives in ONE device allocation: [nodes | tris | normals | colors | mats], every section
-// 16-byte aligned, so a workgroup can stage it into LDS with a single stream of 16-byte copies.
+// The scene lives in ONE device allocation.  A scene small enough for LDS starts with the part a workgroup stages:
+// [nodes | tris | normals | colors | mats | Halton tables], every section 16-byte aligned, so that it goes into LDS with a single
+// stream of 16-byte copies.  Every scene then has what the HBM kernels traverse: [quantised 4-wide nodes | 128-byte leaf records].
 struct SceneDesc {
     const unsigned char *blob;
     uint32_t off_nodes, off_tris, off_normals, off_colors, off_mats, blob_bytes;
@@ -51,7 +47,9 @@ struct SceneDesc {
     uint32_t off_nodes4, n_nodes4;  // 4-wide nodes (HBM traversal); they sit after the LDS-staged part of the blob
     uint32_t lds_stage_bytes;       // bytes a workgroup stages into LDS (everything before the 4-wide nodes)
     uint32_t off_htab;              // Halton group tables (kHtabFloats floats), inside the staged region
+    uint32_t off_fat, n_fat;        // leaf records of the HBM traversal: geometry + attributes, 128 bytes each, 128-byte aligned, leaf order
 };
+constexpr uint32_t kFatRecBytes = 128u;
 
 // albedo textures (trg_load_textures): per-corner texture coordinates, per-triangle texture id (0 = none), a table of
 // (first texel, width, height, -) per texture and the RGBA8 texels of all textures back to back.  uv == nullptr: no textures.
@@ -90,7 +88,11 @@ struct RenderParams {
     void *tail_radbuf;             // float4 [frames of the chunk][pixels of the band]
     uint32_t fsplit, fp_rounds;    // render_fp_kernel: frame lanes per workgroup (2 or 4), rounds parked per fold
     StackDesc stack;
+    // workgroup -> tile (trg_kernels.hip block_tile): tiles_x x tiles_y tiles of the launch; xcd_cols = 0: image columns from the centre
+    // outwards; 1, 2, 4, 8: the workgroups of one XCD (blockIdx.x % 8) own one of xcd_cols x (8 / xcd_cols) contiguous screen regions
+    uint32_t tiles_y, xcd_cols;
 };
+constexpr uint32_t kXcds = 8;   // XCDs of an MI355X: workgroups are dealt round-robin over them (MI355X_MICROARCH.md, workgroup dispatch)
 
 // ---- wavefront schedule (TRG_KERNEL_WAVEFRONT, trg_wavefront.inc.h): path state and ray queues of one batch in HBM ----
 constexpr uint32_t kWfMaxPaths = 8u << 20;   // pixel-samples per batch (112 B of state each)
@@ -134,11 +136,12 @@ struct HtabSpec { uint32_t base, digits, radix, offset; };
 constexpr HtabSpec kHtab[5] = { { 3, 4, 81, 0 }, { 5, 3, 125, 81 }, { 7, 2, 49, 206 }, { 11, 2, 121, 255 }, { 13, 2, 169, 376 } };
 constexpr uint32_t kHtabFloats = 545, kHtabBytes = 2192;  // 545 * 4 rounded up to 16
 
-// which BVH flavour the HBM (non-LDS) kernels traverse; must match TRG_TRAV_HBM in trg_device.h
+// which BVH flavour the HBM (non-LDS) kernels traverse; must match TRG_TRAV_HBM in trg_device.h (3 = quantised 4-wide: the only one)
 #ifndef TRG_TRAV_HBM
 #define TRG_TRAV_HBM 3
 #endif
 constexpr bool kWideHbm = (TRG_TRAV_HBM == 3);
+static_assert(kWideHbm, "scenes in HBM are traversed through the quantised 4-wide tree and 128-byte leaf records");
 // which node layout LDS-resident scenes are staged in; must match TRG_TRAV_LDS in trg_device.h
 #ifndef TRG_TRAV_LDS
 #define TRG_TRAV_LDS 4
@@ -163,7 +166,7 @@ static_assert(!(kSignedLds || kWideLds) || kWideHbm, "the LDS node layouts repla
     hipError_t launch_wf_raygen_##SFX(const WfParams &p, hipStream_t s);                                         \
     hipError_t launch_wf_trace_##SFX(const WfParams &p, bool lds_scene, bool counters, uint32_t grid, size_t lds_bytes, \
                                      hipStream_t s);                                                             \
-    hipError_t launch_wf_shade_##SFX(const WfParams &p, uint32_t grid, hipStream_t s);                           \
+    hipError_t launch_wf_shade_##SFX(const WfParams &p, bool lds_scene, uint32_t grid, hipStream_t s);           \
     hipError_t launch_wf_accumulate_##SFX(const WfParams &p, hipStream_t s);                                     \
     hipError_t launch_trace_##SFX(const TraceParams &p, bool lds_scene, bool any_hit, size_t lds_bytes,          \
                                   hipStream_t s);                                                                \
@@ -175,7 +178,8 @@ static_assert(!(kSignedLds || kWideLds) || kWideHbm, "the LDS node layouts repla
                                    uint32_t n, float *out12, hipStream_t s);                                     \
     hipError_t launch_postprocess_##SFX(const float *accum, uint32_t w, uint32_t h, uint8_t *rgba8, int flip_y,  \
                                         hipStream_t s);                                                          \
-    hipError_t launch_offsets_##SFX(uint32_t seed, uint32_t n, uint32_t *out, hipStream_t s);
+    hipError_t launch_offsets_##SFX(uint32_t seed, uint32_t n, uint32_t *out, hipStream_t s);                   \
+    hipError_t launch_xcc_probe_##SFX(uint32_t n_blocks, uint32_t *out, hipStream_t s);
 
 TRG_DECL_LAUNCHERS(fast)
 TRG_DECL_LAUNCHERS(strict)

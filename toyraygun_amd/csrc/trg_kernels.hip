@@ -41,11 +41,10 @@ TRG_DEV SceneView scene_view(const trg::SceneDesc &sc, unsigned char *smem) {
         v.mats = reinterpret_cast<const uint32_t *>(smem + sc.off_mats);
         v.htab = reinterpret_cast<const float *>(smem + sc.off_htab);
     } else {
-        v.nodes = reinterpret_cast<const v4f *>(sc.blob + (trg::kWideHbm ? sc.off_nodes4 : sc.off_nodes));
-        v.tris = reinterpret_cast<const v4f *>(sc.blob + sc.off_tris);
-        v.normals = reinterpret_cast<const float *>(sc.blob + sc.off_normals);
-        v.colors = reinterpret_cast<const float *>(sc.blob + sc.off_colors);
-        v.mats = reinterpret_cast<const uint32_t *>(sc.blob + sc.off_mats);
+        // traversed from HBM: the quantised 4-wide nodes and the 128-byte leaf records (geometry + attributes, trg_device.h kRecV4)
+        v.nodes = reinterpret_cast<const v4f *>(sc.blob + sc.off_nodes4);
+        v.tris = reinterpret_cast<const v4f *>(sc.blob + sc.off_fat);
+        v.normals = nullptr; v.colors = nullptr; v.mats = nullptr;
         v.htab = nullptr;
     }
     v.tex.uv = nullptr; v.tex.ids = nullptr; v.tex.table = nullptr; v.tex.texels = nullptr;
@@ -65,11 +64,48 @@ TRG_DEV uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
+// Workgroup slot -> tile of the launch (any bijection onto the tiles is correct; this is about time only).
+//  * xcd_cols == 0: image columns from the centre outwards (rows inner).  It starts the tiles a camera usually points at first, so the
+//    tail of the launch is made of the cheap edge tiles (C2: the 16:9 side bars) instead of leaving CUs idle behind a few expensive
+//    ones (+9 % on C2).
+//  * xcd_cols = 1, 2, 4, 8 (scenes traversed from HBM): XCD-aware.  Workgroups are dealt round-robin over the 8 XCDs, each with its own
+//    4 MiB L2, so the workgroups with equal slot % 8 share an L2.  They get ONE of xcd_cols x (8 / xcd_cols) contiguous regions of the
+//    screen (column strips x row bands) and walk it column by column away from the image centre: an L2 then sees the rays of one
+//    screen region -- one part of the scene -- instead of every eighth tile of the whole picture.  Regions differ in size by a
+//    row or a column at most, so the launch is padded to 8 x the largest region and the few slots beyond a region's end return false.
+//    All regions are at the same distance from the centre at the same time, which keeps the eight XCDs equally loaded while the
+//    dispatcher deals the workgroups out in order.
+TRG_DEV bool block_tile(const trg::RenderParams &p, uint32_t slot, uint32_t &bx, uint32_t &by) {
+    const uint32_t cleft = (p.tiles_x - 1u) / 2u;
+    if (p.xcd_cols == 0u) {
+        const uint32_t crank = slot / p.tiles_y;
+        by = slot % p.tiles_y;
+        bx = (crank & 1u) ? cleft + 1u + crank / 2u : cleft - crank / 2u;
+        return true;
+    }
+    const uint32_t x = slot % trg::kXcds, j = slot / trg::kXcds;
+    const uint32_t rc = p.xcd_cols, rq = trg::kXcds / rc;
+    const uint32_t ci = x % rc, qi = x / rc;
+    const uint32_t c0 = ci * p.tiles_x / rc, c1 = (ci + 1u) * p.tiles_x / rc;
+    const uint32_t r0 = qi * p.tiles_y / rq, r1 = (qi + 1u) * p.tiles_y / rq;
+    const uint32_t W = c1 - c0, H = r1 - r0;
+    if (H == 0u) return false;
+    const uint32_t c = j / H, r = j - c * H;
+    if (c >= W) return false;
+    if (rc == 1u) {   // one strip per row band: columns from the centre outwards, as above
+        bx = (c & 1u) ? cleft + 1u + c / 2u : cleft - c / 2u;
+    } else {
+        bx = (2u * ci < rc) ? c1 - 1u - c : c0 + c;   // strips left of the centre walk to the left edge, the others to the right edge
+    }
+    by = r0 + r;
+    return true;
+}
+
 // The shading event of one bounce (primaryHit, Raytracing.metal:115-215) for the lane's current ray and its
 // nearest-hit record: updates throughput / radiance / path state, moves the ray to the continuation ray and
 // returns the shadow ray to trace.  Shared by both loop shapes of render_kernel.
 struct ShadeOut { bool want_shadow, want_next, shaded; V3 sdir, scol; float smax; };
-template <bool TAB = false>
+template <bool TAB = false, bool FAT = false>
 TRG_DEV ShadeOut shade_event(const trg_uniforms &u, const SceneView &sc, const Hit &h, bool found, uint32_t b, bool last, uint32_t hidx,
                              V3 &o, V3 &d, V3 &thr, V3 &rad, uint32_t &rmask, bool &active, V3 light_color, const float *rpre = nullptr) {
     ShadeOut out;
@@ -78,15 +114,16 @@ TRG_DEV ShadeOut shade_event(const trg_uniforms &u, const SceneView &sc, const H
         active = false;  // Raytracing.metal:139-144
         return out;
     }
-    const uint32_t mat = sc.mats[h.prim];
+    const Surf<FAT> sf = surf_fetch<FAT>(sc, h.prim);   // FAT: h.prim is the leaf record of the hit
+    const uint32_t mat = sf.mat;
     if (mat == TRG_MATERIAL_DEFAULT) {
         out.shaded = true;
         // Raytracing.metal:150-199
         const V3 P = o + d * h.t;
         const float cx = 1.0f - h.u - h.v, cy = h.u;  // weights of vertex 0, 1
-        V3 vcol = interp_attr(sc.colors, h.prim, cx, cy);
-        if (sc.tex.uv) vcol = texture_albedo(sc.tex, h.prim, cx, cy, vcol);   // wave-uniform test: scenes without textures skip it
-        const V3 nrm = normalize(interp_attr(sc.normals, h.prim, cx, cy));
+        V3 vcol, nraw;
+        surf_interp<FAT>(sc, sf, cx, cy, vcol, nraw);
+        const V3 nrm = normalize(nraw);
         float r[4];
         // opaque copy: stops LICM from hoisting every bounce's Halton digits (all 60 dimensions) out of the
         // bounce loop and keeping them live in VGPRs
@@ -126,9 +163,9 @@ TRG_DEV ShadeOut shade_event(const trg_uniforms &u, const SceneView &sc, const H
 struct PathCounters { uint32_t primary, bounce, shadow, shaded; };
 TRG_DEV uint32_t wave_count(bool pred) { return (uint32_t)__popcll(__ballot(pred)); }
 typedef __attribute__((address_space(3))) float lds_float_t;
-template <bool LDS_SCENE, bool COUNT, bool QUAD = false, typename STK>
+template <bool LDS_SCENE, bool COUNT, typename STK>
 TRG_DEV V3 path_radiance(const trg::RenderParams &p, const SceneView &sc, STK stk, uint32_t x, uint32_t y, uint32_t offset, uint32_t frame, bool valid,
-                         V3 light_color, PathCounters &pc, Counters &cnt, lds_float_t *path_park = nullptr, QuadLds ql = QuadLds()) {
+                         V3 light_color, PathCounters &pc, Counters &cnt, lds_float_t *path_park = nullptr) {
     // Halton index of this pixel-sample (Raytracing.metal:67: offset + uniforms.frameIndex, wraps mod 2^32).  `frame` is wave-uniform:
     // the sum is re-formed where it is used instead of living in a VGPR of its own across the traversals.
     // (HBM scenes: the offset itself is parked in LDS behind the path state and read back where the index is formed)
@@ -190,12 +227,7 @@ TRG_DEV V3 path_radiance(const trg::RenderParams &p, const SceneView &sc, STK st
         // and the incoherent continuation rays give the wavefront nothing to overlap them with.)
         Hit h; h.t = -1.0f; h.prim = -1; h.u = 0.0f; h.v = 0.0f;
         bool found = false;
-        if (QUAD) {
-            bool occ0;
-            traverse_quads<COUNT, trg::kBlock>(sc, ql, o, false, d, -1.0f, p.bounces > 0u && active, d, TRG_RMASK, occ0, h, found, cnt);
-        } else {
-            if (p.bounces > 0u && active) found = traverse<false, COUNT, trg::kBlock, true>(sc, o, d, INFINITY, TRG_RMASK, h, stk, cnt);
-        }
+        if (p.bounces > 0u && active) found = traverse<false, COUNT, trg::kBlock, true>(sc, o, d, INFINITY, TRG_RMASK, h, stk, cnt);
         for (uint32_t b = 0; b < p.bounces; ++b) {
             if (__ballot(active) == 0ull) break;
             const bool last = (b + 1u == p.bounces);
@@ -205,7 +237,7 @@ TRG_DEV V3 path_radiance(const trg::RenderParams &p, const SceneView &sc, STK st
             ShadeOut so; so.want_shadow = false; so.want_next = false; so.shaded = false; so.sdir = mk(0.0f, 0.0f, 1.0f); so.scol = mk(0.0f, 0.0f, 0.0f); so.smax = -1.0f;
             if (active) {
                 uint32_t rmask = TRG_RMASK;
-                so = shade_event<TAB>(TRG_U, sc, h, found, b, last, TRG_HIDX, o, d, thr, rad, rmask, active, light_color);
+                so = shade_event<TAB, true>(TRG_U, sc, h, found, b, last, TRG_HIDX, o, d, thr, rad, rmask, active, light_color);
                 primary_ray = rmask == 3u;
             }
             pc.shaded += wave_count(so.shaded);
@@ -219,8 +251,7 @@ TRG_DEV V3 path_radiance(const trg::RenderParams &p, const SceneView &sc, STK st
                     path_park[0] = thr.x; path_park[trg::kBlock] = thr.y; path_park[2 * trg::kBlock] = thr.z;
                     path_park[3 * trg::kBlock] = rad.x; path_park[4 * trg::kBlock] = rad.y; path_park[5 * trg::kBlock] = rad.z;
                 }
-                if (QUAD) traverse_quads<COUNT, trg::kBlock>(sc, ql, o, so.want_shadow, so.sdir, so.smax, so.want_next, d, TRG_RMASK, occluded, h, found, cnt);
-                else traverse_pair<COUNT, trg::kBlock, true>(sc, o, so.want_shadow, so.sdir, so.smax, so.want_next, d, TRG_RMASK, occluded, h, found, stk, cnt);
+                traverse_pair<COUNT, trg::kBlock, true>(sc, o, so.want_shadow, so.sdir, so.smax, so.want_next, d, TRG_RMASK, occluded, h, found, stk, cnt);
                 if (path_park) {
                     thr = mk(path_park[0], path_park[trg::kBlock], path_park[2 * trg::kBlock]);
                     rad = mk(path_park[3 * trg::kBlock], path_park[4 * trg::kBlock], path_park[5 * trg::kBlock]);
@@ -257,13 +288,8 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES : TRG_EXP_WA
     // The wavefront index is wave-uniform (an SGPR) and the lane index is re-read with v_mbcnt wherever it is needed, so that
     // pixel coordinates, the pixel index and threadIdx do not occupy VGPRs across the frame loop (they used to be spilled).
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // workgroup -> tile: image columns from the centre outwards (rows inner).  Any bijection is correct; this one
-    // starts the tiles a camera usually points at first, so the tail of the launch is made of the cheap
-    // edge tiles (C2: the 16:9 side bars) instead of leaving CUs idle behind a few expensive ones (+9 %).
-    const uint32_t tiles_y = gridDim.x / p.tiles_x;
-    const uint32_t crank = blockIdx.x / tiles_y, by = blockIdx.x % tiles_y;
-    const uint32_t cleft = (p.tiles_x - 1u) / 2u;
-    const uint32_t bx = (crank & 1u) ? cleft + 1u + crank / 2u : cleft - crank / 2u;
+    uint32_t bx, by;
+    if (!block_tile(p, blockIdx.x, bx, by)) return;   // (a padding slot of the XCD-aware order)
     const uint32_t x0 = bx * trg::kTileW + (wave % (trg::kTileW / 8)) * 8;           // wave-uniform
     const uint32_t y0 = p.row0 + by * trg::kTileH + (wave / (trg::kTileW / 8)) * 8;  // wave-uniform
     bool valid;
@@ -274,16 +300,6 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES : TRG_EXP_WA
     constexpr bool PARK = !LDS_SCENE;
     lds_float_t *park = (lds_float_t *)(reinterpret_cast<float *>(smem + p.acc_off) + threadIdx.x);
     lds_float_t *path_park = (PARK && TRG_PARK_PATH) ? park + 3 * trg::kBlock : nullptr;
-    QuadLds ql; ql.stack = 0u; ql.res = 0u;
-#if TRG_QUAD
-    static_assert(!TRG_PARK_PATH, "the quad tracer's result slots use the LDS of the parked path state");
-    if (!LDS_SCENE) {
-        const uint32_t stride = 4u * p.stack.klds - 1u;   // ints per quad, level 0 = the sentinel
-        ql.stack = (uint32_t)(uintptr_t)(lds_int_t *)(reinterpret_cast<int *>(smem + p.stack_off) + (threadIdx.x >> 2) * stride);
-        ql.res = (uint32_t)(uintptr_t)(lds_int_t *)(reinterpret_cast<int *>(smem + p.acc_off) + 3 * trg::kBlock + (threadIdx.x & ~63u));
-        lds_st(ql.stack, kNodeDone);
-    }
-#endif
     V3 acc = mk(0.0f, 0.0f, 0.0f);
     {
         const uint32_t lane = lane_id();
@@ -307,7 +323,7 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES : TRG_EXP_WA
         // amplification, 8 scratch reloads per frame).  Recomputing them costs a dozen VALU instructions per frame.
         const uint32_t lane_f = lane_id_opaque();
         const uint32_t xf = x0 + (lane_f & 7), yf = y0 + (lane_f >> 3);
-        const V3 rad = path_radiance<LDS_SCENE, COUNT, TRG_QUAD && !LDS_SCENE>(p, sc, stk, xf, yf, offset, f, valid, light_color, pc, cnt, path_park, ql);
+        const V3 rad = path_radiance<LDS_SCENE, COUNT>(p, sc, stk, xf, yf, offset, f, valid, light_color, pc, cnt, path_park);
         if (PARK) acc = mk(park[0], park[trg::kBlock], park[2 * trg::kBlock]);
         // Accumulate.metal:19-39
         if (f == 0) {
@@ -374,10 +390,8 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES_FP : TRG_EXP
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t F = p.fsplit, subt = trg::kWaves / F;   // frame lanes, sub-tiles per workgroup (F in {2,4})
     const uint32_t sub = wave % subt, fl = wave / subt;
-    const uint32_t tiles_y = gridDim.x / p.tiles_x;          // centre-out tile order, as render_kernel
-    const uint32_t crank = blockIdx.x / tiles_y, by = blockIdx.x % tiles_y;
-    const uint32_t cleft = (p.tiles_x - 1u) / 2u;
-    const uint32_t bx = (crank & 1u) ? cleft + 1u + crank / 2u : cleft - crank / 2u;
+    uint32_t bx, by;                                         // tile order as render_kernel
+    if (!block_tile(p, blockIdx.x, bx, by)) return;
     const uint32_t x = (bx * subt + sub) * 8u + (lane & 7);
     const uint32_t y = p.row0 + by * 8u + (lane >> 3);
     const bool valid = (x < p.u.width) && (y < p.row0 + p.rows) && (y < p.u.height);
@@ -472,13 +486,8 @@ __global__ __launch_bounds__(trg::kBlock) void render_pool_kernel(const trg::Ren
     uint32_t *ctr = reinterpret_cast<uint32_t *>(lists + 4 * P);         // [0] head, [1] n(list 0), [2] n(list 1)
 
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // workgroup -> tile: image columns from the centre outwards (rows inner).  Any bijection is correct; this one
-    // starts the tiles a camera usually points at first, so the tail of the launch is made of the cheap
-    // edge tiles (C2: the 16:9 side bars) instead of leaving CUs idle behind a few expensive ones (+9 %).
-    const uint32_t tiles_y = gridDim.x / p.tiles_x;
-    const uint32_t crank = blockIdx.x / tiles_y, by = blockIdx.x % tiles_y;
-    const uint32_t cleft = (p.tiles_x - 1u) / 2u;
-    const uint32_t bx = (crank & 1u) ? cleft + 1u + crank / 2u : cleft - crank / 2u;
+    uint32_t bx, by;
+    if (!block_tile(p, blockIdx.x, bx, by)) return;
     const uint32_t x = bx * trg::kTileW + (wave % (trg::kTileW / 8)) * 8 + (lane & 7);
     const uint32_t y = p.row0 + by * trg::kTileH + (wave / (trg::kTileW / 8)) * 8 + (lane >> 3);
     const bool valid = (x < p.u.width) && (y < p.row0 + p.rows) && (y < p.u.height);
@@ -543,18 +552,19 @@ __global__ __launch_bounds__(trg::kBlock) void render_pool_kernel(const trg::Ren
                     if (!(h.x >= 0.0f)) {
                         alive[j] = false;  // Raytracing.metal:139-144
                     } else {
-                        const int prim = __float_as_int(h.y);
+                        const int prim = __float_as_int(h.y);   // scene in HBM: the leaf record of the hit
                         const float hu = h.z, hv = h.w;
-                        const uint32_t mat = sc.mats[prim];
+                        const Surf<!LDS_SCENE> sf = surf_fetch<!LDS_SCENE>(sc, prim);
+                        const uint32_t mat = sf.mat;
                         if (mat == TRG_MATERIAL_DEFAULT) {
                             n_shaded++;
                             const v4f r0 = pv.R0[slot], r1 = pv.R1[slot];
                             const V3 o = mk(r0.x, r0.y, r0.z), d = mk(r1.x, r1.y, r1.z);
                             const V3 Pp = o + d * h.x;
                             const float cx = 1.0f - hu - hv, cy = hu;
-                            V3 vcol = interp_attr(sc.colors, prim, cx, cy);
-                            if (sc.tex.uv) vcol = texture_albedo(sc.tex, prim, cx, cy, vcol);
-                            const V3 nrm = normalize(interp_attr(sc.normals, prim, cx, cy));
+                            V3 vcol, nraw;
+                            surf_interp<!LDS_SCENE>(sc, sf, cx, cy, vcol, nraw);
+                            const V3 nrm = normalize(nraw);
                             float r[4];
                             uint32_t hi = offset + f0 + j;
                             asm volatile("" : "+v"(hi));
@@ -655,7 +665,8 @@ __global__ __launch_bounds__(trg::kBlock) void trace_kernel(const trg::TracePara
     } else {
         trg_isect is;
         is.distance = found ? h.t : -1.0f;
-        is.primitiveIndex = found ? h.prim : -1;
+        // an HBM-resident scene names the leaf record of the hit: its first row carries the original index
+        is.primitiveIndex = found ? (LDS_SCENE ? h.prim : __float_as_int(sc.tris[(size_t)(uint32_t)h.prim * kRecV4].w)) : -1;
         is.coordinates[0] = found ? (1.0f - h.u - h.v) : 0.0f;
         is.coordinates[1] = found ? h.u : 0.0f;
         reinterpret_cast<trg_isect *>(p.out)[i] = is;
@@ -720,6 +731,13 @@ __global__ void postprocess_kernel(const v4f *accum, uint32_t w, uint32_t h, uin
         packed |= ((uint32_t)(v * 255.0f + 0.5f)) << (8 * a);
     }
     rgba8[i] = packed;
+}
+
+// which XCD does workgroup b run on?  (HW_REG_XCC_ID, bits 3:0; MI355X_MICROARCH.md "Workgroup dispatch, XCD placement")
+__global__ void xcc_probe_kernel(uint32_t *out) {
+    uint32_t id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+    if (threadIdx.x == 0) out[blockIdx.x] = id & 15u;
 }
 
 __global__ void offsets_kernel(uint32_t seed, uint32_t n, uint32_t *out) {
@@ -812,8 +830,9 @@ hipError_t SFX(launch_wf_trace)(const WfParams &p, bool lds_scene, bool counters
     }
     return hipGetLastError();
 }
-hipError_t SFX(launch_wf_shade)(const WfParams &p, uint32_t grid, hipStream_t s) {
-    hipLaunchKernelGGL(wf_shade_kernel, dim3(grid), dim3(256), 0, s, p);
+hipError_t SFX(launch_wf_shade)(const WfParams &p, bool lds_scene, uint32_t grid, hipStream_t s) {
+    if (lds_scene) hipLaunchKernelGGL((wf_shade_kernel<false>), dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((wf_shade_kernel<true>), dim3(grid), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 hipError_t SFX(launch_wf_accumulate)(const WfParams &p, hipStream_t s) {
@@ -863,6 +882,12 @@ hipError_t SFX(launch_postprocess)(const float *accum, uint32_t w, uint32_t h, u
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(postprocess_kernel, dim3((n + 255) / 256), dim3(256), 0, s, reinterpret_cast<const v4f *>(accum), w, h,
                        reinterpret_cast<uint32_t *>(rgba8), flip_y);
+    return hipGetLastError();
+}
+
+hipError_t SFX(launch_xcc_probe)(uint32_t n_blocks, uint32_t *out, hipStream_t s) {
+    if (n_blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(xcc_probe_kernel, dim3(n_blocks), dim3(256), 0, s, out);
     return hipGetLastError();
 }
 

@@ -51,7 +51,7 @@ typedef __attribute__((address_space(3))) v4f regen_rec_t;
 // the wavefront's staged records -> the workgroup's log: one LDS atomic reserves the range, lanes 0..cnt-1 write consecutive records
 TRG_DEV void regen_flush(const regen_rec_t *stage, uint32_t cnt, v4f *rlog, lds_int_t *pool_done) {
     if (cnt == 0u) return;
-    const uint32_t lane = lane_id();
+    const uint32_t lane = lane_id_opaque();   // (opaque: otherwise the address of stage[lane] is hoisted out of the kernel's main loop into a VGPR of its own)
     int base = 0;
     if (lane == 0u) base = atomicAdd((int *)pool_done, (int)cnt);
     base = __builtin_amdgcn_readfirstlane(base);
@@ -75,11 +75,13 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // p.fsplit workgroups share a tile ("frame lanes", as in render_fp_kernel): lane fl takes the frames fl, fl + F, ... of the chunk, so
     // that a launch of few tiles (a row band, a small window) still fills the chip
-    const uint32_t F = p.fsplit, tile_id = blockIdx.x / F, fl = blockIdx.x % F;   // wave-uniform
-    const uint32_t tiles_y = (gridDim.x / F) / p.tiles_x;
-    const uint32_t crank = tile_id / tiles_y, by = tile_id % tiles_y;
-    const uint32_t cleft = (p.tiles_x - 1u) / 2u;
-    const uint32_t bx = (crank & 1u) ? cleft + 1u + crank / 2u : cleft - crank / 2u;
+    // (XCD-aware order: the F workgroups of a tile are F consecutive slots of ONE XCD, so that they share its L2)
+    const uint32_t F = p.fsplit;   // wave-uniform
+    const uint32_t kx = blockIdx.x / trg::kXcds;
+    const uint32_t tile_id = p.xcd_cols ? (kx / F) * trg::kXcds + blockIdx.x % trg::kXcds : blockIdx.x / F;
+    const uint32_t fl = p.xcd_cols ? kx % F : blockIdx.x % F;
+    uint32_t bx, by;
+    if (!block_tile(p, tile_id, bx, by)) return;
     const uint32_t x0 = bx * trg::kTileW, y0 = p.row0 + by * trg::kTileH;   // the workgroup's 16x16 tile
     const uint32_t frames_wg = p.spp > fl ? (p.spp - fl + F - 1u) / F : 0u, frames_max = (p.spp + F - 1u) / F;
     v4f *rlog = reinterpret_cast<v4f *>(p.tail_radbuf) + (size_t)blockIdx.x * trg::kBlock * frames_max;   // this workgroup's log: 256 x frames records
@@ -105,6 +107,10 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
     if (lane_id() < 8u) wred[lane_id()] = 0;
     Counters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.wnodes = 0; cnt.wtris = 0;
     const V3 light_color = mk(p.u.light_color[0], p.u.light_color[1], p.u.light_color[2]);
+    // the number of the last bounce, as an SGPR the optimiser cannot see through (it rewrites `b + 1 == bounces` into `b == bounces - 1` and
+    // kept that difference in a VGPR of its own across the main loop); with no bounces at all it matches no shading event, and there is none
+    uint32_t last_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(p.bounces - 1u));
+    asm volatile("" : "+s"(last_b));
     const uint32_t n_jobs = (uint32_t)trg::kBlock * frames_wg;   // jobs of the workgroup's pool: its (j / 256)-th frame of tile pixel j % 256
 
     uint32_t jobb = 0u;           // the path this lane is working on (bits 0..23: its job) and the shading events it has had so far (bits 24..31)
@@ -217,19 +223,19 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
                         if (at) {
                             uint32_t hi = TRG_RG_HIDX;
                             asm volatile("" : "+v"(hi));
-                            if (bb + 1u == p.bounces) halton2<false>(hi, bb, r4, nullptr); else halton4<false>(hi, bb, r4, nullptr);
+                            if (bb == last_b) halton2<false>(hi, bb, r4, nullptr); else halton4<false>(hi, bb, r4, nullptr);
                         }
                     }
                     ShadeOut so; so.want_shadow = false; so.want_next = false; so.shaded = false;
                     if (mine) {
-                        const bool last = (TRG_RG_B + 1u == p.bounces);
+                        const bool last = TRG_RG_B == last_b;
                         V3 thr = mk(park[3 * trg::kBlock], park[4 * trg::kBlock], park[5 * trg::kBlock]);
                         V3 rad = mk(park[6 * trg::kBlock], park[7 * trg::kBlock], park[8 * trg::kBlock]);
                         if (has_shadow && !occluded) rad = rad + scol;
                         const Hit h = trav_hit(tv);
                         V3 o = tv.o, d = tv.d;
                         uint32_t rmask = primary_ray ? 3u : 1u;
-                        so = shade_event<false>(TRG_RG_U, sc, h, tv.found, TRG_RG_B, last, TRG_RG_HIDX, o, d, thr, rad, rmask, active, light_color, r4);
+                        so = shade_event<false, true>(TRG_RG_U, sc, h, tv.found, TRG_RG_B, last, TRG_RG_HIDX, o, d, thr, rad, rmask, active, light_color, r4);
                         primary_ray = rmask == 3u;
                         jobb += 1u << 24;
                         park[3 * trg::kBlock] = thr.x; park[4 * trg::kBlock] = thr.y; park[5 * trg::kBlock] = thr.z;
@@ -300,10 +306,8 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
 __global__ __launch_bounds__(trg::kBlock) void regen_accumulate_kernel(const trg::RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     v4f *stage = reinterpret_cast<v4f *>(smem);   // [frame in chunk][pixel in tile]
-    const uint32_t tiles_y = gridDim.x / p.tiles_x;
-    const uint32_t crank = blockIdx.x / tiles_y, by = blockIdx.x % tiles_y;
-    const uint32_t cleft = (p.tiles_x - 1u) / 2u;
-    const uint32_t bx = (crank & 1u) ? cleft + 1u + crank / 2u : cleft - crank / 2u;
+    uint32_t bx, by;
+    if (!block_tile(p, blockIdx.x, bx, by)) return;
     const uint32_t pl = threadIdx.x, sub = pl >> 6;
     const uint32_t x = bx * trg::kTileW + (sub % (trg::kTileW / 8)) * 8u + (pl & 7u);
     const uint32_t y = p.row0 + by * trg::kTileH + (sub / (trg::kTileW / 8)) * 8u + ((pl >> 3) & 7u);
@@ -312,7 +316,9 @@ __global__ __launch_bounds__(trg::kBlock) void regen_accumulate_kernel(const trg
     const uint32_t F = p.fsplit, frames_max = (p.spp + F - 1u) / F;
     for (uint32_t fl = 0; fl < F; ++fl) {   // the logs of the tile's frame lanes
         const uint32_t n_rec = n_valid * (p.spp > fl ? (p.spp - fl + F - 1u) / F : 0u);
-        const v4f *rlog = reinterpret_cast<const v4f *>(p.tail_radbuf) + ((size_t)blockIdx.x * F + fl) * trg::kBlock * frames_max;
+        // the workgroup that rendered frame lane fl of this tile (render_regen_kernel's slot arithmetic, inverted)
+        const uint32_t wg = p.xcd_cols ? ((blockIdx.x / trg::kXcds) * F + fl) * trg::kXcds + blockIdx.x % trg::kXcds : blockIdx.x * F + fl;
+        const v4f *rlog = reinterpret_cast<const v4f *>(p.tail_radbuf) + (size_t)wg * trg::kBlock * frames_max;
         for (uint32_t i = threadIdx.x; i < n_rec; i += trg::kBlock) {
             const v4f r = rlog[i];
             const uint32_t code = (uint32_t)__float_as_int(r.w);

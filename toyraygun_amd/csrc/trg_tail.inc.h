@@ -70,10 +70,11 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES) void render_head_kernel
     LdsStackT<trg::kBlock, false> stk;
     stk.set(smem, p.stack_off, p.stack.overflow, p.stack.klds);
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t tiles_y = gridDim.x / p.tiles_x;
-    const uint32_t crank = blockIdx.x / tiles_y, by = blockIdx.x % tiles_y;
-    const uint32_t cleft = (p.tiles_x - 1u) / 2u;
-    const uint32_t bx = (crank & 1u) ? cleft + 1u + crank / 2u : cleft - crank / 2u;
+    uint32_t bx, by;
+    if (!block_tile(p, blockIdx.x, bx, by)) {   // a padding slot of the XCD-aware order: its wavefronts queue nothing
+        if (lane_id() == 0u) p.tail_count[blockIdx.x * (uint32_t)trg::kWaves + wave] = 0u;
+        return;
+    }
     const uint32_t x0 = bx * trg::kTileW + (wave % (trg::kTileW / 8)) * 8;
     const uint32_t y0 = p.row0 + by * trg::kTileH + (wave / (trg::kTileW / 8)) * 8;
     bool valid;

@@ -169,8 +169,6 @@ __global__ __launch_bounds__(trg::kBlock, 8) void wf_trace_kernel(const trg::WfP
             for (;;) {
                 if (mode == 3) {
                     trav_step_wide<COUNT, trg::kBlock>(sc, tv, any, stk, cnt);
-                } else if (mode == 1) {
-                    trav_step_unified<COUNT, trg::kBlock>(sc, tv, any, stk, cnt);
                 } else {
                     while (tv.node >= 0) trav_inner_step<COUNT, trg::kBlock, (mode >= 4 ? mode : 0)>(sc, tv, stk, cnt);
                     if (tv.node == kNodeDone) break;
@@ -226,15 +224,18 @@ TRG_DEV void wf_append2(bool pa, uint32_t va, bool pb, uint32_t vb, uint32_t *li
 
 // ---- the shading event of bounce p.bounce (primaryHit, Raytracing.metal:115-215; the shadowHit of the previous bounce first) for
 //      every nearest-hit entry of stage p.stage; appends the rays of stage p.stage + 1 ----
+// FAT: the tracer walked the scene from HBM, so the hit records name leaf records (trg_device.h kRecV4) and the attributes come from there
+template <bool FAT>
 __global__ __launch_bounds__(256) void wf_shade_kernel(const trg::WfParams p) {
     const WfView w = wf_view(p);
     const trg::SceneDesc &sd = p.sc;
     SceneView sc;
-    sc.nodes = nullptr; sc.tris = nullptr; sc.htab = nullptr;
+    sc.nodes = nullptr; sc.htab = nullptr;
     sc.tex = p.tex;
-    sc.normals = reinterpret_cast<const float *>(sd.blob + sd.off_normals);
-    sc.colors = reinterpret_cast<const float *>(sd.blob + sd.off_colors);
-    sc.mats = reinterpret_cast<const uint32_t *>(sd.blob + sd.off_mats);
+    sc.tris = FAT ? reinterpret_cast<const v4f *>(sd.blob + sd.off_fat) : nullptr;
+    sc.normals = FAT ? nullptr : reinterpret_cast<const float *>(sd.blob + sd.off_normals);
+    sc.colors = FAT ? nullptr : reinterpret_cast<const float *>(sd.blob + sd.off_colors);
+    sc.mats = FAT ? nullptr : reinterpret_cast<const uint32_t *>(sd.blob + sd.off_mats);
     const uint32_t *list = p.stage ? p.b.list[p.stage & 1u] : nullptr;
     const uint32_t count = p.stage ? p.b.ctr[4u * p.stage + 1u] : p.nb;
     uint32_t *next = p.b.list[(p.stage + 1u) & 1u];
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(256) void wf_shade_kernel(const trg::WfParams p) {
             bool active = true;
             Hit h; h.t = hv.x; h.prim = __float_as_int(hv.y); h.u = hv.z; h.v = hv.w;
             const bool found = hv.x >= 0.0f;
-            so = shade_event<false>(p.u, sc, h, found, b, last, p.offsets[pix] + frame, o, d, thr, rad, rmask, active, light_color);
+            so = shade_event<false, FAT>(p.u, sc, h, found, b, last, p.offsets[pix] + frame, o, d, thr, rad, rmask, active, light_color);
             v4f t4, ra4;
             t4.x = thr.x; t4.y = thr.y; t4.z = thr.z; t4.w = 0.0f;
             ra4.x = rad.x; ra4.y = rad.y; ra4.z = rad.z; ra4.w = 0.0f;
