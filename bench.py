@@ -2,28 +2,31 @@
 """bench.py -- headline benchmark: Mrays/s (primary + bounce + shadow rays) on the Cornell box.
 
   python bench.py --gpus 1 --steps K --warmup W [--config c2|c3|c4|c5]
+  python bench.py --gpus N ...                      (N > 1, no launcher: ONE process, one context + host thread per GPU -- trg_group_*)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-         bench.py --gpus N --steps K --warmup W
+         bench.py --gpus N --steps K --warmup W     (one process per GPU, torch.distributed over RCCL)
 
 Default workload = BASELINE.json configs[1] ("C2"): Cornell box (src/cornellBox.h), 1920x1080, 16 spp, 3 bounces,
 synthetic inputs of SURVEY 8d (seeded per-pixel Halton offsets).  `--config c4` = configs[3]: the same settings on the
 1,022,244-triangle replicated-mesh scene (the only configuration whose working set lives in HBM); c3 / c5 = configs[2] /
 configs[4] on one GPU.  One STEP = one pass of the hot path over the whole frame: ONE megakernel launch per GPU (raygen ->
 bounces x [nearest, shade, shadow] -> accumulate for all samples) and, for N > 1, one RCCL all-gather of the row bands.
-The frame is fixed, so N > 1 is STRONG scaling: rank g renders rows [g*h/N, (g+1)*h/N).
+The frame is fixed, so N > 1 is STRONG scaling: rank g renders its band of rows.
 
 Rank 0 prints one JSON line.  `value` counts rays actually traversed (in-kernel counters), inputs resident in HBM
-before the timed region.
+before the timed region.  The default run (N = 1, C2) also times C4 and C3 after the headline and reports them under
+`secondary` (same method, fewer steps): the configurations where the HBM roofline (C4) and the divergence (C3) live.
 
 `roofline` names the resource that BINDS the dominant kernel and never prints a fraction above 1:
   * scene staged in LDS (C2/C3/C5): the kernel is bound by VALU issue -- `bound: "valu_issue"`, wave-level VALU
-    instructions per launch (rocprofv3 SQ_INSTS_VALU of this build, imported from profiles/, labelled so) x 2 cycles
-    / (1024 SIMDs x 2.4 GHz) against the launch duration measured live with HIP events; beside it `lds` (algorithmic
-    bytes of SURVEY 8(d) -- here they are LDS reads -- from this run's in-kernel counters against the ~150 TB/s
-    ds_read_b128 aggregate) and `hbm` (measured FETCH_SIZE + WRITE_SIZE against 8 TB/s).  Without an imported counter
-    file the primary bound falls back to "lds", which is measured entirely in this run.
+    instructions per launch (rocprofv3 SQ_INSTS_VALU, imported from profiles/ and accepted only if the kernel sources
+    hash to what they were measured on) x 2 cycles / (1024 SIMDs x 2.4 GHz) against the launch duration measured live
+    with HIP events; beside it `lds` (algorithmic bytes of SURVEY 8(d) -- here they are LDS reads -- from this run's
+    in-kernel counters against the ~150 TB/s ds_read_b128 aggregate) and `hbm` (measured FETCH_SIZE + WRITE_SIZE against
+    8 TB/s).  Without usable imported counters the primary bound falls back to "lds", which is measured entirely in this run.
   * scene in HBM (C4): `bound: "hbm"`, algorithmic bytes per launch / launch duration against 8 TB/s, with the measured
-    memory-side traffic (`traffic`, `hbm_measured`) side by side.
+    memory-side traffic (`traffic`, `hbm_measured`) side by side; when the algorithmic rate exceeds the HBM peak (L2 serves it)
+    the primary bound is VALU issue.
 `cpu_baseline` times the CPU oracle (a port: the reference has no CPU path) on the host cores, rank 0, N = 1 only:
 the headline leg is the benched configuration on all cores; the other legs are bounded samples (single thread,
 reduced spp) of the BASELINE configurations with the extrapolation factor stated.
@@ -46,7 +49,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 LDS_PEAK_GBS = 150000.0     # aggregate ds_read_b64/b128 rate with every CU streaming (MI355X_MICROARCH.md, LDS)
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0  # wave-level VALU instructions per ns: 1024 SIMDs, 2 cycles per wave64 instruction, 2.4 GHz
-PROFILE_ROUND = "r02"
+PROFILE_ROUNDS = ("r03", "r02")   # newest first: the first counters file whose kernel-source hash matches this tree is used
 
 CONFIGS = {
     "c2": dict(w=1920, h=1080, spp=16, bounces=3, scene="cornell",
@@ -58,6 +61,7 @@ CONFIGS = {
     "c5": dict(w=3840, h=2160, spp=64, bounces=3, scene="cornell",
                workload="Cornell box (36 triangles) 3840x2160, 64 spp, 3 bounces (BASELINE configs[4]; row bands over the GPUs)"),
 }
+SECONDARY = (("c4", 5, 1), ("c3", 3, 1))   # (config, steps, warmup) timed after the headline of the default run
 
 
 def scene_buffers(cfg):
@@ -109,45 +113,105 @@ def cpu_baseline(config_name):
 
 
 def imported_counters(config_name):
-    """Per-launch PMC counters of THIS build's megakernel from the committed rocprofv3 passes (scripts/profile_round.sh ->
-    profiles/<round>/<config>_counters.json).  bench.py cannot run the profiler on itself; the numbers are labelled imported."""
-    path = os.path.join(ROOT, "profiles", PROFILE_ROUND, "%s_counters.json" % config_name)
-    if not os.path.exists(path):
-        return None, None
-    try:
-        return json.load(open(path)), os.path.relpath(path, ROOT)
-    except Exception:
-        return None, None
+    """Per-launch PMC counters of the benched megakernel from the committed rocprofv3 passes (scripts/profile_round.sh ->
+    profiles/<round>/<config>_counters.json).  bench.py cannot run the profiler on itself; the numbers are labelled imported,
+    and they are only USED when the file's kernel-source hash equals this tree's (toyraygun_amd/srchash.py): instruction counts
+    of a different kernel say nothing about this one.  Returns (counters or None, path, stale_counters or None)."""
+    from toyraygun_amd.srchash import kernel_source_hash
+    here = kernel_source_hash()
+    stale = None
+    for rnd in PROFILE_ROUNDS:
+        path = os.path.join(ROOT, "profiles", rnd, "%s_counters.json" % config_name)
+        if not os.path.exists(path):
+            continue
+        try:
+            rec = json.load(open(path))
+        except Exception:
+            continue
+        rel = os.path.relpath(path, ROOT)
+        if rec.get("kernel_source_hash") == here:
+            return rec, rel, None
+        if stale is None:
+            stale = dict(rec, path=rel, reason="kernel sources changed since these counters were taken (hash %s, this tree %s)" % (rec.get("kernel_source_hash"), here))
+    return None, None, stale
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-    cfg = CONFIGS[args.config]
-    W, H, SPP, BOUNCES = cfg["w"], cfg["h"], cfg["spp"], cfg["bounces"]
+def build_roofline(config_name, cst, rays_per_launch, bytes_per_ray, mix, kernel_ms, concurrency, kernel_eff_ms, kernel_ms_alone, lane_util_nodes, use_imported=True):
+    """The roofline object of one timed configuration (module docstring)."""
+    in_lds = bool(cst.scene_in_lds)
+    sec = kernel_eff_ms * 1e-3                       # GPU time per launch in the timed region (slowest rank)
+    bytes_per_launch = rays_per_launch * bytes_per_ray
+    algorithmic_gbs = bytes_per_launch / sec / 1e9
+    imp, imp_path, stale = imported_counters(config_name) if use_imported else (None, None, None)
+    traffic = imp.get("hbm_bytes_per_launch") if imp else None
+    rf = {"kernel_ms": kernel_ms, "launches_in_flight": concurrency, "kernel_ms_per_launch_effective": kernel_eff_ms,
+          "kernel_alone_ms": kernel_ms_alone, "kernel_alone_mrays_per_s": rays_per_launch / (kernel_ms_alone * 1e-3) / 1e6,
+          "algorithmic_bytes_per_ray": bytes_per_ray, "bytes_per_launch": bytes_per_launch, **mix,
+          "lane_utilisation_node_loop": lane_util_nodes,
+          "traffic": traffic,
+          "imported": ("%s (rocprofv3 --pmc passes of this build, kernel-source hash %s: %s)" % (imp_path, imp.get("kernel_source_hash"), imp.get("source", "")) if imp else None)}
+    if stale:
+        rf["imported_stale"] = True
+        rf["imported_stale_detail"] = {k: stale.get(k) for k in ("path", "reason", "commit", "valu_insts_per_launch", "hbm_bytes_per_launch")}
+    hbm_measured = None
+    if traffic:
+        hbm_measured = {"achieved": traffic / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": traffic / sec / 1e9 / HBM_PEAK_GBS,
+                        "bytes_per_launch": traffic, "source": "imported: FETCH_SIZE + WRITE_SIZE per launch"}
+    valu = None
+    if imp and imp.get("valu_insts_per_launch"):
+        g = imp["valu_insts_per_launch"] / sec / 1e9
+        lanes = imp.get("lanes_active_per_valu_inst")
+        valu = {"achieved": g, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s", "frac": g / VALU_PEAK_GINST,
+                "valu_insts_per_launch": imp["valu_insts_per_launch"],
+                "lanes_active_per_instruction": lanes,
+                "lane_weighted_frac": (g / VALU_PEAK_GINST * lanes / 64.0) if lanes else None,
+                "source": "imported: SQ_INSTS_VALU per launch; peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction; lane_weighted_frac = frac x lanes / 64"}
+    if in_lds:
+        lds = {"achieved": algorithmic_gbs, "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": algorithmic_gbs / LDS_PEAK_GBS,
+               "note": "SURVEY 8(d)'s algorithmic bytes are LDS reads here (the %.1f KB scene is staged per workgroup); measured live" % (cst.scene_bytes / 1024.0)}
+        if valu:
+            rf = {"bound": "valu_issue", "achieved": valu["achieved"], "peak": valu["peak"], "unit": valu["unit"], "frac": valu["frac"], **rf,
+                  "valu_issue": valu, "lds": lds, "hbm": hbm_measured}
+        else:
+            rf = {"bound": "lds", "achieved": lds["achieved"], "peak": lds["peak"], "unit": lds["unit"], "frac": lds["frac"], **rf,
+                  "lds": lds, "hbm": hbm_measured}
+        rf["note"] = ("LDS-resident scene: the kernel is VALU-issue bound at partial lane utilisation; the HBM side only sees the "
+                      "4-byte offset read and the 16-byte accumulation write per pixel (SURVEY 8d caveat)")
+    else:
+        hbm_alg = {"achieved": algorithmic_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algorithmic_gbs / HBM_PEAK_GBS}
+        note = ("algorithmic bytes (SURVEY 8d: 16 B per box of the 64-byte 4-wide node + 48 B per triangle test + 76 B per shaded hit) "
+                "against the HBM peak; `traffic` / hbm_measured = what left L2 towards Infinity Cache / HBM")
+        if hbm_alg["frac"] > 1.0 and valu:
+            # L2 serves most of the algorithmic bytes: once they exceed the HBM peak they bound nothing -- report the issue rate that does
+            rf = {"bound": "valu_issue", "achieved": valu["achieved"], "peak": valu["peak"], "unit": valu["unit"], "frac": valu["frac"], **rf,
+                  "hbm_algorithmic": hbm_alg, "hbm_measured": hbm_measured, "valu_issue": valu,
+                  "note": note + "; the algorithmic rate is above the HBM peak (L2 hit rate ~80 %), so the primary bound is VALU issue"}
+        elif hbm_alg["frac"] > 1.0:
+            # no usable instruction counters and an algorithmic rate above the peak: report the rate, never a fraction above 1
+            rf = {"bound": "hbm", "achieved": hbm_alg["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, **rf,
+                  "hbm_algorithmic": hbm_alg, "hbm_measured": hbm_measured,
+                  "note": note + "; the algorithmic rate is ABOVE the HBM peak because L2 serves ~80 % of it: it is no fraction of anything (frac null)"}
+        else:
+            rf = {"bound": "hbm", **hbm_alg, **rf, "hbm_measured": hbm_measured, "valu_issue": valu, "note": note}
+    return rf
 
+
+def kernel_name(st, in_lds):
+    return (("render_regen_kernel (path regeneration: a job pool per workgroup) + regen_accumulate_kernel" if getattr(st, "last_regen", 0)
+             else "render_kernel" if st.last_frame_split <= 1 else "render_fp_kernel, %d frame lanes" % st.last_frame_split)
+            + ("<LDS scene>" if in_lds else "<HBM scene, quantised 4-wide BVH, 128-byte leaf records>")
+            + (" + tail compaction from bounce %d (render_head / render_tail kernels)" % st.last_tail_bounce if st.last_tail_bounce else "") + " (fast build)")
+
+
+def run_torch(config_name, steps, warmup, env, use_imported=True):
+    """One configuration on this process' GPU (N = 1) or on its row band (one process per GPU under torch.distributed.run).
+    Returns the result dict on rank 0, None elsewhere."""
     import torch
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
-    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ  # under torch.distributed.run (also with N = 1)
-    if distributed or launched:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if args.gpus != world:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
-
     from toyraygun_amd import capi
     from toyraygun_amd.dist import DistributedRenderer
-
+    dist, distributed, rank, world, local_rank = env["dist"], env["distributed"], env["rank"], env["world"], env["local_rank"]
+    cfg = CONFIGS[config_name]
+    W, H, SPP, BOUNCES = cfg["w"], cfg["h"], cfg["spp"], cfg["bounces"]
     buffers, uniforms = scene_buffers(cfg)
     # four frame buffers on four alternating render streams (+ a communication stream): consecutive steps are independent
     # images, so the next steps fill the CUs that the tail of step k leaves idle (or that a small row band never fills),
@@ -182,7 +246,7 @@ def main():
     for _ in range(len(r.render_streams)):
         r.render(0, SPP, BOUNCES, gather=False)
     sync_all()
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         r.render(0, SPP, BOUNCES, gather=gather)
     sync_all()
     # launch duration of the megakernel when it runs ALONE: HIP events on the stream it runs on (trg_render brackets the
@@ -198,7 +262,7 @@ def main():
     r.ctx.reset_stats()
     r.time_launches = True   # HIP events around every launch, on the stream it runs on, no host sync
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         r.render(0, SPP, BOUNCES, gather=gather)
     sync_all()
     dt = time.perf_counter() - t0
@@ -223,71 +287,139 @@ def main():
         rays_total = rays_local
         kernel_eff_ms = kernel_ms / concurrency
 
+    out = None
     if rank == 0:
-        value = rays_total / dt / 1e6
         in_lds = bool(cst.scene_in_lds)
-        sec = kernel_eff_ms * 1e-3                       # GPU time per launch in the timed region (slowest rank)
-        bytes_per_launch = rays_per_launch * bytes_per_ray
-        algorithmic_gbs = bytes_per_launch / sec / 1e9
-        imp, imp_path = imported_counters(args.config) if world == 1 else (None, None)
-        traffic = imp.get("hbm_bytes_per_launch") if imp else None
-        rf = {"kernel_ms": kernel_ms, "launches_in_flight": concurrency, "kernel_ms_per_launch_effective": kernel_eff_ms,
-              "kernel_alone_ms": kernel_ms_alone, "kernel_alone_mrays_per_s": rays_per_launch / (kernel_ms_alone * 1e-3) / 1e6,
-              "algorithmic_bytes_per_ray": bytes_per_ray, "bytes_per_launch": bytes_per_launch, **mix,
-              "lane_utilisation_node_loop": lane_util_nodes,
-              "traffic": traffic,
-              "imported": ("%s (rocprofv3 --pmc passes of this build: %s)" % (imp_path, imp.get("source", "")) if imp else None)}
-        hbm_measured = None
-        if traffic:
-            hbm_measured = {"achieved": traffic / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": traffic / sec / 1e9 / HBM_PEAK_GBS,
-                            "bytes_per_launch": traffic, "source": "imported: FETCH_SIZE + WRITE_SIZE per launch"}
-        valu = None
-        if imp and imp.get("valu_insts_per_launch"):
-            g = imp["valu_insts_per_launch"] / sec / 1e9
-            valu = {"achieved": g, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s", "frac": g / VALU_PEAK_GINST,
-                    "valu_insts_per_launch": imp["valu_insts_per_launch"],
-                    "lanes_active_per_instruction": imp.get("lanes_active_per_valu_inst"),
-                    "source": "imported: SQ_INSTS_VALU per launch; peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction"}
-        if in_lds:
-            lds = {"achieved": algorithmic_gbs, "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": algorithmic_gbs / LDS_PEAK_GBS,
-                   "note": "SURVEY 8(d)'s algorithmic bytes are LDS reads here (the %.1f KB scene is staged per workgroup); measured live" % (cst.scene_bytes / 1024.0)}
-            if valu:
-                rf = {"bound": "valu_issue", "achieved": valu["achieved"], "peak": valu["peak"], "unit": valu["unit"], "frac": valu["frac"], **rf,
-                      "valu_issue": valu, "lds": lds, "hbm": hbm_measured}
-            else:
-                rf = {"bound": "lds", "achieved": lds["achieved"], "peak": lds["peak"], "unit": lds["unit"], "frac": lds["frac"], **rf,
-                      "lds": lds, "hbm": hbm_measured}
-            rf["note"] = ("LDS-resident scene: the kernel is VALU-issue bound at partial lane utilisation; the HBM side only sees the "
-                          "4-byte offset read and the 16-byte accumulation write per pixel (SURVEY 8d caveat)")
-        else:
-            hbm_alg = {"achieved": algorithmic_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algorithmic_gbs / HBM_PEAK_GBS}
-            note = ("algorithmic bytes (SURVEY 8d: 16 B per box of the 64-byte 4-wide node + 48 B per triangle test + 76 B per shaded hit) "
-                    "against the HBM peak; `traffic` / hbm_measured = what left L2 towards Infinity Cache / HBM")
-            if hbm_alg["frac"] > 1.0 and valu:
-                # L2 serves most of the algorithmic bytes: once they exceed the HBM peak they bound nothing -- report the issue rate that does
-                rf = {"bound": "valu_issue", "achieved": valu["achieved"], "peak": valu["peak"], "unit": valu["unit"], "frac": valu["frac"], **rf,
-                      "hbm_algorithmic": hbm_alg, "hbm_measured": hbm_measured, "valu_issue": valu,
-                      "note": note + "; the algorithmic rate is above the HBM peak (L2 hit rate ~80 %), so the primary bound is VALU issue"}
-            else:
-                rf = {"bound": "hbm", **hbm_alg, **rf, "hbm_measured": hbm_measured, "valu_issue": valu, "note": note}
+        rf = build_roofline(config_name, cst, rays_per_launch, bytes_per_ray, mix, kernel_ms, concurrency, kernel_eff_ms, kernel_ms_alone, lane_util_nodes,
+                            use_imported=use_imported and world == 1)
         out = {
             "metric": "Mrays/s (primary+shadow+bounce) at %dx%d" % (W, H),
-            "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "value": rays_total / dt / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": cfg["workload"], "name": args.config,
-                       "rays_per_step": rays_total / args.steps, "sharding": "row bands + RCCL all-gather (gather of step k overlaps the renders that follow)" if distributed else "none",
+            "config": {"workload": cfg["workload"], "name": config_name,
+                       "rays_per_step": rays_total / steps, "sharding": "row bands + RCCL all-gather, one process per GPU (gather of step k overlaps the renders that follow)" if distributed else "none",
                        "pipeline": ("%d frames in flight on alternating streams: later steps fill the CUs the tail of step k leaves idle "
                                     "(roofline.kernel_ms = average launch duration while they overlap; kernel_alone_ms = one launch by itself)" % len(r.render_streams)) if getattr(r, "_overlap", False) else "serial launches",
-                       "kernel": ("render_regen_kernel (path regeneration: a job pool per workgroup) + regen_accumulate_kernel" if getattr(st, "last_regen", 0) else "render_kernel" if st.last_frame_split <= 1 else "render_fp_kernel, %d frame lanes" % st.last_frame_split) + ("<LDS scene>" if in_lds else "<HBM scene, quantised 4-wide BVH>") +
-                                 (" + tail compaction from bounce %d (render_head / render_tail kernels)" % st.last_tail_bounce if st.last_tail_bounce else "") + " (fast build)",
+                       "kernel": kernel_name(st, in_lds),
                        "triangles": int(len(buffers["material_ids"])), "scene_bytes": int(cst.scene_bytes)},
             "roofline": rf,
         }
+    r.close()
+    return out
+
+
+def run_group(args):
+    """`--gpus N` without a launcher: ONE process, trg_group_* (one context + one host thread per device, row bands, one
+    in-place ncclAllGather per frame over xGMI).  Same JSON line; `config.sharding` names the design, `gather_ms_per_step` is the
+    exchange (steps with the all-gather minus steps without it)."""
+    import torch   # device count only: nothing here initialises the GPU before the library does
+    from toyraygun_amd import capi
+    n = args.gpus
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (n, have))
+    cfg = CONFIGS[args.config]
+    W, H, SPP, BOUNCES = cfg["w"], cfg["h"], cfg["spp"], cfg["bounces"]
+    buffers, uniforms = scene_buffers(cfg)
+    g = capi.Group(list(range(n)), W, H)
+    try:
+        g.load_scene(buffers["positions"], buffers["normals"], buffers["colors"], buffers["indices"], buffers["material_ids"])
+        g.set_uniforms(uniforms)
+        g.set_pixel_offsets_seed()
+        # counters pass (untimed, synchronous): rays per step and the algorithmic bytes per ray, summed over the bands
+        g.set_option(capi.OPT_COUNTERS, 1)
+        g.render(0, SPP, BOUNCES, capi.GATHER_NONE)
+        g.sync()
+        cst = g.stats()
+        bytes_per_ray, mix = algorithmic_bytes_per_ray(cst, H * W * SPP)
+        rays_per_step = float(cst.rays)
+        per_rank_rays = g.rank_rays() if hasattr(g, "rank_rays") else None
+        g.set_option(capi.OPT_COUNTERS, 0)
+        kernel_ms_alone = cst.last_render_ms      # slowest device, its band alone (HIP events)
+        g.set_option(capi.OPT_TIMING, 0)          # asynchronous from here on: a step only enqueues
+
+        def timed(gather, k):
+            g.sync()
+            t0 = time.perf_counter()
+            for _ in range(k):
+                g.render(0, SPP, BOUNCES, gather)
+            g.sync()
+            return time.perf_counter() - t0
+
+        timed(capi.GATHER_ALL, max(args.warmup, 1))
+        dt = timed(capi.GATHER_ALL, args.steps)
+        dt_nogather = timed(capi.GATHER_NONE, args.steps)
+        in_lds = bool(cst.scene_in_lds)
+        sec = dt / args.steps
+        rf = build_roofline(args.config, cst, rays_per_step, bytes_per_ray, mix, sec * 1e3, 1.0, sec * 1e3, kernel_ms_alone, None, use_imported=False)
+        out = {
+            "metric": "Mrays/s (primary+shadow+bounce) at %dx%d" % (W, H),
+            "value": rays_per_step * args.steps / dt / 1e6, "unit": "Mrays/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": cfg["workload"], "name": args.config, "rays_per_step": rays_per_step,
+                       "sharding": "single process, trg_group: %d contexts + persistent host threads, bands of ceil(h / N) rows, one in-place ncclAllGather per frame over xGMI" % n,
+                       "per_rank_rays_per_step": per_rank_rays,
+                       "ms_per_step_without_gather": dt_nogather / args.steps * 1e3,
+                       "gather_ms_per_step": max(0.0, (dt - dt_nogather) / args.steps * 1e3),
+                       "kernel": "per-band launches of the configuration's megakernel" + ("<LDS scene>" if in_lds else "<HBM scene>") + " (fast build)",
+                       "triangles": int(len(buffers["material_ids"])), "scene_bytes": int(cst.scene_bytes)},
+            "roofline": rf,
+        }
+        print(json.dumps(out), flush=True)
+    finally:
+        g.close()
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the C4 / C3 legs the default run adds under `secondary`")
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ  # under torch.distributed.run (also with N = 1)
+    if args.gpus > 1 and not launched:
+        return run_group(args)   # plain invocation: the single-process design of SURVEY 8(e); nothing is re-executed
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d, or plainly (no launcher) for the single-process group" % (args.gpus, world, args.gpus))
+
+    import torch
+    distributed = world > 1
+    dist = None
+    if distributed or launched:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    env = dict(dist=dist, distributed=distributed, rank=rank, world=world, local_rank=local_rank)
+
+    out = run_torch(args.config, args.steps, args.warmup, env)
+    if rank == 0 and world == 1 and args.config == "c2" and not args.no_secondary:
+        # the configurations where the roofline question lives, timed in the same (driver-witnessed) run: same method, fewer steps
+        sec = {}
+        for name, k, wu in SECONDARY:
+            try:
+                s = run_torch(name, k, wu, env)
+                sec[name] = {"value": s["value"], "unit": s["unit"], "ms_per_step": s["ms_per_step"], "steps": k, "warmup": wu,
+                             "kernel_alone_ms": s["roofline"]["kernel_alone_ms"], "workload": s["config"]["workload"], "kernel": s["config"]["kernel"],
+                             "rays_per_step": s["config"]["rays_per_step"], "roofline": s["roofline"]}
+            except Exception as e:   # a secondary leg never takes the headline down with it
+                sec[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        out["secondary"] = sec
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config)
         print(json.dumps(out), flush=True)
-    r.close()
     if distributed or launched:
         dist.barrier()
         dist.destroy_process_group()

@@ -200,8 +200,11 @@ TRG_API int trg_fence_wait(trg_ctx *ctx, int slot);
 
 /* --- multi-GPU (the reference is single-device): one process, one context per device, frames sharded by contiguous ROW
  *     BANDS, one RCCL exchange per frame over xGMI.  Device g of G renders rows [g*B, min(h, (g+1)*B)), B = ceil(h / G), into its
- *     slice of a full-frame buffer (padded to G*B rows, so that the in-place all-gather is exact for any height).  One host thread
- *     per context drives the launches.  A group of one device needs no RCCL (it is loaded with dlopen for G > 1). */
+ *     slice of a full-frame buffer (padded to G*B rows, so that the in-place all-gather is exact for any height).  One PERSISTENT host
+ *     thread per context drives the launches (started at create, handed each call through a condition variable); a host-built scene
+ *     is built once and uploaded to every device.  A group of one device needs no RCCL (it is loaded with dlopen for G > 1) and no thread.
+ *     NOT YET RUN ON MORE THAN ONE DEVICE: the development pool has single-GPU boxes, so n > 1 (ncclCommInitAll, the exchange) is
+ *     covered by code review and the CPU rehearsals of tests/test_dist_gloo.py only. */
 typedef struct trg_group trg_group;
 enum trg_gather {
     TRG_GATHER_NONE = 0,  /* every device keeps only its own band */
@@ -216,6 +219,8 @@ TRG_API int trg_group_size(trg_group *g);
 TRG_API trg_ctx *trg_group_ctx(trg_group *g, int rank); /* the context of one device (options, stats); owned by the group */
 TRG_API int trg_group_load_scene(trg_group *g, const float *positions3, const float *normals3, const float *colors3, const uint32_t *indices,
                                  const uint32_t *material_ids, uint32_t n_verts, uint32_t n_tris); /* replicated on every device */
+TRG_API int trg_group_load_textures(trg_group *g, const float *uv2, const uint32_t *texture_ids, uint32_t n_tris, const uint8_t *const *images_rgba8,
+                                    const uint32_t *widths, const uint32_t *heights, uint32_t n_textures); /* trg_load_textures on every device */
 TRG_API int trg_group_set_uniforms(trg_group *g, const trg_uniforms *u);
 TRG_API int trg_group_set_pixel_offsets_seed(trg_group *g, uint32_t seed);
 TRG_API int trg_group_set_option(trg_group *g, int option, int64_t value);
@@ -223,6 +228,9 @@ TRG_API int trg_group_set_option(trg_group *g, int option, int64_t value);
  * render on its stream; trg_group_sync / trg_group_read_accum wait for it) */
 TRG_API int trg_group_render(trg_group *g, uint32_t frameIndexBegin, uint32_t spp, uint32_t bounces, int gather, int root);
 TRG_API int trg_group_sync(trg_group *g);
+/* frames in flight for a group (MetalRenderer.mm:33,377,385-387): trg_fence_record / trg_fence_wait on every device's stream */
+TRG_API int trg_group_fence_record(trg_group *g, int slot);
+TRG_API int trg_group_fence_wait(trg_group *g, int slot);
 TRG_API int trg_group_read_accum(trg_group *g, int rank, float *rgba); /* width*height*4 floats of device `rank`'s frame buffer */
 TRG_API int trg_group_get_stats(trg_group *g, trg_stats *out);         /* ray counters summed over the devices, times of the slowest one */
 

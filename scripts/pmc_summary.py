@@ -11,6 +11,8 @@ import sys
 out = sys.argv[1]
 cfgs = sys.argv[2:] or ["c2", "c4"]
 import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from toyraygun_amd.srchash import kernel_source_hash
 commit = os.environ.get("TRG_COMMIT", "")
 if not commit:
     try:
@@ -63,7 +65,7 @@ for cfg in cfgs:
         fetch = 2.0 * fetch_raw
         write = c.get("WRITE_SIZE", 0.0) * 1024.0
         dram32 = c.get("TCC_EA0_RDREQ_DRAM_32B_sum")
-        rec = {"kernel": kname, "commit": commit,
+        rec = {"kernel": kname, "commit": commit, "kernel_source_hash": kernel_source_hash(),
                "valu_insts_per_launch": c.get("SQ_INSTS_VALU"), "salu_insts_per_launch": c.get("SQ_INSTS_SALU"), "lds_insts_per_launch": c.get("SQ_INSTS_LDS"),
                "lanes_active_per_valu_inst": (c["SQ_THREAD_CYCLES_VALU"] / c["SQ_INSTS_VALU"]) if c.get("SQ_THREAD_CYCLES_VALU") and c.get("SQ_INSTS_VALU") else None,
                "fetch_bytes": fetch, "fetch_size_raw_bytes": fetch_raw, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
@@ -73,7 +75,7 @@ for cfg in cfgs:
                "tcc_hit": c.get("TCC_HIT_sum"), "tcc_miss": c.get("TCC_MISS_sum"), "ta_busy_avr": c.get("TA_BUSY_avr"), "gui_active": c.get("GRBM_GUI_ACTIVE"),
                "alone_mean_ms": summary[cfg].get("launches", {}).get("alone_mean_ms"),
                "source": "scripts/profile_round.sh at commit %s: one rocprofv3 --pmc pass per counter group of `python3 bench.py%s`, per-launch means; "
-                         "fetch_bytes = 2 x FETCH_SIZE x 1024 (gfx950 counts each 128-byte request as 64: profiles/%s/fetch_calibration.md), write_bytes = WRITE_SIZE x 1024" % (commit, "" if cfg == "c2" else " --config " + cfg, "r02")}
+                         "fetch_bytes = 2 x FETCH_SIZE x 1024 (gfx950 counts each 128-byte request as 64: profiles/%s/fetch_calibration.md), write_bytes = WRITE_SIZE x 1024" % (commit, " --no-secondary" if cfg == "c2" else " --config " + cfg, "r02")}
         json.dump(rec, open(f"{out}/{cfg}_counters.json", "w"), indent=1)
         print(cfg, json.dumps({k: (round(v) if isinstance(v, float) and v > 100 else v) for k, v in rec.items() if k not in ("source",)}))
     for r in stats[:2]:

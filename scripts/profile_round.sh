@@ -11,7 +11,7 @@ export TMPDIR=/tmp
 export GPU_MAX_HW_QUEUES=16
 OUT=$PWD/gpurun_out/profiles; mkdir -p "$OUT"
 WHAT="${*:-c2 c4}"
-C2="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+C2="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary"
 C4="python3 bench.py --config c4 --steps 5 --warmup 1 --no-cpu-baseline"
 C3="python3 bench.py --config c3 --steps 3 --warmup 1 --no-cpu-baseline"
 run() { name=$1; shift; rm -rf "$OUT/$name"; rocprofv3 "$@" > "$OUT/$name.log" 2>&1 || { echo "FAILED $name"; tail -5 "$OUT/$name.log"; }; }

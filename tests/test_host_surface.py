@@ -511,3 +511,82 @@ def test_textured_mesh_buffers(built, tmp_path):
     assert np.array_equal(uvs[108:114], uv[[0, 1, 2, 0, 2, 3]])
     assert np.array_equal(uvs[150:153], np.array([[0.25, 0.5], [0.75, 0.5], [0.25, 1.5]], np.float32))
     assert len(imgs) == 1 and imgs[0].shape == (4, 4, 4)
+
+
+def test_device_group_worker_hand_off(tmp_path):
+    """The persistent host threads of trg_group_* (trg_workers.h): hand-off, completion, per-rank results, thread affinity, 3,000 rounds
+    on 1 / 2 / 3 / 8 workers -- plain and under ThreadSanitizer."""
+    src = os.path.join(ROOT, "tests", "helpers", "workers_test.cpp")
+    for name, flags in (("plain", ["-O2"]), ("tsan", ["-O1", "-g", "-fsanitize=thread"])):
+        exe = str(tmp_path / ("workers_" + name))
+        subprocess.check_call(["g++", "-std=c++17", "-pthread"] + flags + [src, "-o", exe])
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "workers ok" in r.stdout, (name, r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_one_band_rule(built):
+    """dist.band_rows (one process per GPU) and trg_band_rows (device groups behind the C ABI) are the same arithmetic: bands of
+    ceil(h / n) rows, the tail shorter or empty."""
+    from toyraygun_amd import capi
+    from toyraygun_amd.dist import band_rows
+    capi.load()
+    for h in (1, 2, 5, 17, 30, 34, 64, 135, 1079, 1080, 2160, 4321):
+        for n in (1, 2, 3, 4, 5, 7, 8, 16, 64):
+            rows = [band_rows(h, n, r) for r in range(n)]
+            assert rows == [capi.band_rows(h, n, r) for r in range(n)], (h, n)
+            assert rows[0][0] == 0 and sum(k for _, k in rows) == h
+            B = -(-h // n)
+            assert all(k in (B, h - r0) or k == 0 for r0, k in rows)
+
+
+def test_bench_runs_plainly_with_several_gpus(built, monkeypatch, capsys):
+    """`python bench.py --gpus 2` WITHOUT a launcher must not die in argument handling (the driver's scaling run invokes it like
+    that): it takes the single-process device group (trg_group_*).  Rehearsed with a stand-in for the group so that no GPU is needed:
+    the JSON line, its sharding description, per-rank ray counts and the separated gather time are produced; too few devices is a
+    clear error with a non-zero exit."""
+    import importlib
+    import json
+    import torch
+    from toyraygun_amd import capi
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    calls = []
+
+    class FakeGroup:
+        def __init__(self, devices, w, h):
+            self.n, self.w, self.h = len(devices), w, h
+            calls.append(("create", list(devices), w, h))
+        def load_scene(self, *a): calls.append(("scene", len(a[4])))
+        def set_uniforms(self, u): pass
+        def set_pixel_offsets_seed(self, seed=0): pass
+        def set_option(self, o, v): calls.append(("opt", o, v))
+        def render(self, f0, spp, b, gather=capi.GATHER_ALL, root=0): calls.append(("render", gather))
+        def sync(self): pass
+        def stats(self):
+            st = capi.Stats()
+            st.primary_rays, st.bounce_rays, st.shadow_rays, st.shaded_hits = 1000, 500, 700, 600
+            st.node_fetches, st.tri_tests, st.wave_node_iters, st.scene_in_lds, st.scene_bytes, st.last_render_ms = 9000, 3000, 100, 1, 9900, 0.5
+            return st
+        def rank_rays(self): return [1100, 1100]
+        def close(self): calls.append(("close",))
+
+    monkeypatch.setattr(capi, "Group", FakeGroup)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    for k in ("RANK", "WORLD_SIZE", "MASTER_PORT", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    bench.main(["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
+    line = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0 and out["scaling"] == "strong" and out["unit"] == "Mrays/s"
+    assert "single process" in out["config"]["sharding"] and out["config"]["per_rank_rays_per_step"] == [1100, 1100]
+    assert out["config"]["gather_ms_per_step"] >= 0 and "bound" in out["roofline"]   # (the stand-in renders in no time: its rates mean nothing)
+    assert ("create", [0, 1], 1920, 1080) in calls and ("close",) in calls
+    assert sum(1 for c in calls if c == ("render", capi.GATHER_ALL)) == 1 + 3 and sum(1 for c in calls if c == ("render", capi.GATHER_NONE)) == 1 + 3
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(SystemExit) as e:
+        bench.main(["--gpus", "2", "--no-cpu-baseline"])
+    assert "only 1 GPU" in str(e.value)
+    monkeypatch.setenv("RANK", "0"); monkeypatch.setenv("MASTER_PORT", "1"); monkeypatch.setenv("WORLD_SIZE", "1")
+    with pytest.raises(SystemExit) as e:   # under a launcher the world size must match
+        bench.main(["--gpus", "2", "--no-cpu-baseline"])
+    assert "WORLD_SIZE=1" in str(e.value)

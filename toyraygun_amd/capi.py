@@ -90,11 +90,14 @@ _SYMBOLS = [
     ("trg_group_size", C.c_int, [_P]),
     ("trg_group_ctx", _P, [_P, C.c_int]),
     ("trg_group_load_scene", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint32, C.c_uint32]),
+    ("trg_group_load_textures", C.c_int, [_P, _P, _P, C.c_uint32, C.POINTER(_P), _P, _P, C.c_uint32]),
     ("trg_group_set_uniforms", C.c_int, [_P, C.POINTER(Uniforms)]),
     ("trg_group_set_pixel_offsets_seed", C.c_int, [_P, C.c_uint32]),
     ("trg_group_set_option", C.c_int, [_P, C.c_int, C.c_int64]),
     ("trg_group_render", C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int]),
     ("trg_group_sync", C.c_int, [_P]),
+    ("trg_group_fence_record", C.c_int, [_P, C.c_int]),
+    ("trg_group_fence_wait", C.c_int, [_P, C.c_int]),
     ("trg_group_read_accum", C.c_int, [_P, C.c_int, _P]),
     ("trg_group_get_stats", C.c_int, [_P, C.POINTER(Stats)]),
     ("trg_trace", C.c_int, [_P, _P, C.c_size_t, C.c_int, _P]),
@@ -346,6 +349,21 @@ class Group:
         mat = np.ascontiguousarray(material_ids, np.uint32).reshape(-1)
         self._chk(self.L.trg_group_load_scene(self.g, _ptr(pos), _ptr(nrm), _ptr(col), _ptr(idx), _ptr(mat), pos.shape[0], mat.shape[0]))
 
+    def load_textures(self, uvs, texture_ids, images):
+        uv = np.ascontiguousarray(uvs, np.float32).reshape(-1, 2)
+        ids = np.ascontiguousarray(texture_ids, np.uint32).reshape(-1)
+        imgs = [np.ascontiguousarray(im, np.uint8) for im in images]
+        ptrs = (_P * max(len(imgs), 1))(*[im.ctypes.data for im in imgs])
+        ws = np.array([im.shape[1] for im in imgs], np.uint32)
+        hs = np.array([im.shape[0] for im in imgs], np.uint32)
+        self._chk(self.L.trg_group_load_textures(self.g, _ptr(uv), _ptr(ids), ids.shape[0], ptrs, _ptr(ws), _ptr(hs), len(imgs)))
+
+    def fence_record(self, slot):
+        self._chk(self.L.trg_group_fence_record(self.g, slot))
+
+    def fence_wait(self, slot):
+        self._chk(self.L.trg_group_fence_wait(self.g, slot))
+
     def set_uniforms(self, u):
         if not isinstance(u, Uniforms):
             u = Uniforms.from_buffer_copy(bytes(u))
@@ -372,6 +390,17 @@ class Group:
         st = Stats()
         self._chk(self.L.trg_group_get_stats(self.g, C.byref(st)))
         return st
+
+    def rank_stats(self, rank):
+        """trg_get_stats of one device's context (trg_group_ctx)."""
+        st = Stats()
+        ctx = self.L.trg_group_ctx(self.g, rank)
+        if not ctx or self.L.trg_get_stats(ctx, C.byref(st)) != OK:
+            raise TrgError(ERR_INVALID, "trg_group_ctx / trg_get_stats failed for rank %d" % rank)
+        return st
+
+    def rank_rays(self):
+        return [int(self.rank_stats(r).rays) for r in range(self.n)]
 
 
 def debug_build_bvh(positions, indices, material_ids):

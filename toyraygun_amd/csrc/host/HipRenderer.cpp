@@ -118,14 +118,12 @@ void HipRenderer::loadScene(Scene *scene) {
             }
             ptrs.push_back(rgba[k].data()); ws.push_back((uint32_t)w); hs.push_back((uint32_t)h);
         }
-        const int n = m_group ? trg_group_size(m_group) : 1;
-        for (int r = 0; r < n; ++r) {
-            trg_ctx *c = m_group ? trg_group_ctx(m_group, r) : m_ctx;
-            if (trg_load_textures(c, uv.data(), ids.data(), nTris, ptrs.data(), ws.data(), hs.data(), (uint32_t)ptrs.size()) != TRG_OK) {
-                printf("HipRenderer: %s\n", trg_last_error(c));
-                m_sceneLoaded = false;
-                return;
-            }
+        const int rc = m_group ? trg_group_load_textures(m_group, uv.data(), ids.data(), nTris, ptrs.data(), ws.data(), hs.data(), (uint32_t)ptrs.size())
+                               : trg_load_textures(m_ctx, uv.data(), ids.data(), nTris, ptrs.data(), ws.data(), hs.data(), (uint32_t)ptrs.size());
+        if (rc != TRG_OK) {
+            printf("HipRenderer: %s\n", m_group ? trg_group_last_error(m_group) : trg_last_error(m_ctx));
+            m_sceneLoaded = false;
+            return;
         }
     }
 }
@@ -157,9 +155,11 @@ bool HipRenderer::flush() {
     if (!m_sceneLoaded) return false;
     static_assert(sizeof(Uniforms) == sizeof(trg_uniforms), "Uniforms / trg_uniforms layout mismatch");
     const int slot = (int)(m_launches % (unsigned int)kFramesInFlight);
-    if (m_group) {   // row bands over the devices, gathered on the first one (which presents)
-        if (trg_group_set_uniforms(m_group, reinterpret_cast<const trg_uniforms *>(&m_pendingUniforms)) != TRG_OK ||
-            trg_group_render(m_group, (uint32_t)m_pendingFirst, frames, m_bounces, TRG_GATHER_ROOT, 0) != TRG_OK) {
+    if (m_group) {   // row bands over the devices, gathered on the first one (which presents); the same bound on launches in flight
+        if (trg_group_fence_wait(m_group, slot) != TRG_OK ||
+            trg_group_set_uniforms(m_group, reinterpret_cast<const trg_uniforms *>(&m_pendingUniforms)) != TRG_OK ||
+            trg_group_render(m_group, (uint32_t)m_pendingFirst, frames, m_bounces, TRG_GATHER_ROOT, 0) != TRG_OK ||
+            trg_group_fence_record(m_group, slot) != TRG_OK) {
             printf("HipRenderer: %s\n", trg_group_last_error(m_group));
             return false;
         }

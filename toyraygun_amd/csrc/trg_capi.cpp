@@ -16,6 +16,7 @@
 #include "bvh_build.h"
 #include "q4node.h"
 #include "trg_build.h"
+#include "trg_internal.h"
 #include "trg_kernels.h"
 
 using namespace trg;
@@ -406,7 +407,18 @@ static int render_wavefront(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint
 }
 
 
-extern "C" void *trg_internal_stream(trg_ctx *c) { return c ? (void *)c->stream : nullptr; }   // for trg_group.cpp; hidden visibility
+namespace trg {
+struct HostScene {
+    std::vector<unsigned char> blob;   // the image of the device allocation (plan_scene_layout)
+    SceneDesc sc{};                    // offsets; sc.blob is filled in per context
+    uint32_t bvh_nodes = 0, bvh_depth = 0, bvh_leaves = 0, bvh_nodes4 = 0, bvh_depth4 = 0;
+    double build_ms = 0.0;
+};
+int ctx_gpu_build_option(const trg_ctx *c) { return c ? c->opt_gpu_build : 0; }
+void *ctx_current_stream(trg_ctx *c) { return c ? (void *)c->stream : nullptr; }
+int ctx_device(const trg_ctx *c) { return c ? c->device : -1; }
+void host_scene_free(HostScene *hs) { delete hs; }
+}  // namespace trg
 
 extern "C" {
 
@@ -470,31 +482,35 @@ void trg_destroy(trg_ctx *c) {
     delete c;
 }
 
-int trg_load_scene(trg_ctx *c, const float *pos, const float *nrm, const float *col, const uint32_t *idx,
-                   const uint32_t *mat, uint32_t n_verts, uint32_t n_tris) {
-    if (!c) return TRG_ERR_INVALID;
+}  // extern "C" (reopened below)
+
+// argument checks shared by trg_load_scene and host_scene_build
+static int check_scene_args(trg_ctx *c, const float *pos, const float *nrm, const float *col, const uint32_t *idx, const uint32_t *mat, uint32_t n_verts, uint32_t n_tris) {
     if (n_tris && (!pos || !nrm || !col || !idx || !mat)) return fail(c, TRG_ERR_INVALID, "trg_load_scene: null buffer");
     if (n_tris >= (1u << 28)) return fail(c, TRG_ERR_RANGE, "trg_load_scene: too many triangles (%u)", n_tris);
     for (size_t i = 0; i < (size_t)n_tris * 3; ++i)
         if (idx[i] >= n_verts) return fail(c, TRG_ERR_INVALID, "trg_load_scene: index %u out of range (%u vertices) at %zu", idx[i], n_verts, i);
-    {   // refuse a scene that cannot fit the 32-bit blob offsets before anything is built, allocated or copied
-        SceneDesc probe{};
-        uint64_t least = 0;
-        if (!plan_scene_layout(0, 64u, 0, 0, false, 0, n_tris, probe, least))
-            return fail(c, TRG_ERR_RANGE, "trg_load_scene: %u triangles need at least %llu B on the device (limit 4 GiB)", n_tris, (unsigned long long)least);
-    }
-    HIPCHK(c, hipSetDevice(c->device));
-    if (c->tex_mem) {   // textures belong to the scene they were loaded for
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        (void)hipFree(c->tex_mem); c->tex_mem = nullptr; c->tex = TexDesc{};
-    }
-    if (c->opt_gpu_build && n_tris >= 2) return load_scene_gpu_build(c, pos, nrm, col, idx, mat, n_verts, n_tris);
+    // refuse a scene that cannot fit the 32-bit blob offsets before anything is built, allocated or copied
+    SceneDesc probe{};
+    uint64_t least = 0;
+    if (!plan_scene_layout(0, 64u, 0, 0, false, 0, n_tris, probe, least))
+        return fail(c, TRG_ERR_RANGE, "trg_load_scene: %u triangles need at least %llu B on the device (limit 4 GiB)", n_tris, (unsigned long long)least);
+    return TRG_OK;
+}
 
+namespace trg {
+// Host SAH build + the image of the device blob.  No device work: a device group calls this once and uploads to every context.
+int host_scene_build(trg_ctx *c, const float *pos, const float *nrm, const float *col, const uint32_t *idx, const uint32_t *mat, uint32_t n_verts,
+                     uint32_t n_tris, HostScene **out) {
+    if (!c || !out) return TRG_ERR_INVALID;
+    *out = nullptr;
+    if (int rc = check_scene_args(c, pos, nrm, col, idx, mat, n_verts, n_tris)) return rc;
+    HostScene *hs = new (std::nothrow) HostScene;
+    if (!hs) return fail(c, TRG_ERR_NOMEM, "trg_load_scene: out of host memory");
     const auto host_t0 = std::chrono::steady_clock::now();
     Bvh bvh;
     build_bvh(pos, idx, mat, n_tris, bvh);
-    c->last_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
-    c->gpu_built = false;
+    hs->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
 
     // Positions go through the index buffer (MPS vertexBuffer + indexBuffer, MetalRenderer.mm:274-275);
     // normals and colours are read as attributes[triangle*3 + j], NOT through the index buffer
@@ -511,9 +527,12 @@ int trg_load_scene(trg_ctx *c, const float *pos, const float *nrm, const float *
     const uint32_t node_bytes = kLdsNodeBytes;
     sc.n_nodes4 = bvh.n_nodes4;
     uint64_t total = 0;
-    if (!plan_scene_layout(sc.n_nodes, node_bytes, lds_candidate ? nt_rec : 0u, lds_candidate ? attr_tris : 0u, lds_candidate, sc.n_nodes4, nt_rec, sc, total))
+    if (!plan_scene_layout(sc.n_nodes, node_bytes, lds_candidate ? nt_rec : 0u, lds_candidate ? attr_tris : 0u, lds_candidate, sc.n_nodes4, nt_rec, sc, total)) {
+        delete hs;
         return fail(c, TRG_ERR_RANGE, "trg_load_scene: scene needs %llu B on the device (limit 4 GiB)", (unsigned long long)total);
-    std::vector<unsigned char> host(sc.blob_bytes, 0);
+    }
+    std::vector<unsigned char> &host = hs->blob;
+    host.assign(sc.blob_bytes, 0);
     if (sc.n_nodes && lds_candidate && kWideLds) {
         // sign-ordered 4-wide LDS nodes (trav_node4_step_lds): per axis [lo x4 | hi x4 | lo x4] = 48 bytes, so that a 32-byte read at
         // +0 gives (near, far) for a positive direction and at +16 for a negative one; then the four children (inner: byte offset
@@ -582,18 +601,54 @@ int trg_load_scene(trg_ctx *c, const float *pos, const float *nrm, const float *
     }
     if (sc.n_nodes4) memcpy(&host[sc.off_nodes4], bvh.nodes4q.data(), (size_t)sc.n_nodes4 * kQ4NodeBytes);
 
+    hs->sc = sc;
+    hs->bvh_nodes = bvh.n_nodes; hs->bvh_depth = bvh.depth; hs->bvh_leaves = bvh.n_leaves;
+    hs->bvh_nodes4 = bvh.n_nodes4; hs->bvh_depth4 = bvh.depth4;
+    *out = hs;
+    return TRG_OK;
+}
+
+int host_scene_upload(trg_ctx *c, const HostScene *hs) {
+    if (!c || !hs) return TRG_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->tex_mem) { (void)hipFree(c->tex_mem); c->tex_mem = nullptr; c->tex = TexDesc{}; }   // textures belong to the scene they were loaded for
     if (c->blob) { (void)hipFree(c->blob); c->blob = nullptr; c->scene_loaded = false; }
+    SceneDesc sc = hs->sc;
     hipError_t e = hipMalloc((void **)&c->blob, sc.blob_bytes);
     if (e != hipSuccess) return fail(c, TRG_ERR_NOMEM, "trg_load_scene: hipMalloc(%u) failed: %s", sc.blob_bytes, hipGetErrorString(e));
-    HIPCHK(c, hipMemcpy(c->blob, host.data(), sc.blob_bytes, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->blob, hs->blob.data(), sc.blob_bytes, hipMemcpyHostToDevice));
     sc.blob = c->blob;
     c->sc = sc;
-    c->bvh_nodes = bvh.n_nodes; c->bvh_depth = bvh.depth; c->bvh_leaves = bvh.n_leaves;
-    c->bvh_nodes4 = bvh.n_nodes4; c->bvh_depth4 = bvh.depth4;
+    c->last_build_ms = hs->build_ms;
+    c->gpu_built = false;
+    c->bvh_nodes = hs->bvh_nodes; c->bvh_depth = hs->bvh_depth; c->bvh_leaves = hs->bvh_leaves;
+    c->bvh_nodes4 = hs->bvh_nodes4; c->bvh_depth4 = hs->bvh_depth4;
     c->scene_loaded = true;
     LdsPlan plan;
     return plan_lds(c, plan, c->opt_kernel == TRG_KERNEL_POOL);
+}
+}  // namespace trg
+
+extern "C" {
+
+int trg_load_scene(trg_ctx *c, const float *pos, const float *nrm, const float *col, const uint32_t *idx,
+                   const uint32_t *mat, uint32_t n_verts, uint32_t n_tris) {
+    if (!c) return TRG_ERR_INVALID;
+    if (c->opt_gpu_build && n_tris >= 2) {
+        if (int rc = check_scene_args(c, pos, nrm, col, idx, mat, n_verts, n_tris)) return rc;
+        HIPCHK(c, hipSetDevice(c->device));
+        if (c->tex_mem) {   // textures belong to the scene they were loaded for
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            (void)hipFree(c->tex_mem); c->tex_mem = nullptr; c->tex = TexDesc{};
+        }
+        return load_scene_gpu_build(c, pos, nrm, col, idx, mat, n_verts, n_tris);
+    }
+    HostScene *hs = nullptr;
+    if (int rc = host_scene_build(c, pos, nrm, col, idx, mat, n_verts, n_tris, &hs)) return rc;
+    const int rc = host_scene_upload(c, hs);
+    host_scene_free(hs);
+    return rc;
 }
 
 int trg_load_textures(trg_ctx *c, const float *uv2, const uint32_t *texture_ids, uint32_t n_tris, const uint8_t *const *images, const uint32_t *widths,

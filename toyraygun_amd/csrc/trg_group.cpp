@@ -1,5 +1,5 @@
 // trg_group.cpp -- multi-GPU rendering behind the C ABI (include/trg.h, "trg_group_*"): one process, one context per device,
-// one host thread per context while a frame is enqueued, RCCL over xGMI for the one exchange a frame needs.
+// one PERSISTENT host thread per context (trg_workers.h), RCCL over xGMI for the one exchange a frame needs.
 //
 // pixels are independent (every quantity is a function of (x, y, frameIndex); the scene is read-only and
 // replicated), so a frame shards by contiguous ROW BANDS: device g renders rows [g*B, min(h, (g+1)*B)), B = ceil(h / G), all its
@@ -18,13 +18,13 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "../../include/trg.h"
-
-extern "C" void *trg_internal_stream(trg_ctx *c);   // trg_capi.cpp (not exported)
+#include "trg_internal.h"
+#include "trg_workers.h"
 
 namespace {
 struct Rccl {
@@ -67,6 +67,7 @@ struct trg_group {
     std::vector<trg_ctx *> ctx;
     std::vector<float *> frame;                // per device: n * band rows x w float4 (padded full frame), bound as its accumulation buffer
     std::vector<ncclComm_t> comm;
+    std::unique_ptr<trg::DeviceWorkers> workers;   // one persistent host thread per device (none for a group of one)
     std::string err;
 };
 
@@ -80,20 +81,12 @@ static int gfail(trg_group *g, int code, const char *fmt, ...) {
     return code;
 }
 
-// run f(rank) on one host thread per device and collect the first failure
+// run f(rank) on every device's own host thread at the same time and collect the first failure
 template <typename F>
 static int for_each_device(trg_group *g, F f) {
-    std::vector<int> rc(g->n, TRG_OK);
-    if (g->n == 1) {
-        rc[0] = f(0);
-    } else {
-        std::vector<std::thread> th;
-        th.reserve(g->n);
-        for (int r = 0; r < g->n; ++r) th.emplace_back([&, r] { rc[r] = f(r); });
-        for (auto &t : th) t.join();
-    }
-    for (int r = 0; r < g->n; ++r)
-        if (rc[r] != TRG_OK) return gfail(g, rc[r], "device %d (rank %d): %s", g->devices[r], r, trg_last_error(g->ctx[r]));
+    g->workers->run([&](int r) { return f(r); });
+    const int r = g->workers->first_failure();
+    if (r >= 0) return gfail(g, g->workers->rc(r), "device %d (rank %d): %s", g->devices[r], r, trg_last_error(g->ctx[r]));
     return TRG_OK;
 }
 
@@ -113,6 +106,7 @@ trg_ctx *trg_group_ctx(trg_group *g, int rank) { return (g && rank >= 0 && rank 
 
 void trg_group_destroy(trg_group *g) {
     if (!g) return;
+    g->workers.reset();   // joins the host threads (none of them has work: every entry point waits for its jobs)
     for (int r = 0; r < g->n; ++r) {
         if (r < (int)g->ctx.size() && g->ctx[r]) { (void)trg_sync(g->ctx[r]); }
     }
@@ -162,6 +156,9 @@ int trg_group_create(trg_group **out, const int *devices, int n, uint32_t width,
             return TRG_ERR_DEVICE;
         }
     }
+    // the devices' host threads: started once, each bound to its device; a frame is handed to them through a condition variable
+    g->workers.reset(new (std::nothrow) trg::DeviceWorkers(n, [g](int r) { (void)hipSetDevice(g->devices[r]); }));
+    if (!g->workers) { gfail(nullptr, TRG_ERR_NOMEM, "trg_group_create: out of host memory"); trg_group_destroy(g); return TRG_ERR_NOMEM; }
     *out = g;
     return TRG_OK;
 }
@@ -169,7 +166,21 @@ int trg_group_create(trg_group **out, const int *devices, int n, uint32_t width,
 int trg_group_load_scene(trg_group *g, const float *positions3, const float *normals3, const float *colors3, const uint32_t *indices,
                          const uint32_t *material_ids, uint32_t n_verts, uint32_t n_tris) {
     if (!g) return TRG_ERR_INVALID;
-    return for_each_device(g, [&](int r) { return trg_load_scene(g->ctx[r], positions3, normals3, colors3, indices, material_ids, n_verts, n_tris); });
+    // a device build (TRG_OPT_GPU_BUILD) runs on every device, at the same time; the host build runs ONCE here and its blob is
+    // uploaded to every device in parallel (round 2 ran the same SAH build on all N threads)
+    if (trg::ctx_gpu_build_option(g->ctx[0]) && n_tris >= 2)
+        return for_each_device(g, [&](int r) { return trg_load_scene(g->ctx[r], positions3, normals3, colors3, indices, material_ids, n_verts, n_tris); });
+    trg::HostScene *hs = nullptr;
+    if (int rc = trg::host_scene_build(g->ctx[0], positions3, normals3, colors3, indices, material_ids, n_verts, n_tris, &hs))
+        return gfail(g, rc, "%s", trg_last_error(g->ctx[0]));
+    const int rc = for_each_device(g, [&](int r) { return trg::host_scene_upload(g->ctx[r], hs); });
+    trg::host_scene_free(hs);
+    return rc;
+}
+int trg_group_load_textures(trg_group *g, const float *uv2, const uint32_t *texture_ids, uint32_t n_tris, const uint8_t *const *images_rgba8,
+                            const uint32_t *widths, const uint32_t *heights, uint32_t n_textures) {
+    if (!g) return TRG_ERR_INVALID;
+    return for_each_device(g, [&](int r) { return trg_load_textures(g->ctx[r], uv2, texture_ids, n_tris, images_rgba8, widths, heights, n_textures); });
 }
 int trg_group_set_uniforms(trg_group *g, const trg_uniforms *u) {
     if (!g) return TRG_ERR_INVALID;
@@ -200,11 +211,12 @@ int trg_group_render(trg_group *g, uint32_t frameIndexBegin, uint32_t spp, uint3
         }))
         return rc;
     if (g->n == 1 || gather == TRG_GATHER_NONE) return TRG_OK;
-    // the one exchange of the frame, enqueued behind each device's render on its own stream
+    // the one exchange of the frame, enqueued behind each device's render: on the stream that render was launched on (the context's
+    // current stream -- trg_set_stream's if the caller set one through trg_group_ctx, the context's own otherwise)
     const size_t count = (size_t)g->band * g->w * 4u;   // floats per band
     ncclResult_t nr = g_rccl.GroupStart();
     for (int r = 0; r < g->n && nr == ncclSuccess; ++r) {
-        hipStream_t s = static_cast<hipStream_t>(trg_internal_stream(g->ctx[r]));
+        hipStream_t s = static_cast<hipStream_t>(trg::ctx_current_stream(g->ctx[r]));
         float *mine = g->frame[r] + (size_t)r * count;
         if (gather == TRG_GATHER_ALL) {
             nr = g_rccl.AllGather(mine, g->frame[r], count, ncclFloat, g->comm[r], s);   // in place: sendbuff = recvbuff + rank * count
@@ -224,6 +236,20 @@ int trg_group_render(trg_group *g, uint32_t frameIndexBegin, uint32_t spp, uint3
 int trg_group_sync(trg_group *g) {
     if (!g) return TRG_ERR_INVALID;
     return for_each_device(g, [&](int r) { return trg_sync(g->ctx[r]); });
+}
+
+// frames in flight (MetalRenderer.mm:33,377,385-387: a semaphore of three): a mark on EVERY device's stream, and the wait for all of them
+int trg_group_fence_record(trg_group *g, int slot) {
+    if (!g) return TRG_ERR_INVALID;
+    for (int r = 0; r < g->n; ++r)
+        if (int rc = trg_fence_record(g->ctx[r], slot)) return gfail(g, rc, "rank %d: %s", r, trg_last_error(g->ctx[r]));
+    return TRG_OK;
+}
+int trg_group_fence_wait(trg_group *g, int slot) {
+    if (!g) return TRG_ERR_INVALID;
+    for (int r = 0; r < g->n; ++r)
+        if (int rc = trg_fence_wait(g->ctx[r], slot)) return gfail(g, rc, "rank %d: %s", r, trg_last_error(g->ctx[r]));
+    return TRG_OK;
 }
 
 int trg_group_read_accum(trg_group *g, int rank, float *rgba) {

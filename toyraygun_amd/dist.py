@@ -1,7 +1,7 @@
 """Multi-GPU rendering: one process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).
 
 Pixels are independent, so the frame is split into contiguous ROW BANDS: rank g renders rows
-[g*h/G, (g+1)*h/G) for all its samples with no communication, writing straight into its slice of a
+[g*B, min(h, (g+1)*B)), B = ceil(h / G) (band_rows: the rule of trg_band_rows), for all its samples with no communication, writing straight into its slice of a
 full-frame device tensor; ONE all-gather at the end lands every band in place on every rank (disjoint
 pixels: no reduction, no change of floating-point summation order).  The reference has no multi-GPU
 code at all; this is new.
@@ -29,9 +29,10 @@ _INPLACE_OK = True
 
 
 def band_rows(height, world, rank):
-    """Rows [row0, row0+rows) of rank `rank` (the last bands absorb the remainder)."""
-    row0 = (height * rank) // world
-    row1 = (height * (rank + 1)) // world
+    """Rows [row0, row0+rows) of rank `rank`: bands of ceil(height / world) rows, the last one(s) shorter or empty -- the ONE band
+    rule of the project (trg_band_rows in include/trg.h does the same arithmetic; tests assert they agree)."""
+    band = -(-height // world) if world else height
+    row0, row1 = min(height, band * rank), min(height, band * (rank + 1))
     return row0, row1 - row0
 
 
