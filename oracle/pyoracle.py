@@ -300,5 +300,13 @@ def set_trig_mode(mode):
     lib().orc_set_trig_mode(mode)
 
 
+VAR_BOUNCE_SEES_LIGHT, VAR_LIGHT_NORMALISED = 1, 2
+
+
+def set_variant(flags):
+    """Negative controls of the radiometric screenshot pin (trg_oracle.h orc_set_variant); 0 = the reference's estimator."""
+    lib().orc_set_variant(int(flags))
+
+
 def num_threads():
     return int(lib().orc_num_threads())

@@ -38,6 +38,8 @@ static inline float saturatef(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 static int g_trig_mode = ORC_TRIG_LIBM;
 void orc_set_trig_mode(int mode) { g_trig_mode = mode; }
 int orc_get_trig_mode(void) { return g_trig_mode; }
+static int g_variant = 0;   /* negative controls of the radiometric screenshot pin (trg_oracle.h); 0 = the reference's estimator */
+void orc_set_variant(int flags) { g_variant = flags; }
 
 /* Portable sin/cos for phi in [0, 2*pi]: quadrant reduction with a 3-term Cody-Waite split of pi/2,
  * then odd/even minimax polynomials on [-pi/4, pi/4].  Plain IEEE ops only, fixed order; the HIP
@@ -498,6 +500,13 @@ void orc_sample_area_light(const orc_uniforms *u, const float r[2], const float 
     for (int a = 0; a < 3; ++a) c[a] *= k1;
     float k2 = saturatef(dot3(nrm, dir));
     for (int a = 0; a < 3; ++a) c[a] *= k2;
+    if (g_variant & ORC_VAR_LIGHT_NORMALISED) {   /* negative control only: area / pi, area of the quad = |2 right x 2 up| */
+        float cr[3] = { u->light_right[1] * u->light_up[2] - u->light_right[2] * u->light_up[1],
+                        u->light_right[2] * u->light_up[0] - u->light_right[0] * u->light_up[2],
+                        u->light_right[0] * u->light_up[1] - u->light_right[1] * u->light_up[0] };
+        float k3 = 4.0f * sqrtf(dot3(cr, cr)) / 3.14159265f;
+        for (int a = 0; a < 3; ++a) c[a] *= k3;
+    }
     color[0] = c[0]; color[1] = c[1]; color[2] = c[2];
     *dist = d;
 }
@@ -611,7 +620,7 @@ void orc_primary_hit(const orc_uniforms *u, orc_ray *rays, orc_ray *shadow_rays,
         for (int a = 0; a < 3; ++a) ray->origin[a] = P[a] + vn[a] * 1e-3f;
         for (int a = 0; a < 3; ++a) ray->direction[a] = ad[a];
         for (int a = 0; a < 3; ++a) ray->color[a] = color[a];
-        ray->mask = 1u; /* RAY_MASK_SECONDARY */
+        ray->mask = (g_variant & ORC_VAR_BOUNCE_SEES_LIGHT) ? 3u : 1u; /* RAY_MASK_SECONDARY (the variant: negative control only) */
         if (st) st->shaded_hits++;
     } else if (materialID == 2u) {
         float *o = &dst[(size_t)rayIdx * 4];

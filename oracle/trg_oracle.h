@@ -90,6 +90,13 @@ enum { ORC_TRIG_LIBM = 0, ORC_TRIG_PORTABLE = 1 };
  * ORC_TRIG_PORTABLE: a fixed polynomial written with plain IEEE ops only, which the HIP
  * kernel restates operation by operation, so that strict builds can be compared bit for bit. */
 void orc_set_trig_mode(int mode);
+/* NEGATIVE CONTROLS for tests/test_screenshot_pin.py (radiometric pin): estimators the reference's Metal backend does NOT implement.
+ * 0 (default) = Raytracing.metal / common.h as written.  ORC_VAR_BOUNCE_SEES_LIGHT: continuation rays keep RAY_MASK_PRIMARY, so they
+ * can hit the emissive quad (what the D3D12 shader allows, Raytracing.hlsl:227-228; Raytracing.metal:198 gives them mask 1).
+ * ORC_VAR_LIGHT_NORMALISED: the light sample is weighted by area / pi (a radiometrically normalised area light) instead of
+ * common.h:119-159's bare 1 / max(dist, 1e-3)^2. */
+enum { ORC_VAR_BOUNCE_SEES_LIGHT = 1, ORC_VAR_LIGHT_NORMALISED = 2 };
+void orc_set_variant(int flags);
 int  orc_get_trig_mode(void);
 
 /* ---- bx matrix functions (bodies absent from the reference tree; restated from the
