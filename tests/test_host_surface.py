@@ -590,3 +590,52 @@ def test_bench_runs_plainly_with_several_gpus(built, monkeypatch, capsys):
     with pytest.raises(SystemExit) as e:   # under a launcher the world size must match
         bench.main(["--gpus", "2", "--no-cpu-baseline"])
     assert "WORLD_SIZE=1" in str(e.value)
+
+
+def test_texture_images_follow_the_native_registration_order(built, tmp_path):
+    """ADVICE r02: Scene::textureID registers a texture when a face with texture coordinates first USES it.  An OBJ without `vt`
+    faces (or an unreadable file) given a texture registers nothing, so the image list handed to trg_load_textures must come from
+    the native list, not from the order Python saw the textures in -- otherwise texture id 1 would upload the wrong picture."""
+    from toyraygun_amd import host
+    s = host.Scene.cornell_box()
+    t1 = host.Texture(rgba=np.full((2, 2, 4), 11, np.uint8))
+    t2 = host.Texture(rgba=np.full((3, 3, 4), 22, np.uint8))
+    plain = tmp_path / "plain.obj"
+    plain.write_text("v 0 0 1\nv 1 0 1\nv 0 1 1\nf 1 2 3\n")                    # no vt: t1 is never registered
+    assert s.add_obj(plain, np.eye(4, dtype=np.float32), (1, 1, 1), 1, texture=t1) == 1
+    assert s.add_obj(tmp_path / "missing.obj", np.eye(4, dtype=np.float32), (1, 1, 1), 1, texture=t1) == -1
+    v = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0]], np.float32)
+    n = np.tile(np.array([[0, 0, 1]], np.float32), (3, 1))
+    uv = np.array([[0, 0], [1, 0], [1, 1]], np.float32)
+    s.add_textured_mesh(v, n, uv, [0, 1, 2], np.eye(4, dtype=np.float32), (1, 1, 1), 1, t2)   # native id 1 = t2
+    uvs, ids, imgs = s.texture_buffers()
+    assert ids[-1] == 1 and (ids[:-1] == 0).all()
+    assert len(imgs) == 1 and imgs[0].shape == (3, 3, 4) and (imgs[0] == 22).all()
+    s.add_textured_mesh(v, n, uv, [0, 1, 2], np.eye(4, dtype=np.float32), (1, 1, 1), 1, t1)   # now t1 becomes id 2
+    _, ids, imgs = s.texture_buffers()
+    assert ids[-1] == 2 and [im.shape[0] for im in imgs] == [3, 2]
+
+
+def test_png_header_cannot_size_the_decoder(built, tmp_path):
+    """a tiny file whose IHDR claims 32768 x 32768 x 4 must be refused without reserving 4 GiB (this library is built
+    without exceptions: a failed allocation would end the process), and a deflate stream longer than the header implies stops
+    at the implied size."""
+    import struct
+    import zlib
+    from toyraygun_amd import host
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+
+    def png(w, h, raw):
+        return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw, 9)) + chunk(b"IEND", b"")
+    (tmp_path / "huge.png").write_bytes(png(32768, 32768, b"\0" * 64))               # 4 GiB claimed, 64 bytes delivered
+    (tmp_path / "bomb.png").write_bytes(png(4, 4, b"\0" * (64 << 20)))               # 68 bytes implied, 64 MiB delivered
+    (tmp_path / "ok.png").write_bytes(png(4, 4, (b"\0" + b"\x10\x20\x30\xff" * 4) * 4))
+    for bad in ("huge.png",):
+        with pytest.raises(IOError):
+            host.Texture(path=tmp_path / bad)
+    with pytest.raises(IOError):
+        host.Texture(path=tmp_path / "bomb.png")
+    t = host.Texture(path=tmp_path / "ok.png")
+    assert t.info() == (4, 4, 4) and (t.pixels()[..., 0] == 0x10).all()

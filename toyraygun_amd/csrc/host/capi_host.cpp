@@ -88,6 +88,13 @@ void trh_scene_copy_textures(void *s, float *uv, uint32_t *ids) {
     for (size_t i = 0; i < nv * 2; ++i) uv[i] = i < sc->m_uvBuffer.size() ? sc->m_uvBuffer[i] : 0.0f;
     for (size_t i = 0; i < nt; ++i) ids[i] = i < sc->m_textureIDBuffer.size() ? sc->m_textureIDBuffer[i] : 0u;
 }
+// the textures the scene actually registered (Scene::textureID: on first use by a face with texture coordinates), in id order:
+// out[k] = the Texture of id k + 1.  Returns the count; out may be NULL / cap 0 to query it.
+unsigned int trh_scene_texture_handles(void *s, void **out, unsigned int cap) {
+    Scene *sc = static_cast<Scene *>(s);
+    for (size_t k = 0; k < sc->m_textures.size() && k < cap && out; ++k) out[k] = sc->m_textures[k];
+    return (unsigned int)sc->m_textures.size();
+}
 int trh_scene_add_obj(void *s, const char *path, const float *mtx16, const float *color3, unsigned int materialID) {
     float m[16];
     memcpy(m, mtx16, sizeof(m));

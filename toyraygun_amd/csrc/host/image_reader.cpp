@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 namespace trg_host {
@@ -58,7 +59,8 @@ struct Huffman {
     }
 };
 
-bool inflate_raw(const uint8_t *src, size_t n, std::vector<uint8_t> &out) {
+// `cap`: the decoder fails as soon as the output would exceed it (a few bytes of deflate can expand a thousandfold)
+bool inflate_raw(const uint8_t *src, size_t n, std::vector<uint8_t> &out, size_t cap) {
     static const uint16_t lbase[29] = { 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258 };
     static const uint16_t lext[29] = { 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0 };
     static const uint16_t dbase[30] = { 1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577 };
@@ -72,7 +74,7 @@ bool inflate_raw(const uint8_t *src, size_t n, std::vector<uint8_t> &out) {
             if (br.end - br.p < 4) return false;
             const uint32_t len = br.p[0] | (br.p[1] << 8), nlen = br.p[2] | (br.p[3] << 8);
             br.p += 4;
-            if ((len ^ 0xFFFFu) != nlen || (size_t)(br.end - br.p) < len) return false;
+            if ((len ^ 0xFFFFu) != nlen || (size_t)(br.end - br.p) < len || out.size() + len > cap) return false;
             out.insert(out.end(), br.p, br.p + len);
             br.p += len;
         } else if (type == 1 || type == 2) {
@@ -114,7 +116,7 @@ bool inflate_raw(const uint8_t *src, size_t n, std::vector<uint8_t> &out) {
             for (;;) {
                 const int sym = lit.decode(br);
                 if (sym < 0) return false;
-                if (sym < 256) { out.push_back((uint8_t)sym); continue; }
+                if (sym < 256) { if (out.size() >= cap) return false; out.push_back((uint8_t)sym); continue; }
                 if (sym == 256) break;
                 const int li = sym - 257;
                 if (li >= 29) return false;
@@ -122,7 +124,7 @@ bool inflate_raw(const uint8_t *src, size_t n, std::vector<uint8_t> &out) {
                 const int ds = dist.decode(br);
                 if (ds < 0 || ds >= 30) return false;
                 const size_t d = dbase[ds] + br.bits(dext[ds]);
-                if (br.bad || d > out.size()) return false;
+                if (br.bad || d > out.size() || out.size() + (size_t)len > cap) return false;
                 const size_t start = out.size() - d;
                 for (int k = 0; k < len; ++k) out.push_back(out[start + k]);
             }
@@ -161,11 +163,15 @@ uint8_t *decode_png(const std::vector<uint8_t> &file, int *w, int *h, int *chann
         pos += 12 + (size_t)len;
     }
     if (!ch || z.size() < 6) return nullptr;
+    // The header alone must not size anything: a 60-byte file can claim 32768 x 32768 x 4.  Deflate expands at most ~1032-fold, so the
+    // compressed size bounds what is reserved; the decoder stops at the size the header implies; and a picture over 1 GiB decoded is
+    // refused outright (this library is built without exceptions: a failed allocation would end the process, not the call).
+    const size_t stride = (size_t)width * ch, expected = (size_t)height * (stride + 1);
+    if (expected > ((size_t)1 << 30)) return nullptr;
     std::vector<uint8_t> raw;
-    raw.reserve((size_t)height * ((size_t)width * ch + 1));
-    if (!inflate_raw(z.data() + 2, z.size() - 2, raw)) return nullptr;   // 2-byte zlib header; the adler32 trailer is not checked
-    const size_t stride = (size_t)width * ch;
-    if (raw.size() < (size_t)height * (stride + 1)) return nullptr;
+    raw.reserve(std::min(expected, z.size() * 1032u + 64u));
+    if (!inflate_raw(z.data() + 2, z.size() - 2, raw, expected)) return nullptr;   // 2-byte zlib header; the adler32 trailer is not checked
+    if (raw.size() < expected) return nullptr;
     uint8_t *out = (uint8_t *)malloc((size_t)height * stride);
     if (!out) return nullptr;
     for (uint32_t y = 0; y < height; ++y) {

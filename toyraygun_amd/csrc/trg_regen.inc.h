@@ -63,7 +63,8 @@ TRG_DEV void regen_count(lds_int_t *wred, int k, bool pred) {
     if (n != 0u && lane_id() == 0u) wred[k] = wred[k] + (int)n;
 }
 
-static_assert(TRG_PARK_PATH, "render_regen_kernel keeps nine words of path state per thread in the LDS render_kernel parks its path in");
+static_assert(TRG_PARK_PATH && TRG_PARK_OFFSET, "render_regen_kernel uses all ten words per thread of the LDS render_kernel parks its path and its Halton offset in "
+                                               "(plan_lds_as: 40 bytes per thread): nine of path state, and waves 2 and 3 stage their log records in word [9]");
 template <bool COUNT>
 __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_kernel(const trg::RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

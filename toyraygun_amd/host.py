@@ -14,7 +14,7 @@ HOST_SO = os.path.join(capi.LIB_DIR, "libtoyraygun.so")
 _lib = None
 
 SYMBOL_NAMES = ["trh_scene_new", "trh_scene_cornell", "trh_scene_lattice", "trh_scene_free", "trh_scene_add", "trh_scene_add_mesh", "trh_scene_add_mesh_colors", "trh_scene_add_obj", "trh_texture_load", "trh_texture_from_rgba",
-                "trh_texture_info", "trh_texture_copy", "trh_texture_free", "trh_scene_add_textured_mesh", "trh_scene_add_obj_textured", "trh_scene_copy_textures",
+                "trh_texture_info", "trh_texture_copy", "trh_texture_free", "trh_scene_add_textured_mesh", "trh_scene_add_obj_textured", "trh_scene_copy_textures", "trh_scene_texture_handles",
                 "trh_scene_counts", "trh_scene_copy", "trh_mtx_srt", "trh_mtx_inverse", "trh_uniforms",
                 "trh_random_texture", "trh_run_app", "trh_async_camera_move", "trh_render_scene"]
 
@@ -46,6 +46,8 @@ def load():
         L.trh_scene_add_obj_textured.argtypes = [P, C.c_char_p, F, F, C.c_uint, P]
         L.trh_scene_add_obj_textured.restype = C.c_int
         L.trh_scene_copy_textures.argtypes = [P, F, F]
+        L.trh_scene_texture_handles.restype = C.c_uint
+        L.trh_scene_texture_handles.argtypes = [P, C.POINTER(C.c_void_p), C.c_uint]
         L.trh_scene_add_obj.argtypes = [P, C.c_char_p, F, F, C.c_uint]
         L.trh_scene_add_obj.restype = C.c_int
         L.trh_scene_counts.argtypes = [P, C.POINTER(C.c_uint)]
@@ -132,11 +134,13 @@ class Scene:
         nv = self.L.trh_scene_counts(self.h, C.byref(nt))
         uv, ids = np.zeros((nv, 2), np.float32), np.zeros(nt.value, np.uint32)
         self.L.trh_scene_copy_textures(self.h, uv.ctypes.data, ids.ctypes.data)
-        seen, imgs = [], []
-        for t in self._textures:
-            if t.h not in seen:
-                seen.append(t.h)
-                imgs.append(t.rgba())
+        # the image list follows the NATIVE registration order (Scene::textureID registers a texture when a face with texture
+        # coordinates first uses it -- an OBJ without `vt`, or an unreadable file, registers nothing), not the order Python saw them in
+        n = self.L.trh_scene_texture_handles(self.h, None, 0)
+        handles = (C.c_void_p * max(n, 1))()
+        self.L.trh_scene_texture_handles(self.h, handles, n)
+        by_handle = {int(t.h): t for t in self._textures}
+        imgs = [by_handle[int(handles[k])].rgba() for k in range(n)]
         return uv, ids, imgs
 
     def buffers(self):
