@@ -1,8 +1,11 @@
-"""C4 (1.02 M triangles, 1920 wide, 16 spp, 3 bounces) on row bands of a multi-GPU job / small windows: ms alone per schedule."""
+"""An HBM-resident lattice scene (default 44 = C4, 1.02 M triangles; python scripts/gpu_c4_bands.py 6 = 2,628 triangles, 12 = 20,772) at
+1920 wide, 16 spp, 3 bounces on row bands of a multi-GPU job / small windows: ms alone per schedule."""
 import sys; sys.path.insert(0, ".")
 from toyraygun_amd import capi, host
 W, H = 1920, 1080
-b = host.Scene.cornell_lattice(44).buffers()
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 44
+b = host.Scene.cornell_lattice(N).buffers()
+print("lattice %d: %d triangles" % (N, len(b["material_ids"])))
 c = capi.Context(W, H)
 c.load_scene(b["positions"], b["normals"], b["colors"], b["indices"], b["material_ids"])
 c.set_uniforms(host.uniforms(W, H)[0]); c.set_pixel_offsets_seed()

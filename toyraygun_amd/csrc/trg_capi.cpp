@@ -183,6 +183,9 @@ static bool plan_lds_as(const trg_ctx *c, LdsPlan &p, bool lds_scene, bool pool,
     // traversal; an LDS-resident scene has neither the room -- 8 workgroups of 20 KB per CU -- nor the need: it is spill-free)
     p.acc_off = 0;
     if (park && !p.lds_scene && !pool && !fp_slots) { p.acc_off = p.total; p.total += (uint32_t)kBlock * (TRG_PARK_PATH ? (TRG_PARK_OFFSET ? 40u : 36u) : 12u); }
+    // render_fp_kernel on an HBM-resident scene parks throughput, radiance and the Halton offset the same way (seven words per thread; its
+    // running average stays in the registers of the one wave per sub-tile that folds)
+    if (park && !p.lds_scene && !pool && fp_slots && TRG_PARK_PATH && TRG_PARK_OFFSET) { p.acc_off = p.total; p.total += (uint32_t)kBlock * 28u; }
     limit = (pool || fp_slots) ? 160u * 1024u : 64u * 1024u;  // above 64 KB the launcher opts in per kernel
     return p.total <= limit;
 }
@@ -210,6 +213,7 @@ static int plan_lds(trg_ctx *c, LdsPlan &p, bool pool = false, uint32_t fp_slots
 // resident sets (1/2, 1/4, 1/8 of a 1080p frame: -8 %, -18 %, -36 %) and lose above (full 1080p +1.6 %, 4K +9 %:
 // every workgroup stages the scene and folds once more per pixel).
 constexpr uint32_t kFpMaxRounds = 4;         // parked rounds per fold: 3 KB of LDS per round
+constexpr uint32_t kFpMaxRoundsHbm = 2;      // ... for a scene traversed from HBM (render_fp_kernel<false>: 6 waves/SIMD = 6 workgroups of 26 KB per CU)
 constexpr uint32_t kResidentGroups = 1536;   // 256 CUs x 6 workgroups of 4 waves (the HBM kernels' 6 waves/SIMD; LDS scenes: 8)
 static uint32_t choose_fsplit(const trg_ctx *c, uint32_t spp, uint32_t rows) {
     if (c->opt_fsplit == 1 || spp < 2) return 1u;
@@ -762,6 +766,10 @@ int trg_render(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces,
         if (plan_lds_quiet(c, rp) && !rp.lds_scene && rp.acc_off != 0u) { regen_lanes = fsplit; fsplit = 1u; }
     }
     uint32_t fp_rounds = fsplit > 1 ? std::min<uint32_t>((spp + fsplit - 1) / fsplit, kFpMaxRounds) : 0u;
+    if (fp_rounds > kFpMaxRoundsHbm) {   // a scene in HBM also keeps 12 KB of stack levels and 7 KB of parked path state in LDS: two rounds leave room for 6 workgroups per CU
+        LdsPlan probe;
+        if (plan_lds_quiet(c, probe) && !probe.lds_scene) fp_rounds = kFpMaxRoundsHbm;
+    }
     LdsPlan plan;
     if (fsplit > 1 && c->opt_fsplit == 0 && plan_lds(c, plan, false, fp_rounds) != TRG_OK) { fsplit = 1u; fp_rounds = 0u; }  // auto: no room to park
     if (int rc = plan_lds(c, plan, pool, fp_rounds)) return rc;

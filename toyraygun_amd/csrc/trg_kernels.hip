@@ -379,47 +379,63 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES : TRG_EXP_WA
 #ifndef TRG_EXP_WAVES_FP
 #define TRG_EXP_WAVES_FP 6   // its grids do not fill the chip anyway: 80 VGPRs without spills beats 8 waves by 1.5 %
 #endif
+#ifndef TRG_EXP_WAVES_FP_HBM
+#define TRG_EXP_WAVES_FP_HBM 6   // HBM scene: 79 VGPRs and no scratch with throughput / radiance / offset parked in LDS (round 2: 72 VGPRs, 31 spilled, 96 B/lane at 7)
+#endif
 template <bool LDS_SCENE, bool COUNT>
-__global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES_FP : TRG_EXP_WAVES_HBM) void render_fp_kernel(const trg::RenderParams p) {
+__global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES_FP : TRG_EXP_WAVES_FP_HBM) void render_fp_kernel(const trg::RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     SceneView sc = scene_view<LDS_SCENE>(p.sc, smem);
     sc.tex = p.tex;
     LdsStackT<trg::kBlock, !LDS_SCENE> stk;
     stk.set(smem, p.stack_off, p.stack.overflow, p.stack.klds);  // also writes the sentinel at level 0 of this thread's column
 
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // wave-uniform indices in SGPRs, the lane index re-read where it is needed (as render_kernel: pixel coordinates and indices must not
+    // live in VGPRs across the traversals)
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t F = p.fsplit, subt = trg::kWaves / F;   // frame lanes, sub-tiles per workgroup (F in {2,4})
     const uint32_t sub = wave % subt, fl = wave / subt;
     uint32_t bx, by;                                         // tile order as render_kernel
     if (!block_tile(p, blockIdx.x, bx, by)) return;
-    const uint32_t x = (bx * subt + sub) * 8u + (lane & 7);
-    const uint32_t y = p.row0 + by * 8u + (lane >> 3);
-    const bool valid = (x < p.u.width) && (y < p.row0 + p.rows) && (y < p.u.height);
-    const uint32_t pix = y * p.u.width + x;
+    const uint32_t x0 = (bx * subt + sub) * 8u, y0 = p.row0 + by * 8u;   // wave-uniform
+    bool valid;
+    uint32_t offset = 0u;
+    v4f *accum = reinterpret_cast<v4f *>(p.accum);
+    V3 acc = mk(0.0f, 0.0f, 0.0f);
+    // an HBM-resident scene parks throughput, radiance and the pixel's Halton offset in LDS while rays are traced (path_radiance), as
+    // render_kernel does: seven words per thread behind the parked radiances
+    constexpr bool PARK = !LDS_SCENE && TRG_PARK_PATH && TRG_PARK_OFFSET;
+    lds_float_t *path_park = PARK ? (lds_float_t *)(reinterpret_cast<float *>(smem + p.acc_off) + threadIdx.x) : nullptr;
+    {
+        const uint32_t lane = lane_id();
+        const uint32_t x = x0 + (lane & 7), y = y0 + (lane >> 3);
+        valid = (x < p.u.width) && (y < p.row0 + p.rows) && (y < p.u.height);
+        const uint32_t pix = y * p.u.width + x;
+        if (valid) offset = p.offsets[pix];
+        if (fl == 0 && valid && p.frame_begin > 0) { const v4f a = accum[pix]; acc = mk(a.x, a.y, a.z); }
+        if (PARK) { path_park[6 * trg::kBlock] = __int_as_float((int)offset); offset = 0u; }
+    }
 
     PathCounters pc; pc.primary = 0; pc.bounce = 0; pc.shadow = 0; pc.shaded = 0;
     Counters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.wnodes = 0; cnt.wtris = 0;
-
-    const uint32_t offset = valid ? p.offsets[pix] : 0u;
-    v4f *accum = reinterpret_cast<v4f *>(p.accum);
-    V3 acc = mk(0.0f, 0.0f, 0.0f);
-    if (fl == 0 && valid && p.frame_begin > 0) { const v4f a = accum[pix]; acc = mk(a.x, a.y, a.z); }
     const V3 light_color = mk(p.u.light_color[0], p.u.light_color[1], p.u.light_color[2]);
 
     // parked radiance: slot-major, component, then the 64*subt pixels of the workgroup (conflict-free rows)
     float *park = reinterpret_cast<float *>(smem + p.pool_off);
-    const uint32_t npx = 64u * subt, mypx = sub * 64u + lane;
+    const uint32_t npx = 64u * subt;
     const uint32_t chunk = p.fp_rounds * F;
     for (uint64_t rel = 0; rel < p.spp; rel += chunk) {
         for (uint32_t r = 0; r < p.fp_rounds; ++r) {
             const uint64_t i = rel + (uint64_t)r * F + fl;
             if (i >= p.spp) break;   // wave-uniform
-            const V3 rad = path_radiance<LDS_SCENE, COUNT>(p, sc, stk, x, y, offset, p.frame_begin + (uint32_t)i, valid, light_color, pc, cnt);
-            float *slot = park + (size_t)(r * F + fl) * 3u * npx + mypx;
+            const uint32_t lane_f = lane_id_opaque();
+            const V3 rad = path_radiance<LDS_SCENE, COUNT>(p, sc, stk, x0 + (lane_f & 7), y0 + (lane_f >> 3), offset, p.frame_begin + (uint32_t)i, valid, light_color, pc, cnt, path_park);
+            float *slot = park + (size_t)(r * F + fl) * 3u * npx + sub * 64u + lane_id_opaque();
             slot[0] = rad.x; slot[npx] = rad.y; slot[2u * npx] = rad.z;
         }
         __syncthreads();
         if (fl == 0) {
+            const uint32_t mypx = sub * 64u + lane_id_opaque();
             for (uint32_t s = 0; s < chunk && rel + s < p.spp; ++s) {
                 const uint32_t f = p.frame_begin + (uint32_t)(rel + s);
                 const float *slot = park + (size_t)s * 3u * npx + mypx;
@@ -437,9 +453,11 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES_FP : TRG_EXP
         }
         __syncthreads();
     }
+    const uint32_t lane = lane_id_opaque();
     if (fl == 0 && valid) {
+        const uint32_t x = x0 + (lane & 7), y = y0 + (lane >> 3);
         v4f outv; outv.x = acc.x; outv.y = acc.y; outv.z = acc.z; outv.w = 1.0f;
-        accum[pix] = outv;
+        accum[y * p.u.width + x] = outv;
     }
 
     uint32_t vals[8] = { pc.primary, pc.bounce, pc.shadow, pc.shaded, cnt.nodes, cnt.tris, cnt.wnodes, cnt.wtris };

@@ -44,49 +44,6 @@ TRG_DEV void path_segment_lds(const trg::RenderParams &p, const SceneView &sc, S
     }
 }
 
-// The same bounces [b0, b1) with the shadow ray of bounce b and the nearest-hit ray of bounce b + 1 walked back to back in ONE loop per
-// lane (traverse_pair): both come out of the same shading event and, from the second bounce on, both are incoherent, so the wavefront
-// pays max over lanes of (len_shadow + len_next) instead of max(len_shadow) + max(len_next).  (Over the whole path on the Cornell box the
-// pairing LOSES 7 % -- the bounce-0 shadow rays are coherent and cheap, DESIGN section 6 -- which is why only the tail launches take
-// it.)  The first nearest-hit ray of the segment and the last shadow ray are traced alone: the queue hands over untraced rays.  Same
-// sequence of float operations per path as path_segment_lds (the shadow term is added before the next shading event either way).
-#ifndef TRG_TAIL_PAIR
-#define TRG_TAIL_PAIR 1
-#endif
-template <bool COUNT, typename STK>
-TRG_DEV void path_segment_lds_paired(const trg::RenderParams &p, const SceneView &sc, STK stk, uint32_t offset, uint32_t frame, uint32_t b0, uint32_t b1,
-                                     V3 &o, V3 &d, V3 &thr, V3 &rad, bool &active, bool &primary_ray, V3 light_color, PathCounters &pc, Counters &cnt) {
-    constexpr bool TAB = !TRG_STRICT && TRG_HALTON_TABLES;
-    typedef const __attribute__((address_space(4))) trg_uniforms cu_t;
-    cu_t *up = (cu_t *)__builtin_amdgcn_kernarg_segment_ptr();   // RenderParams::u is the first member (see path_radiance)
-    Hit h; h.t = -1.0f; h.prim = -1; h.u = 0.0f; h.v = 0.0f;
-    bool found = false;
-    if (b0 < b1) {
-        if (b0 > 0) pc.bounce += wave_count(active);
-        if (active) found = traverse<false, COUNT, trg::kBlock, false>(sc, o, d, INFINITY, primary_ray ? 3u : 1u, h, stk, cnt);
-    }
-    for (uint32_t b = b0; b < b1; ++b) {
-        if (__ballot(active) == 0ull) break;
-        const bool last = (b + 1u == p.bounces), seg_last = (b + 1u == b1);   // wave-uniform
-        asm volatile("" : "+s"(up));
-        ShadeOut so; so.want_shadow = false; so.want_next = false; so.shaded = false; so.sdir = mk(0.0f, 0.0f, 1.0f); so.scol = mk(0.0f, 0.0f, 0.0f); so.smax = -1.0f;
-        if (active) {
-            uint32_t rmask = primary_ray ? 3u : 1u;
-            so = shade_event<TAB>(*(const trg_uniforms *)up, sc, h, found, b, last, offset + frame, o, d, thr, rad, rmask, active, light_color);
-            primary_ray = rmask == 3u;
-        }
-        pc.shaded += wave_count(so.shaded);
-        pc.shadow += wave_count(so.want_shadow);
-        const bool trace_next = so.want_next && !seg_last;   // the continuation ray of the segment's last bounce goes to the queue untraced
-        pc.bounce += wave_count(trace_next);
-        if (__ballot(so.want_shadow || trace_next) != 0ull) {
-            bool occluded = false;
-            traverse_pair<COUNT, trg::kBlock, false>(sc, o, so.want_shadow, so.sdir, so.smax, trace_next, d, primary_ray ? 3u : 1u, occluded, h, found, stk, cnt);
-            if (so.want_shadow && !occluded) rad = rad + so.scol;
-        }
-    }
-}
-
 TRG_DEV void flush_counters(const trg::RenderParams &p, unsigned char *smem, uint32_t wave, uint32_t lane, const PathCounters &pc, const Counters &cnt, bool count) {
     uint32_t vals[8] = { pc.primary, pc.bounce, pc.shadow, pc.shaded, cnt.nodes, cnt.tris, cnt.wnodes, cnt.wtris };
     uint32_t *red = reinterpret_cast<uint32_t *>(smem + p.red_off);
@@ -175,11 +132,12 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES) void render_head_kernel
 
 // ---- tail: bounces [tail_k, tail_k_end) for the queued paths, 64 consecutive entries of a segment per wavefront; when it stops
 //      before the last bounce the survivors are compacted again into the wavefront's segment of the output queue ----
-#ifndef TRG_EXP_WAVES_TAIL
-#define TRG_EXP_WAVES_TAIL (TRG_TAIL_PAIR ? 7 : TRG_EXP_WAVES)   // the paired loop keeps two rays' constants live: 72 VGPRs without spills
-#endif
+// (Round 3, measured and not kept: walking the shadow ray of bounce b and the nearest-hit ray of bounce b + 1 as a pair in one loop per
+// lane, as the HBM kernels do.  Both rays are incoherent in a tail launch, so the wavefront would pay max(len_s + len_n) instead of
+// max(len_s) + max(len_n) -- but the pair loop needs the any-hit flag per lane and 72 VGPRs: C3 at 64 spp 15.65 -> 17.7 ms per step at
+// 7 waves/SIMD, 17.7 with spills at 8, 18.4 at 6.)
 template <bool COUNT>
-__global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_TAIL) void render_tail_kernel(const trg::RenderParams p) {
+__global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES) void render_tail_kernel(const trg::RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     SceneView sc = scene_view<true>(p.sc, smem);
     sc.tex = p.tex;
@@ -214,11 +172,7 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_TAIL) void render_tail_k
         }
         // `frame` must be wave-uniform for path_segment_lds (Halton index = offset + frame): the entries of one round may belong
         // to different frames, so the per-lane frame rides in `offset` and the uniform part is zero
-#if TRG_TAIL_PAIR
-        path_segment_lds_paired<COUNT>(p, sc, stk, offset + p.frame_begin + fl, 0u, p.tail_k, p.tail_k_end, o, d, thr, rad, active, primary_ray, light_color, pc, cnt);
-#else
         path_segment_lds<COUNT>(p, sc, stk, offset + p.frame_begin + fl, 0u, p.tail_k, p.tail_k_end, o, d, thr, rad, active, primary_ray, light_color, pc, cnt);
-#endif
         if (i < n) {
             v4f r4; r4.x = rad.x; r4.y = rad.y; r4.z = rad.z; r4.w = 0.0f;
             radbuf[(size_t)fl * p.tail_band_pixels + pl] = r4;
