@@ -92,7 +92,7 @@ enum trg_option {
     TRG_OPT_GPU_BUILD = 6,    /* the next trg_load_scene builds the BVH on the GPU (4-wide, HBM traversal only): 1 = binned SAH, one tree level per
                                  round (the host builder's split rule), 2 = Morton order + Karras LBVH hierarchy (fastest build), 3 = Morton
                                  order + PLOC merges by surface area; 0 (default): host SAH build */
-    TRG_OPT_KERNEL = 5,       /* which megakernel trg_render launches: TRG_KERNEL_DIRECT (default) or TRG_KERNEL_POOL */
+    TRG_OPT_KERNEL = 5,       /* which schedule trg_render launches: enum trg_kernel below (default TRG_KERNEL_AUTO = TRG_KERNEL_DIRECT) */
     TRG_OPT_LAUNCHES_IN_FLIGHT = 8, /* hint, default 1: how many trg_render launches of this context the caller keeps in flight on different
                                  streams (at most 16): the automatic frame split then favours throughput (the overlap hides a launch's tail).
                                  Per-launch scratch is keyed on the stream (trg_set_stream), so launches on different streams never share
@@ -126,7 +126,8 @@ enum trg_kernel {
     TRG_KERNEL_WAVEFRONT = 2, /* rays and path state of a batch of pixel-samples in HBM: a persistent tracer whose lanes pull the next ray of
                                  a ballot/prefix-compacted queue as soon as they are free + one shading kernel per bounce (same arithmetic
                                  and results; the schedule for scenes that live in HBM, where ray lengths diverge and paths die) */
-    TRG_KERNEL_AUTO = -1      /* default: TRG_KERNEL_WAVEFRONT for a scene that is traversed from HBM, TRG_KERNEL_DIRECT for one staged in LDS */
+    TRG_KERNEL_AUTO = -1      /* default: TRG_KERNEL_DIRECT for every scene (the megakernel; scenes in HBM take its path-regeneration form from 32,768
+                                 triangles on, TRG_OPT_REGEN).  The wavefront schedule measured 2.5x slower on the million-triangle scene and stays an option */
 };
 
 /* --- lifetime: replaces MetalRenderer::init / resize (src/engine/Metal/MetalRenderer.mm:282-338,557-574):
