@@ -1,4 +1,4 @@
-# A/B of experimental builds on the GPU box:  bash scripts/r3_ab.sh <config> <variant> [<variant> ...]   (variants of scripts/exp_build.sh, or "shipped")
+# A/B of experimental builds on the GPU box:  bash scripts/ab.sh <config> <variant> [<variant> ...]   (variants of scripts/exp_build.sh, or "shipped")
 set -o pipefail
 cd "$GRAFT_REPO_ROOT"
 cfg=$1; shift
