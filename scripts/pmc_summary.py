@@ -76,6 +76,29 @@ for cfg in cfgs:
                "alone_mean_ms": summary[cfg].get("launches", {}).get("alone_mean_ms"),
                "source": "scripts/profile_round.sh at commit %s: one rocprofv3 --pmc pass per counter group of `python3 bench.py%s`, per-launch means; "
                          "fetch_bytes = 2 x FETCH_SIZE x 1024 (gfx950 counts each 128-byte request as 64: profiles/%s/fetch_calibration.md), write_bytes = WRITE_SIZE x 1024" % (commit, " --no-secondary" if cfg == "c2" else " --config " + cfg, "r02")}
+        # a step of a tail-compacted configuration (C3) is many launches -- per 16-frame chunk one head, the tail levels, one fold: the
+        # per-STEP instruction counts are the sums over the <false> instantiations divided by the steps profiled (head launches / chunks per step)
+        heads = [k for k in counters if "render_head_kernel<false>" in k]
+        if heads:
+            chunks_per_step = int(os.environ.get("TRG_CHUNKS_PER_STEP", "16"))   # C3: 256 spp in chunks of 16 frames
+            steps = counters[heads[0]]["SQ_INSTS_VALU"]["launches"] / chunks_per_step
+            tot = collections.defaultdict(float)
+            for k, cs in counters.items():
+                if "<false>" in k or "accumulate" in k:
+                    for n, v in cs.items():
+                        tot[n] += v["mean"] * v["launches"]
+            rec["kernel"] = "render_head_kernel<false> + render_tail_kernel<false> (all launches of a step)"
+            rec["per_kernel_launch"] = {k: {"valu_insts": cs.get("SQ_INSTS_VALU", {}).get("median"), "launches_profiled": cs.get("SQ_INSTS_VALU", {}).get("launches"),
+                                            "lanes_active_per_valu_inst": (cs["SQ_THREAD_CYCLES_VALU"]["median"] / cs["SQ_INSTS_VALU"]["median"]) if "SQ_THREAD_CYCLES_VALU" in cs and "SQ_INSTS_VALU" in cs else None}
+                                        for k, cs in counters.items() if "<false>" in k}
+            rec["steps_profiled"] = steps
+            rec["valu_insts_per_launch"] = tot["SQ_INSTS_VALU"] / steps
+            rec["salu_insts_per_launch"] = tot["SQ_INSTS_SALU"] / steps
+            rec["lanes_active_per_valu_inst"] = tot["SQ_THREAD_CYCLES_VALU"] / tot["SQ_INSTS_VALU"] if tot["SQ_INSTS_VALU"] else None
+            rec["fetch_bytes"] = 2.0 * tot["FETCH_SIZE"] * 1024.0 / steps
+            rec["write_bytes"] = tot["WRITE_SIZE"] * 1024.0 / steps
+            rec["hbm_bytes_per_launch"] = rec["fetch_bytes"] + rec["write_bytes"]
+            rec["note"] = "`per launch` here = per bench step (one trg_render of the whole configuration): sums over every kernel launch of the step"
         json.dump(rec, open(f"{out}/{cfg}_counters.json", "w"), indent=1)
         print(cfg, json.dumps({k: (round(v) if isinstance(v, float) and v > 100 else v) for k, v in rec.items() if k not in ("source",)}))
     for r in stats[:2]:
