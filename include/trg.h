@@ -204,8 +204,9 @@ TRG_API int trg_fence_wait(trg_ctx *ctx, int slot);
  *     slice of a full-frame buffer (padded to G*B rows, so that the in-place all-gather is exact for any height).  One PERSISTENT host
  *     thread per context drives the launches (started at create, handed each call through a condition variable); a host-built scene
  *     is built once and uploaded to every device.  A group of one device needs no RCCL (it is loaded with dlopen for G > 1) and no thread.
- *     NOT YET RUN ON MORE THAN ONE DEVICE: the development pool has single-GPU boxes, so n > 1 (ncclCommInitAll, the exchange) is
- *     covered by code review and the CPU rehearsals of tests/test_dist_gloo.py only. */
+ *     NOT YET RUN ON MORE THAN ONE DEVICE: the development pool has single-GPU boxes, so n > 1 is covered by code review, the CPU
+ *     rehearsals of tests/test_dist_gloo.py, and -- environment variable TRG_GROUP_FORCE_RCCL -- a group of one device that goes through
+ *     RCCL all the same (dlopen, ncclCommInitAll, the in-place all-gather on the render's stream: a GPU test). */
 typedef struct trg_group trg_group;
 enum trg_gather {
     TRG_GATHER_NONE = 0,  /* every device keeps only its own band */

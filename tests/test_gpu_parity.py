@@ -1346,6 +1346,43 @@ def test_device_group_c_abi(capi, O, cornell, force_global):
         capi.Group([0, 0], 16, 16)
 
 
+def test_device_group_exchange_through_rccl_on_one_device(capi, O, cornell, monkeypatch):
+    """The part of the multi-GPU exchange a single-GPU box CAN run ("the exchange was never run on hardware"): with
+    TRG_GROUP_FORCE_RCCL a group of one device loads RCCL, creates its communicator with ncclCommInitAll and enqueues the in-place
+    ncclAllGather (sendbuff = recvbuff + rank * count) / the grouped send-recv on the stream its render went to -- one rank, so the
+    collective moves nothing, but symbol binding, communicator, argument layout, stream order and the padded frame buffer are real.
+    Frames before and after the exchange are the plain context's bit for bit, asynchronously over several frames too."""
+    w, h, spp, bnc = 120, 45, 2, 3
+    ref_ctx = make_ctx(O, cornell, w, h)
+    try:
+        ref_ctx.set_option(capi.OPT_STRICT, 1)
+        ref_ctx.render(0, spp, bnc)
+        ref = ref_ctx.read_accum()
+        ref_ctx.render(spp, spp, bnc)
+        ref2 = ref_ctx.read_accum()
+    finally:
+        ref_ctx.close()
+    monkeypatch.setenv("TRG_GROUP_FORCE_RCCL", "1")
+    b = cornell.buffers()
+    g = capi.Group([0], w, h)
+    try:
+        g.load_scene(b["positions"], b["normals"], b["colors"], b["indices"], b["material_ids"])
+        g.set_uniforms(O.uniforms_bytes(O.make_uniforms(w, h)))
+        g.set_pixel_offsets_seed()
+        g.set_option(capi.OPT_STRICT, 1)
+        for mode in (capi.GATHER_ALL, capi.GATHER_ROOT):
+            g.render(0, spp, bnc, gather=mode, root=0)
+            g.sync()
+            assert np.array_equal(_bits(g.read_accum(0)), _bits(ref)), mode
+        g.set_option(capi.OPT_TIMING, 0)              # asynchronous: render, exchange, fence -- twice, then wait
+        g.render(0, spp, bnc, gather=capi.GATHER_ALL); g.fence_record(0)
+        g.render(spp, spp, bnc, gather=capi.GATHER_ALL); g.fence_record(1)
+        g.fence_wait(0); g.fence_wait(1)
+        assert np.array_equal(_bits(g.read_accum(0)), _bits(ref2))
+    finally:
+        g.close()
+
+
 def _checker_texture(n, cells, a, b, seed):
     rng = np.random.default_rng(seed)
     yy, xx = np.mgrid[0:n, 0:n]

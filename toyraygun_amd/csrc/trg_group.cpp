@@ -17,6 +17,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -144,7 +145,9 @@ int trg_group_create(trg_group **out, const int *devices, int n, uint32_t width,
         }
         (void)trg_bind_accum(g->ctx[r], g->frame[r]);
     }
-    if (n > 1) {
+    // (TRG_GROUP_FORCE_RCCL: a group of ONE device goes through RCCL too -- dlopen, ncclCommInitAll, the in-place all-gather on the render's
+    // stream -- so that as much of the exchange as one GPU can exercise is exercised by the GPU tests of a single-GPU box)
+    if (n > 1 || getenv("TRG_GROUP_FORCE_RCCL")) {
         std::string err;
         if (!g_rccl.load(err)) { gfail(nullptr, TRG_ERR_DEVICE, "trg_group_create: %s", err.c_str()); trg_group_destroy(g); return TRG_ERR_DEVICE; }
         g->comm.assign(n, nullptr);
@@ -210,7 +213,7 @@ int trg_group_render(trg_group *g, uint32_t frameIndexBegin, uint32_t spp, uint3
             return trg_render(g->ctx[r], frameIndexBegin, spp, bounces, row0, rows);
         }))
         return rc;
-    if (g->n == 1 || gather == TRG_GATHER_NONE) return TRG_OK;
+    if (g->comm.empty() || gather == TRG_GATHER_NONE) return TRG_OK;
     // the one exchange of the frame, enqueued behind each device's render: on the stream that render was launched on (the context's
     // current stream -- trg_set_stream's if the caller set one through trg_group_ctx, the context's own otherwise)
     const size_t count = (size_t)g->band * g->w * 4u;   // floats per band
