@@ -10,12 +10,14 @@ CSRC = os.path.join(_HERE, "csrc")
 
 
 def kernel_source_files():
-    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)
-                  if f.endswith((".hip", ".h")) and os.path.isfile(os.path.join(CSRC, f)))
+    """What the render kernels are compiled from: trg_kernels.hip and everything it includes from this directory (the host-side
+    sources -- C ABI, builders, device groups -- can change without making a kernel's instruction counts stale)."""
+    names = ["trg_kernels.hip", "trg_kernels.h", "trg_device.h"] + sorted(f for f in os.listdir(CSRC) if f.endswith(".inc.h"))
+    return [os.path.join(CSRC, f) for f in names]
 
 
 def kernel_source_hash():
-    """sha256 over the names and contents of toyraygun_amd/csrc/*.hip, *.h (the .inc.h files included), first 16 hex digits."""
+    """sha256 over the names and contents of the files above, first 16 hex digits."""
     h = hashlib.sha256()
     for path in kernel_source_files():
         h.update(os.path.basename(path).encode() + b"\0")
