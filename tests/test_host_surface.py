@@ -639,3 +639,27 @@ def test_png_header_cannot_size_the_decoder(built, tmp_path):
         host.Texture(path=tmp_path / "bomb.png")
     t = host.Texture(path=tmp_path / "ok.png")
     assert t.info() == (4, 4, 4) and (t.pixels()[..., 0] == 0x10).all()
+
+
+def test_committed_counters_belong_to_these_kernel_sources(built):
+    """Evidence hygiene (round-2 verdict, item 8): the profiler counters bench.py imports into its roofline object carry a hash of the
+    kernel sources they were measured on; the committed files must match THIS tree (re-run scripts/profile_round.sh after touching
+    a kernel), and a file with another hash is refused and reported as stale rather than used."""
+    import importlib
+    import json
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    from toyraygun_amd.srchash import kernel_source_hash
+    here = kernel_source_hash()
+    for cfg in ("c2", "c3", "c4"):
+        rec, path, stale = bench.imported_counters(cfg)
+        assert rec is not None and stale is None, (cfg, stale and stale.get("reason"))
+        assert rec["kernel_source_hash"] == here and rec["valu_insts_per_launch"] > 0 and path.startswith("profiles/")
+    # a counters file of another build is not used
+    rounds = bench.PROFILE_ROUNDS
+    try:
+        bench.PROFILE_ROUNDS = ("r02",)          # round 2's files carry no hash at all
+        rec, path, stale = bench.imported_counters("c2")
+        assert rec is None and stale is not None and "changed" in stale["reason"]
+    finally:
+        bench.PROFILE_ROUNDS = rounds
