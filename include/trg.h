@@ -269,6 +269,11 @@ TRG_API int trg_debug_build_bvh4(const float *positions3, const uint32_t *indice
 TRG_API int trg_debug_build_bvh4q(const float *positions3, const uint32_t *indices, const uint32_t *material_ids, uint32_t n_verts,
                                   uint32_t n_tris, uint32_t *nodes4q_out, uint32_t nodes4_cap, uint32_t *n_nodes4);
 
+/* host-only: the tile (bx, by) workgroup slot `slot` of a launch over tiles_x x tiles_y tiles renders under tile order `order` (0, 1, 2, 4, 8:
+ * TRG_OPT_TILE_ORDER), exactly as the kernels compute it.  Returns 1, 0 for a padding slot of an XCD-aware order (or a slot beyond the
+ * launch), negative on bad arguments; *n_slots = workgroup slots of the launch.  The slots with return 1 cover every tile exactly once. */
+TRG_API int trg_debug_tile_of_slot(uint32_t tiles_x, uint32_t tiles_y, uint32_t order, uint32_t slot, uint32_t *n_slots, uint32_t *bx, uint32_t *by);
+
 /* which XCD runs workgroup b of a plain launch of n_blocks 256-thread workgroups: out[b] = HW_REG_XCC_ID (0..7).  The tile order above
  * relies, for speed only, on the observed round-robin placement (b and b + 8 share an XCD); this is how the tests and profiles check it. */
 TRG_API int trg_debug_xcc_ids(trg_ctx *ctx, uint32_t n_blocks, uint32_t *out);

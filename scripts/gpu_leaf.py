@@ -38,6 +38,6 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     st = c.stats()
     print("maxleaf=%s travcost=%s nodes=%d depth=%d : %s" % (os.environ.get("TRG_BVH_MAXLEAF"), os.environ.get("TRG_BVH_TRAVCOST"), st.bvh_nodes, st.bvh_depth, " ".join(out)), flush=True)
     sys.exit(0)
-for ml, tc in (("2", "1.2"), ("1", "1.2"), ("1", "0.5"), ("2", "0.5"), ("2", "0.8"), ("3", "1.2"), ("4", "1.2"), ("2", "2.0"), ("3", "0.8"), ("2", "1.2")):
+for ml, tc in (("2", "1.2"), ("1", "1.2"), ("1", "0.5"), ("2", "0.5"), ("2", "0.8"), ("3", "1.2"), ("4", "1.2"), ("2", "2.0"), ("3", "0.8"), ("4", "3.0"), ("6", "3.0"), ("8", "3.0"), ("6", "8.0"), ("8", "8.0"), ("2", "1.2")):
     env = dict(os.environ, TRG_BVH_MAXLEAF=ml, TRG_BVH_TRAVCOST=tc)
     subprocess.run([sys.executable, __file__, "--one"], env=env)

@@ -663,3 +663,38 @@ def test_committed_counters_belong_to_these_kernel_sources(built):
         assert rec is None and stale is not None and "changed" in stale["reason"]
     finally:
         bench.PROFILE_ROUNDS = rounds
+
+
+def test_every_tile_order_is_a_bijection(built):
+    """TRG_OPT_TILE_ORDER (host replica of the kernels' slot -> tile map, trg_kernels.h tile_of_slot): for every order the valid slots of
+    a launch cover every tile exactly once; the XCD-aware orders pad by less than one column / row of tiles per region, give the slots
+    with equal slot % 8 ONE rectangle of the screen, and walk it away from the image centre."""
+    import ctypes as C
+    from toyraygun_amd import capi
+    L = capi.load()
+    n, bx, by = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    for tx, ty in ((120, 68), (1, 1), (7, 3), (13, 1), (2, 9), (240, 135), (5, 5), (64, 2)):
+        for order in (0, 1, 2, 4, 8):
+            assert L.trg_debug_tile_of_slot(tx, ty, order, 0, C.byref(n), None, None) >= 0
+            slots = n.value
+            seen, per_xcd = set(), {}
+            for s_ in range(slots):
+                rc = L.trg_debug_tile_of_slot(tx, ty, order, s_, None, C.byref(bx), C.byref(by))
+                assert rc in (0, 1)
+                if rc:
+                    assert bx.value < tx and by.value < ty and (bx.value, by.value) not in seen
+                    seen.add((bx.value, by.value))
+                    per_xcd.setdefault(s_ % 8, []).append((bx.value, by.value))
+            assert len(seen) == tx * ty, (tx, ty, order)
+            assert L.trg_debug_tile_of_slot(tx, ty, order, slots, None, None, None) == 0
+            if order == 0:
+                assert slots == tx * ty
+            else:
+                assert slots <= tx * ty + 8 * (tx + ty + 1)          # padding: at most a column + a row of tiles per region
+                for tiles in per_xcd.values():                        # one rectangle per XCD, filled completely
+                    xs, ys = [t[0] for t in tiles], [t[1] for t in tiles]
+                    assert (max(xs) - min(xs) + 1) * (max(ys) - min(ys) + 1) == len(tiles)
+                if order == 2 and tx >= 4 and ty >= 4:
+                    left = [t[0] for t in per_xcd[0]]                 # strip left of the centre: starts at the centre column, ends at the edge
+                    assert left[0] == tx // 2 - 1 and left[-1] == 0
+    assert L.trg_debug_tile_of_slot(4, 4, 3, 0, None, None, None) < 0

@@ -1118,6 +1118,18 @@ int trg_debug_build_bvh4q(const float *positions3, const uint32_t *indices, cons
     return TRG_OK;
 }
 
+int trg_debug_tile_of_slot(uint32_t tiles_x, uint32_t tiles_y, uint32_t order, uint32_t slot, uint32_t *n_slots, uint32_t *bx, uint32_t *by) {
+    if (tiles_x == 0 || tiles_y == 0 || (order != 0 && order != 1 && order != 2 && order != 4 && order != 8)) return TRG_ERR_INVALID;
+    const uint64_t slots = tile_slots(tiles_x, tiles_y, order);
+    if (slots > 0x7FFFFFFFull) return TRG_ERR_RANGE;
+    if (n_slots) *n_slots = (uint32_t)slots;
+    uint32_t x = 0, y = 0;
+    const bool valid = slot < slots && tile_of_slot(tiles_x, tiles_y, order, slot, x, y);
+    if (bx) *bx = x;
+    if (by) *by = y;
+    return valid ? 1 : 0;
+}
+
 int trg_debug_xcc_ids(trg_ctx *c, uint32_t n_blocks, uint32_t *out) {
     if (!c || (n_blocks && !out) || n_blocks > (1u << 20)) return TRG_ERR_INVALID;
     if (n_blocks == 0) return TRG_OK;

@@ -64,41 +64,9 @@ TRG_DEV uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
-// Workgroup slot -> tile of the launch (any bijection onto the tiles is correct; this is about time only).
-//  * xcd_cols == 0: image columns from the centre outwards (rows inner).  It starts the tiles a camera usually points at first, so the
-//    tail of the launch is made of the cheap edge tiles (C2: the 16:9 side bars) instead of leaving CUs idle behind a few expensive
-//    ones (+9 % on C2).
-//  * xcd_cols = 1, 2, 4, 8 (scenes traversed from HBM): XCD-aware.  Workgroups are dealt round-robin over the 8 XCDs, each with its own
-//    4 MiB L2, so the workgroups with equal slot % 8 share an L2.  They get ONE of xcd_cols x (8 / xcd_cols) contiguous regions of the
-//    screen (column strips x row bands) and walk it column by column away from the image centre: an L2 then sees the rays of one
-//    screen region -- one part of the scene -- instead of every eighth tile of the whole picture.  Regions differ in size by a
-//    row or a column at most, so the launch is padded to 8 x the largest region and the few slots beyond a region's end return false.
-//    All regions are at the same distance from the centre at the same time, which keeps the eight XCDs equally loaded while the
-//    dispatcher deals the workgroups out in order.
+// workgroup slot -> tile of the launch: trg_kernels.h tile_of_slot (shared with the host)
 TRG_DEV bool block_tile(const trg::RenderParams &p, uint32_t slot, uint32_t &bx, uint32_t &by) {
-    const uint32_t cleft = (p.tiles_x - 1u) / 2u;
-    if (p.xcd_cols == 0u) {
-        const uint32_t crank = slot / p.tiles_y;
-        by = slot % p.tiles_y;
-        bx = (crank & 1u) ? cleft + 1u + crank / 2u : cleft - crank / 2u;
-        return true;
-    }
-    const uint32_t x = slot % trg::kXcds, j = slot / trg::kXcds;
-    const uint32_t rc = p.xcd_cols, rq = trg::kXcds / rc;
-    const uint32_t ci = x % rc, qi = x / rc;
-    const uint32_t c0 = ci * p.tiles_x / rc, c1 = (ci + 1u) * p.tiles_x / rc;
-    const uint32_t r0 = qi * p.tiles_y / rq, r1 = (qi + 1u) * p.tiles_y / rq;
-    const uint32_t W = c1 - c0, H = r1 - r0;
-    if (H == 0u) return false;
-    const uint32_t c = j / H, r = j - c * H;
-    if (c >= W) return false;
-    if (rc == 1u) {   // one strip per row band: columns from the centre outwards, as above
-        bx = (c & 1u) ? cleft + 1u + c / 2u : cleft - c / 2u;
-    } else {
-        bx = (2u * ci < rc) ? c1 - 1u - c : c0 + c;   // strips left of the centre walk to the left edge, the others to the right edge
-    }
-    by = r0 + r;
-    return true;
+    return trg::tile_of_slot(p.tiles_x, p.tiles_y, p.xcd_cols, slot, bx, by);
 }
 
 // The shading event of one bounce (primaryHit, Raytracing.metal:115-215) for the lane's current ray and its
