@@ -162,7 +162,7 @@ static bool plan_lds_as(const trg_ctx *c, LdsPlan &p, bool lds_scene, bool pool,
     if (p.lds_scene) {
         // the sentinel at level 0 + BVH2, near child first: at most one pending entry per level + the scratch slot above the top;
         // 4-wide LDS tree: up to three pending entries per level (its branch-free pushes write at most into those slots)
-        levels = kWideLds ? 3 * c->bvh_depth4 + 2 : c->bvh_depth + 3;
+        levels = kThreadedLds ? 1u : (kWideLds ? 3 * c->bvh_depth4 + 2 : c->bvh_depth + 3);   // (the threaded walk has no stack: only the sentinel level)
         p.klds = levels;
     } else {
         levels = kWideHbm ? 3 * c->bvh_depth4 + 3 : c->bvh_depth + 3;  // the sentinel at level 0; 4-wide: up to three pending entries per level
@@ -524,10 +524,14 @@ int host_scene_build(trg_ctx *c, const float *pos, const float *nrm, const float
     // [ LDS nodes | 48-byte triangle records | normals | colours | material ids | Halton tables ] [ quantised 4-wide nodes ] [ 128-byte leaf records ]
     // The first bracket is what a workgroup stages into LDS; only a scene small enough for that has it.  The other two are what
     // the HBM kernels traverse (a small scene kept in HBM -- TRG_OPT_FORCE_GLOBAL, a tree too deep for LDS stacks -- uses them too).
-    const uint64_t small_bytes = (uint64_t)(kWideLds ? bvh.n_nodes4 : bvh.n_nodes) * kLdsNodeBytes + (uint64_t)nt_rec * 48u + (uint64_t)attr_tris * 76u + 64u + kHtabBytes;
-    const bool lds_candidate = small_bytes <= kMaxLdsScene;
+    // TRG_TRAV_LDS == 6: 2 entries of 64 bytes per BVH2 node, then 8 order tables of (entries + 1) words, counted in 64-byte units
+    const uint32_t thr_entries = 2u * bvh.n_nodes, thr_units = thr_entries + (8u * (thr_entries + 1u) * 4u + 63u) / 64u;
+    const uint32_t lds_nodes = kThreadedLds ? thr_units : (kWideLds ? bvh.n_nodes4 : bvh.n_nodes);
+    const uint64_t small_bytes = (uint64_t)lds_nodes * kLdsNodeBytes + (uint64_t)nt_rec * 48u + (uint64_t)attr_tris * 76u + 64u + kHtabBytes;
+    const bool lds_candidate = small_bytes <= kMaxLdsScene && (!kThreadedLds || thr_units * 64u < 65536u);
     SceneDesc sc{};
-    sc.n_nodes = lds_candidate ? (kWideLds ? bvh.n_nodes4 : bvh.n_nodes) : 0u; sc.n_tris = n_tris;
+    sc.n_nodes = lds_candidate ? lds_nodes : 0u; sc.n_tris = n_tris;
+    sc.thr_entries = (kThreadedLds && lds_candidate) ? thr_entries : 0u;
     const uint32_t node_bytes = kLdsNodeBytes;
     sc.n_nodes4 = bvh.n_nodes4;
     uint64_t total = 0;
@@ -537,7 +541,54 @@ int host_scene_build(trg_ctx *c, const float *pos, const float *nrm, const float
     }
     std::vector<unsigned char> &host = hs->blob;
     host.assign(sc.blob_bytes, 0);
-    if (sc.n_nodes && lds_candidate && kWideLds) {
+    if (sc.n_nodes && lds_candidate && kThreadedLds) {
+        // Octant-threaded BVH2 (experiment).  Entry 2 n + s = child s of node n: per axis (lo, hi, hi, lo) so that an 8-byte read at +0 gives
+        // (near, far) for a positive direction and at +8 for a negative one; word 12 = the leaf code (< 0) or 0 for an inner child.
+        unsigned char *base = &host[sc.off_nodes];
+        for (uint32_t n = 0; n < bvh.n_nodes; ++n) {
+            const F4 *nd = &bvh.nodes[(size_t)n * 4];
+            int32_t ch[2];
+            memcpy(ch, &nd[3].x, 8);
+            for (int k = 0; k < 2; ++k) {
+                const float lo[3] = { k ? nd[1].x : nd[0].x, k ? nd[1].z : nd[0].z, k ? nd[2].z : nd[2].x };
+                const float hi[3] = { k ? nd[1].y : nd[0].y, k ? nd[1].w : nd[0].w, k ? nd[2].w : nd[2].y };
+                float *e = reinterpret_cast<float *>(base + (size_t)(2u * n + (uint32_t)k) * 64u);
+                for (int a = 0; a < 3; ++a) { e[a * 4 + 0] = lo[a]; e[a * 4 + 1] = hi[a]; e[a * 4 + 2] = hi[a]; e[a * 4 + 3] = lo[a]; }
+                const int32_t code = ch[k] < 0 ? ch[k] : 0;
+                memcpy(&e[12], &code, 4);
+            }
+        }
+        // the eight orders: depth first, the child that lies first along the octant's direction first; word = entry byte offset | skip << 16
+        uint32_t *tables = reinterpret_cast<uint32_t *>(base + (size_t)thr_entries * 64u);
+        for (uint32_t oct = 0; oct < 8u; ++oct) {
+            uint32_t *tab = tables + (size_t)oct * (thr_entries + 1u);
+            uint32_t pos = 0;
+            struct Item { uint32_t node; int stage; uint32_t k[2]; int first; };
+            std::vector<Item> st;
+            st.push_back(Item{ 0u, 0, { 0u, 0u }, 0 });
+            while (!st.empty()) {
+                Item &it = st.back();
+                const F4 *nd = &bvh.nodes[(size_t)it.node * 4];
+                int32_t ch[2];
+                memcpy(ch, &nd[3].x, 8);
+                if (it.stage == 0) {   // which child comes first for this octant: the smaller centre along every axis the ray moves up, the larger where it moves down
+                    const float c0[3] = { nd[0].x + nd[0].y, nd[0].z + nd[0].w, nd[2].x + nd[2].y }, c1[3] = { nd[1].x + nd[1].y, nd[1].z + nd[1].w, nd[2].z + nd[2].w };
+                    float k0 = 0.f, k1 = 0.f;
+                    for (int a = 0; a < 3; ++a) { const float sgn = ((oct >> a) & 1u) ? -1.f : 1.f; k0 += sgn * c0[a]; k1 += sgn * c1[a]; }
+                    it.first = k1 < k0 ? 1 : 0;
+                }
+                if (it.stage >= 1) tab[it.k[it.stage - 1]] |= pos << 16;   // the skip link of the child whose subtree has just been laid out
+                if (it.stage == 2) { st.pop_back(); continue; }
+                const int slot = it.stage == 0 ? it.first : 1 - it.first;
+                it.k[it.stage] = pos;
+                tab[pos++] = (2u * it.node + (uint32_t)slot) * 64u;
+                const int32_t child = ch[slot];
+                it.stage++;
+                if (child >= 0) st.push_back(Item{ (uint32_t)child, 0, { 0u, 0u }, 0 });   // (invalidates `it`: not used below)
+            }
+            tab[thr_entries] = 0xFFFFu | (thr_entries << 16);   // end marker (never read: the walk stops at position == entries)
+        }
+    } else if (sc.n_nodes && lds_candidate && kWideLds) {
         // sign-ordered 4-wide LDS nodes (trav_node4_step_lds): per axis [lo x4 | hi x4 | lo x4] = 48 bytes, so that a 32-byte read at
         // +0 gives (near, far) for a positive direction and at +16 for a negative one; then the four children (inner: byte offset
         // of the node; leaf code < 0; unused slot: 0x80000000 behind an inverted box that no ray enters)

@@ -515,6 +515,7 @@ struct SceneView {
     const uint32_t *mats;   // LDS scene: 1 per triangle, ORIGINAL order (reference triangleMasks buffer); HBM scene: nullptr
     const float *htab;      // Halton group tables in LDS (trg_kernels.h kHtab), or nullptr
     trg::TexDesc tex;       // albedo textures in global memory (tex.uv == nullptr: none)
+    uint32_t thr_entries;   // TRG_TRAV_LDS == 6: entries of the octant-threaded tree behind `nodes`
 };
 struct Hit { float t; int prim; float u, v; };  // u, v = Moeller-Trumbore weights of vertex 1 and 2; prim = original index (LDS scene) or leaf record (HBM scene)
 struct Counters { uint32_t nodes, tris, wnodes, wtris; };  // per-lane work and wave-level iterations (first active lane counts)
@@ -744,6 +745,21 @@ TRG_DEV Hit trav_hit(const Trav &tv) {
 
 // One leaf: test its 1..8 triangles.  ~node = (first << 3) | (count - 1).  Pops the next node (the sentinel kNodeDone when
 // nothing is pending) and returns true when an any-hit query is satisfied -- the caller then stops whatever was popped.
+// the triangles of one leaf, without touching the stack (the octant-threaded walk, TRG_TRAV_LDS == 6)
+template <bool COUNT>
+TRG_DEV bool trav_leaf_test(const SceneView &sc, Trav &tv, int leaf, bool any, Counters &cnt) {
+    const uint32_t code = (uint32_t)~leaf;
+    const uint32_t first = code >> 3, count = (code & 7u) + 1u;
+    const v4f *tr = sc.tris + first * 3;
+    bool stop = trav_tri_math<COUNT>(tr[0], tr[1], tr[2], tv, any, cnt);
+    if (!stop && count > 1u) stop = trav_tri_math<COUNT>(tr[3], tr[4], tr[5], tv, any, cnt);
+    for (uint32_t k = 2; k < count && !stop; ++k) {
+        const v4f *t2 = sc.tris + (first + k) * 3;
+        stop = trav_tri_math<COUNT>(t2[0], t2[1], t2[2], tv, any, cnt);
+    }
+    return stop;
+}
+
 template <bool COUNT, int BLOCK, typename STK>
 TRG_DEV bool trav_leaf_step(const SceneView &sc, Trav &tv, bool any, STK stk, Counters &cnt) {
     const uint32_t code = (uint32_t)~tv.node;
@@ -856,7 +872,8 @@ TRG_DEV void trav_node4_step_lds(const SceneView &sc, Trav &tv, STK stk, Counter
 // the inner-node step of the while-while schedules: BVH2 (0), sign-ordered BVH2 in LDS (4), sign-ordered 4-wide in LDS (5)
 template <bool COUNT, int BLOCK, int LMODE, typename STK>
 TRG_DEV void trav_inner_step(const SceneView &sc, Trav &tv, STK stk, Counters &cnt) {
-    if (LMODE == 5) trav_node4_step_lds<COUNT, BLOCK>(sc, tv, stk, cnt, (uint32_t)(uintptr_t)(const lds_v4f_t *)sc.nodes + 144u);
+    if (LMODE == 6) tv.node = kNodeDone;   // the octant-threaded layout is walked by traverse() only: the pool / wavefront / pair loops trace nothing in that (experimental) build
+    else if (LMODE == 5) trav_node4_step_lds<COUNT, BLOCK>(sc, tv, stk, cnt, (uint32_t)(uintptr_t)(const lds_v4f_t *)sc.nodes + 144u);
     else trav_node_step<COUNT, BLOCK, LMODE>(sc, tv, stk, cnt);
 }
 
@@ -899,7 +916,7 @@ TRG_DEV void trav_step_wide(const SceneView &sc, Trav &tv, bool any, STK stk, Co
 // LDS address of the node array when the traversal reads sign-ordered LDS nodes (UNIFIED = false selects the LDS schedule)
 template <bool UNIFIED>
 TRG_DEV uint32_t lds_node_base(const SceneView &sc) {
-    return (!UNIFIED && (TRG_TRAV_LDS == 4 || TRG_TRAV_LDS == 5)) ? (uint32_t)(uintptr_t)(const lds_v4f_t *)sc.nodes : 0u;
+    return (!UNIFIED && (TRG_TRAV_LDS == 4 || TRG_TRAV_LDS == 5 || TRG_TRAV_LDS == 6)) ? (uint32_t)(uintptr_t)(const lds_v4f_t *)sc.nodes : 0u;
 }
 
 // Nearest-hit (ANY=false) or any-hit (ANY=true) query for one ray per lane.
@@ -915,6 +932,38 @@ TRG_DEV bool traverse(const SceneView &sc, V3 o, V3 d, float tmax_ray, uint32_t 
     constexpr int mode = UNIFIED ? TRG_TRAV_HBM : TRG_TRAV_LDS;
     if (mode == 3) {
         while (tv.node != kNodeDone) trav_step_wide<COUNT, BLOCK>(sc, tv, ANY, stk, cnt);
+    } else if (mode == 6) {
+        // Octant-threaded walk (experiment; layout: trg_capi.cpp host_scene_build): position k of this ray's octant table names an entry
+        // (one child box) and a skip link; box entered -> k + 1 (its first child, or the next sibling after a leaf), missed -> the link.
+        const uint32_t nb = lds_node_base<UNIFIED>(sc), E = sc.thr_entries;
+        const uint32_t negx = __float_as_uint(tv.idx) >> 31, negy = __float_as_uint(tv.idy) >> 31, negz = __float_as_uint(tv.idz) >> 31;
+        const uint32_t ax = nb + negx * 8u, ay = nb + 16u + negy * 8u, az = nb + 32u + negz * 8u;
+        const uint32_t otab = nb + E * 64u + (negx | (negy << 1) | (negz << 2)) * (E + 1u) * 4u;
+        uint32_t k = 0u;
+        for (;;) {
+            int leaf = 0;
+            while (k < E) {
+                const uint32_t w = (uint32_t)*(const lds_int_t *)(uintptr_t)(otab + k * 4u);
+                const uint32_t e = w & 0xFFFFu;
+                typedef float v2f __attribute__((ext_vector_type(2)));
+                typedef __attribute__((address_space(3))) v2f lds_v2f_t;
+                const v2f X = *(const lds_v2f_t *)(uintptr_t)(e + ax);
+                const v2f Y = *(const lds_v2f_t *)(uintptr_t)(e + ay);
+                const v2f Z = *(const lds_v2f_t *)(uintptr_t)(e + az);
+                const int code = *(const lds_int_t *)(uintptr_t)(e + nb + 48u);
+                if (COUNT) { if (k & 1u) cnt.nodes++; if (mbcnt64(__ballot(1)) == 0) cnt.wnodes++; }
+                const float nx = X.x * tv.idx - tv.oix, fx = X.y * tv.idx - tv.oix;
+                const float ny = Y.x * tv.idy - tv.oiy, fy = Y.y * tv.idy - tv.oiy;
+                const float nz = Z.x * tv.idz - tv.oiz, fz = Z.y * tv.idz - tv.oiz;
+                const float tmin = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));
+                const float tmax = fminf(fminf(fx, fy), min_raw(fz, tv.best));
+                const bool in = tmin <= tmax;
+                k = in ? k + 1u : (w >> 16);
+                if (in && code < 0) { leaf = code; break; }
+            }
+            if (leaf == 0) break;
+            if (trav_leaf_test<COUNT>(sc, tv, leaf, ANY, cnt)) break;   // any-hit satisfied
+        }
     } else {
         for (;;) {
             while (tv.node >= 0) trav_inner_step<COUNT, BLOCK, (mode >= 4 ? mode : 0)>(sc, tv, stk, cnt);

@@ -48,6 +48,7 @@ struct SceneDesc {
     uint32_t lds_stage_bytes;       // bytes a workgroup stages into LDS (everything before the 4-wide nodes)
     uint32_t off_htab;              // Halton group tables (kHtabFloats floats), inside the staged region
     uint32_t off_fat, n_fat;        // leaf records of the HBM traversal: geometry + attributes, 128 bytes each, 128-byte aligned, leaf order
+    uint32_t thr_entries;           // TRG_TRAV_LDS == 6 (experiment): entries of the octant-threaded tree in the LDS node section
 };
 constexpr uint32_t kFatRecBytes = 128u;
 
@@ -188,8 +189,13 @@ static_assert(kWideHbm, "scenes in HBM are traversed through the quantised 4-wid
 #endif
 constexpr bool kSignedLds = (TRG_TRAV_LDS == 4);
 constexpr bool kWideLds = (TRG_TRAV_LDS == 5);   // sign-ordered 4-wide float nodes in LDS (160 bytes)
+// 6 (round-3 experiment, measured slower: DESIGN section 6): the BVH2 as an OCTANT-THREADED list -- one 64-byte entry per child box (its
+// slab planes in both orders per axis + the leaf code), and for each of the 8 direction octants a table of the entries in depth-first
+// near-to-far order with a skip link each (next position when the box is missed): no stack, no near / far select.  Only traverse() walks it
+// (the direct, frame-parallel and tail kernels); the pool and wavefront schedules are not available in that build.
+constexpr bool kThreadedLds = (TRG_TRAV_LDS == 6);
 constexpr uint32_t kLdsNodeBytes = kWideLds ? 160u : (kSignedLds ? 144u : 64u);
-static_assert(!(kSignedLds || kWideLds) || kWideHbm, "the LDS node layouts replace the BVH2 array: the HBM kernels must use the 4-wide tree");
+static_assert(!(kSignedLds || kWideLds || kThreadedLds) || kWideHbm, "the LDS node layouts replace the BVH2 array: the HBM kernels must use the 4-wide tree");
 
 #define TRG_DECL_LAUNCHERS(SFX)                                                                                   \
     hipError_t launch_render_##SFX(const RenderParams &p, bool lds_scene, bool counters, uint32_t grid,          \

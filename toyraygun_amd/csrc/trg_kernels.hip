@@ -48,6 +48,7 @@ TRG_DEV SceneView scene_view(const trg::SceneDesc &sc, unsigned char *smem) {
         v.htab = nullptr;
     }
     v.tex.uv = nullptr; v.tex.ids = nullptr; v.tex.table = nullptr; v.tex.texels = nullptr;
+    v.thr_entries = sc.thr_entries;
     return v;
 }
 
