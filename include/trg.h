@@ -269,6 +269,13 @@ TRG_API int trg_debug_build_bvh4(const float *positions3, const uint32_t *indice
 TRG_API int trg_debug_build_bvh4q(const float *positions3, const uint32_t *indices, const uint32_t *material_ids, uint32_t n_verts,
                                   uint32_t n_tris, uint32_t *nodes4q_out, uint32_t nodes4_cap, uint32_t *n_nodes4);
 
+/* host-only: the 128-byte leaf records an HBM-resident scene is traversed through, exactly as trg_load_scene lays them out (32 floats
+ * per record, leaf order of trg_debug_build_bvh: rows 0-2 = (v0 | original index) (e1 | mask = material id) (e2 | 0), floats 12-20 the
+ * triangle's nine normal floats, 21-29 its nine colour floats).  Pass NULL to query the count. */
+TRG_API int trg_debug_leaf_records(const float *positions3, const float *normals3, const float *colors3, const uint32_t *indices,
+                                   const uint32_t *material_ids, uint32_t n_verts, uint32_t n_tris, float *records32_out, uint32_t records_cap,
+                                   uint32_t *n_records);
+
 /* host-only: the tile (bx, by) workgroup slot `slot` of a launch over tiles_x x tiles_y tiles renders under tile order `order` (0, 1, 2, 4, 8:
  * TRG_OPT_TILE_ORDER), exactly as the kernels compute it.  Returns 1, 0 for a padding slot of an XCD-aware order (or a slot beyond the
  * launch), negative on bad arguments; *n_slots = workgroup slots of the launch.  The slots with return 1 cover every tile exactly once. */

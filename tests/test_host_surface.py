@@ -698,3 +698,35 @@ def test_every_tile_order_is_a_bijection(built):
                     left = [t[0] for t in per_xcd[0]]                 # strip left of the centre: starts at the centre column, ends at the edge
                     assert left[0] == tx // 2 - 1 and left[-1] == 0
     assert L.trg_debug_tile_of_slot(4, 4, 3, 0, None, None, None) < 0
+
+
+def test_leaf_records_carry_each_triangles_geometry_and_attributes(built, O):
+    """The 128-byte leaf records of HBM-resident scenes (round 3): every triangle exactly once, in the leaf order of the BVH; rows 0-2 the
+    geometry record (v0 | original index, e1 | material id, e2), then THAT triangle's normals and colours from the reference's
+    per-corner buffers -- checked on the lattice scene (distinct colours per cube) and on a soup with per-vertex attributes."""
+    import ctypes as C
+    from toyraygun_amd import capi
+    L = capi.load()
+    rng = np.random.default_rng(5)
+    scenes = [O.OracleScene.cornell_lattice(3).buffers()]
+    nt = 200
+    soup = dict(positions=rng.uniform(-1, 1, (3 * nt, 3)).astype(np.float32), normals=rng.normal(size=(3 * nt, 3)).astype(np.float32),
+                colors=rng.uniform(0, 1, (3 * nt, 3)).astype(np.float32), indices=rng.permutation(3 * nt).astype(np.uint32),
+                material_ids=rng.choice([1, 2, 3], nt).astype(np.uint32))
+    scenes.append(soup)
+    for b in scenes:
+        pos, nrm, col = (np.ascontiguousarray(b[k], np.float32) for k in ("positions", "normals", "colors"))
+        idx, mat = np.ascontiguousarray(b["indices"], np.uint32), np.ascontiguousarray(b["material_ids"], np.uint32)
+        n = C.c_uint32()
+        args = (pos.ctypes.data, nrm.ctypes.data, col.ctypes.data, idx.ctypes.data, mat.ctypes.data, pos.shape[0], mat.shape[0])
+        assert L.trg_debug_leaf_records(*args, None, 0, C.byref(n)) == capi.OK and n.value == mat.shape[0]
+        rec = np.zeros((n.value, 32), np.float32)
+        assert L.trg_debug_leaf_records(*args, rec.ctypes.data, n.value, C.byref(n)) == capi.OK
+        prim = rec[:, 3].view(np.uint32)
+        assert sorted(prim.tolist()) == list(range(mat.shape[0]))                       # a permutation: every triangle once
+        v = pos[idx.reshape(-1, 3)[prim]]                                                # [n, 3 corners, 3]
+        assert np.array_equal(rec[:, 0:3], v[:, 0]) and np.array_equal(rec[:, 4:7], v[:, 1] - v[:, 0]) and np.array_equal(rec[:, 8:11], v[:, 2] - v[:, 0])
+        assert np.array_equal(rec[:, 7].view(np.uint32), mat[prim])                      # the mask IS the material id
+        assert np.array_equal(rec[:, 12:21], nrm.reshape(-1, 9)[prim]) and np.array_equal(rec[:, 21:30], col.reshape(-1, 9)[prim])
+        _, tris, _ = capi.debug_build_bvh(pos, idx, mat)                                 # same order as the 48-byte records of the LDS path
+        assert np.array_equal(rec[:, :12].view(np.uint32), tris.view(np.uint32))

@@ -111,6 +111,7 @@ _SYMBOLS = [
     ("trg_debug_build_bvh4", C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("trg_debug_scene_layout", C.c_int, [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), _P]),
     ("trg_debug_xcc_ids", C.c_int, [_P, C.c_uint32, _P]),
+    ("trg_debug_leaf_records", C.c_int, [_P, _P, _P, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
     ("trg_debug_tile_of_slot", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("trg_debug_build_bvh4q", C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
 ]

@@ -1169,6 +1169,23 @@ int trg_debug_build_bvh4q(const float *positions3, const uint32_t *indices, cons
     return TRG_OK;
 }
 
+int trg_debug_leaf_records(const float *positions3, const float *normals3, const float *colors3, const uint32_t *indices, const uint32_t *material_ids,
+                           uint32_t n_verts, uint32_t n_tris, float *records32_out, uint32_t records_cap, uint32_t *n_records) {
+    if (n_tris && (!positions3 || !normals3 || !colors3 || !indices || !material_ids)) return TRG_ERR_INVALID;
+    for (size_t i = 0; i < (size_t)n_tris * 3; ++i)
+        if (indices[i] >= n_verts) return TRG_ERR_INVALID;
+    Bvh bvh;
+    build_bvh(positions3, indices, material_ids, n_tris, bvh);
+    const uint32_t nrec = (uint32_t)(bvh.tris.size() / 3);
+    if (n_records) *n_records = nrec;
+    if (records32_out) {
+        if (records_cap < nrec) return TRG_ERR_RANGE;
+        for (uint32_t i = 0; i < nrec; ++i)
+            fill_fat_record(reinterpret_cast<unsigned char *>(records32_out) + (size_t)i * kFatRecBytes, &bvh.tris[(size_t)i * 3], normals3, colors3, n_tris);
+    }
+    return TRG_OK;
+}
+
 int trg_debug_tile_of_slot(uint32_t tiles_x, uint32_t tiles_y, uint32_t order, uint32_t slot, uint32_t *n_slots, uint32_t *bx, uint32_t *by) {
     if (tiles_x == 0 || tiles_y == 0 || (order != 0 && order != 1 && order != 2 && order != 4 && order != 8)) return TRG_ERR_INVALID;
     const uint64_t slots = tile_slots(tiles_x, tiles_y, order);
