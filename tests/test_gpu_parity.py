@@ -1446,6 +1446,18 @@ def test_textured_scene_parity(capi, O, nu, nv, in_lds):
         c.render(0, spp, bnc)
         rmse, frac_ok, worst = image_metrics(c.read_accum(), ref_lib)
         assert rmse <= TOL_RMSE and frac_ok >= TOL_FRAC, (rmse, frac_ok, worst)
+        # the same scene and textures through a device group (trg_group_load_scene builds the host scene once, trg_group_load_textures)
+        g = capi.Group([0], w, h)
+        try:
+            g.load_scene(b["positions"], b["normals"], b["colors"], b["indices"], b["material_ids"])
+            g.load_textures(uvs, ids, imgs)
+            g.set_uniforms(O.uniforms_bytes(O.make_uniforms(w, h)))
+            g.set_pixel_offsets_seed()
+            g.set_option(capi.OPT_STRICT, 1)
+            g.render(0, spp, bnc, gather=capi.GATHER_ALL)
+            assert np.array_equal(_bits(g.read_accum(0)), _bits(ref)) and g.stats().rays == rst.rays
+        finally:
+            g.close()
         # removing the textures restores the untextured picture; a scene reload drops them too
         c.load_textures(uvs, ids, [])
         c.set_option(capi.OPT_STRICT, 1)
