@@ -29,6 +29,7 @@ public:
 
     // ---- beyond the reference: several GPUs of one node.  Call before init(): the frame is then sharded by row bands over the
     //      devices (trg_group_*, include/trg.h) and gathered on the first one, which presents / reads back / writes the PNG.
+    //      One device is a group of one (the same calls, nothing to exchange).
     bool setDevices(const int *devices, int count);
     int getDeviceCount() const { return m_deviceCount; }
 

@@ -1545,6 +1545,37 @@ def test_async_frames_keep_their_uniforms(capi, O, cornell):
         c.close()
 
 
+def test_plugin_on_a_device_group(capi, O):
+    """HipRenderer::setDevices: the plugin on a device group (trg_group_*), also a group of one -- the frame loop then goes through
+    trg_group_fence_wait / trg_group_render / trg_group_fence_record, the scene through trg_group_load_scene and the textures
+    through trg_group_load_textures.  Same frames as the plain renderer bit for bit: the asynchronous loop with a camera move in
+    the middle (coalesced launches, three in flight), an HBM scene built on the device, and a textured scene."""
+    from toyraygun_amd import host
+    w, h, fa, fb, bnc = 320, 240, 9, 7, 3
+    eye_b = (0.3, 1.1, 3.0)
+    plain, launches_plain = host.async_camera_move(w, h, fa, fb, eye_b, bnc)
+    grouped, launches = host.async_camera_move(w, h, fa, fb, eye_b, bnc, devices=[0])
+    assert 2 <= launches <= fa + fb
+    assert np.array_equal(_bits(grouped), _bits(plain))
+    lattice = host.Scene.cornell_lattice(12)     # 20,772 triangles: lives in HBM
+    ref, _ = host.render_scene(lattice, 160, 120, 4, 3)
+    for builder in (0, 1):
+        got, _ = host.render_scene(lattice, 160, 120, 4, 3, device_build=builder, devices=[0])
+        assert np.array_equal(_bits(got), _bits(ref)), builder
+    v, n, col, tris = _uv_sphere(12, 8, 0.33, (0.25, 1.1, 0.15))
+    uv = np.array([[p, t] for t in np.linspace(0.0, 1.0, 9) for p in np.linspace(0.0, 3.0, 12, endpoint=False)], np.float32)
+    tex = host.Texture(rgba=_checker_texture(64, 8, (230, 60, 40), (40, 90, 220), 1))
+    hs = host.Scene.cornell_box()
+    hs.add_textured_mesh(v, n, uv, tris, np.eye(4, dtype=np.float32), (0.9, 0.9, 0.9), 1, tex)
+    a, _ = host.render_scene(hs, 160, 120, 3, 3)
+    b, _ = host.render_scene(hs, 160, 120, 3, 3, devices=[0])
+    assert np.array_equal(_bits(a), _bits(b))
+    untextured, _ = host.render_scene(host.Scene.cornell_box(), 160, 120, 3, 3, devices=[0])
+    assert not np.array_equal(_bits(b), _bits(untextured))
+    with pytest.raises(RuntimeError):
+        host.render_scene(hs, 160, 120, 1, 3, devices=[0, 0])     # a device listed twice: init() fails, nothing is rendered
+
+
 # ------------------------------------------------------------------ round 3: tile order, leaf records
 @pytest.mark.parametrize("force_global", [0, 1])
 def test_tile_order_never_changes_the_image(capi, O, cornell, force_global):

@@ -29,7 +29,7 @@ bool HipRenderer::setDevices(const int *devices, int count) {
 bool HipRenderer::init() {
     Renderer::init();  // width/height/aspect from the Engine (Renderer.cpp:18-27)
     destroy();
-    if (m_deviceCount > 1) {
+    if (m_deviceCount >= 1) {   // setDevices() was called: a device group, also for one device (same calls, nothing to exchange)
         const int rc = trg_group_create(&m_group, m_devices, m_deviceCount, (uint32_t)m_width, (uint32_t)m_height);
         if (rc != TRG_OK) {
             printf("HipRenderer: %s\n", trg_group_last_error(nullptr));
@@ -42,7 +42,7 @@ bool HipRenderer::init() {
             return false;
         }
     } else {
-        const int dev = m_deviceCount == 1 ? m_devices[0] : Engine::instance()->getDevice();
+        const int dev = Engine::instance()->getDevice();
         const int rc = trg_create(&m_ctx, dev, (uint32_t)m_width, (uint32_t)m_height);
         if (rc != TRG_OK) {
             printf("HipRenderer: %s\n", trg_last_error(nullptr));

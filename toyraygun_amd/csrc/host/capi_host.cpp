@@ -151,12 +151,17 @@ void trh_random_texture(int w, int h, uint32_t seed, uint32_t *out) {
 
 // ---- asynchronous frame loop with a camera move in the middle: framesA x renderFrame(), setCameraPosition(eyeB), framesB x
 //      renderFrame(), read back.  Frames queued before the move must be rendered with the old camera. ----
-int trh_async_camera_move(int w, int h, int framesA, int framesB, const float *eyeB3, int bounces, int device, float *accumOut, unsigned int *launchesOut) {
+// nDevices > 0: the renderer is put on a device group first (HipRenderer::setDevices; one device is a group of one and goes through
+// the same trg_group_* calls, launch fences included).
+int trh_async_camera_move_on(int w, int h, int framesA, int framesB, const float *eyeB3, int bounces, int device, const int *devices, int nDevices,
+                             float *accumOut, unsigned int *launchesOut) {
     Engine *engine = Engine::instance();
-    engine->setDevice(device);
+    engine->setDevice(nDevices > 0 ? devices[0] : device);
     engine->init(w, h);
     HipRenderer r;
+    if (nDevices > 0 && !r.setDevices(devices, nDevices)) return -2;
     if (!r.init()) return -3;
+    if (r.getDeviceCount() != (nDevices > 0 ? nDevices : 0)) return -6;
     r.setCameraPosition(bx::Vec3(0.0f, 1.0f, 3.38f));
     r.setCameraLookAt(bx::Vec3(0.0f, 1.0f, -1.0f));
     Scene *scene = createCornellBoxScene();
@@ -171,13 +176,18 @@ int trh_async_camera_move(int w, int h, int framesA, int framesB, const float *e
     if (launchesOut) *launchesOut = r.getLaunchCount();
     return 0;
 }
+int trh_async_camera_move(int w, int h, int framesA, int framesB, const float *eyeB3, int bounces, int device, float *accumOut, unsigned int *launchesOut) {
+    return trh_async_camera_move_on(w, h, framesA, framesB, eyeB3, bounces, device, nullptr, 0, accumOut, launchesOut);
+}
 
 // ---- HipRenderer on a caller-built Scene: init, setDeviceBuild, loadScene, `frames` samples, read back ----
-int trh_render_scene(void *scene, int w, int h, int frames, int bounces, int deviceBuild, int device, float *accumOut, double *loadMsOut) {
+int trh_render_scene_on(void *scene, int w, int h, int frames, int bounces, int deviceBuild, int device, const int *devices, int nDevices,
+                        float *accumOut, double *loadMsOut) {
     Engine *engine = Engine::instance();
-    engine->setDevice(device);
+    engine->setDevice(nDevices > 0 ? devices[0] : device);
     engine->init(w, h);
     HipRenderer r;
+    if (nDevices > 0 && !r.setDevices(devices, nDevices)) return -2;
     if (!r.init()) return -3;
     if (!r.setDeviceBuild(deviceBuild)) return -2;
     r.setCameraPosition(bx::Vec3(0.0f, 1.0f, 3.38f));
@@ -189,6 +199,9 @@ int trh_render_scene(void *scene, int w, int h, int frames, int bounces, int dev
     if (!r.renderFrames((unsigned int)frames)) return -4;
     if (!r.readAccumulation(accumOut)) return -5;
     return 0;
+}
+int trh_render_scene(void *scene, int w, int h, int frames, int bounces, int deviceBuild, int device, float *accumOut, double *loadMsOut) {
+    return trh_render_scene_on(scene, w, h, frames, bounces, deviceBuild, device, nullptr, 0, accumOut, loadMsOut);
 }
 
 // ---- the reference app's call sequence (main.cpp:21-95), headless ----

@@ -16,7 +16,7 @@ _lib = None
 SYMBOL_NAMES = ["trh_scene_new", "trh_scene_cornell", "trh_scene_lattice", "trh_scene_free", "trh_scene_add", "trh_scene_add_mesh", "trh_scene_add_mesh_colors", "trh_scene_add_obj", "trh_texture_load", "trh_texture_from_rgba",
                 "trh_texture_info", "trh_texture_copy", "trh_texture_free", "trh_scene_add_textured_mesh", "trh_scene_add_obj_textured", "trh_scene_copy_textures", "trh_scene_texture_handles",
                 "trh_scene_counts", "trh_scene_copy", "trh_mtx_srt", "trh_mtx_inverse", "trh_uniforms",
-                "trh_random_texture", "trh_run_app", "trh_async_camera_move", "trh_render_scene"]
+                "trh_random_texture", "trh_run_app", "trh_async_camera_move", "trh_async_camera_move_on", "trh_render_scene", "trh_render_scene_on"]
 
 
 def load():
@@ -64,6 +64,10 @@ def load():
         L.trh_async_camera_move.restype = C.c_int
         L.trh_render_scene.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, F, C.POINTER(C.c_double)]
         L.trh_render_scene.restype = C.c_int
+        L.trh_async_camera_move_on.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, F, C.c_int, C.c_int, C.c_void_p, C.c_int, F, C.POINTER(C.c_uint)]
+        L.trh_async_camera_move_on.restype = C.c_int
+        L.trh_render_scene_on.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, F, C.POINTER(C.c_double)]
+        L.trh_render_scene_on.restype = C.c_int
         _lib = L
     return _lib
 
@@ -231,22 +235,31 @@ def random_texture(w, h, seed=capi.SEED_OFFSETS):
     return out
 
 
-def async_camera_move(w, h, frames_a, frames_b, eye_b, bounces=3, device=0):
-    """HipRenderer: frames_a x renderFrame(), setCameraPosition(eye_b), frames_b x renderFrame(); returns (accum, launches)."""
+def _device_list(devices):
+    d = np.ascontiguousarray(devices if devices is not None else [], np.int32)
+    return d, (d.ctypes.data if d.size else None), int(d.size)
+
+
+def async_camera_move(w, h, frames_a, frames_b, eye_b, bounces=3, device=0, devices=None):
+    """HipRenderer: frames_a x renderFrame(), setCameraPosition(eye_b), frames_b x renderFrame(); returns (accum, launches).
+    devices: a list of HIP devices -> HipRenderer::setDevices (a device group, also for one device)."""
     acc = np.zeros((h, w, 4), np.float32)
     e = _f32(eye_b)
     n = C.c_uint()
-    rc = load().trh_async_camera_move(w, h, frames_a, frames_b, e.ctypes.data, bounces, device, acc.ctypes.data, C.byref(n))
+    d, dp, dn = _device_list(devices)
+    rc = load().trh_async_camera_move_on(w, h, frames_a, frames_b, e.ctypes.data, bounces, device, dp, dn, acc.ctypes.data, C.byref(n))
     if rc != 0:
         raise RuntimeError("trh_async_camera_move failed at step %d" % rc)
     return acc, n.value
 
 
-def render_scene(scene, w, h, frames, bounces=3, device_build=0, device=0):
-    """HipRenderer on a host.Scene: setDeviceBuild(device_build), loadScene, `frames` samples; returns (accum[h,w,4], load ms)."""
+def render_scene(scene, w, h, frames, bounces=3, device_build=0, device=0, devices=None):
+    """HipRenderer on a host.Scene: setDeviceBuild(device_build), loadScene, `frames` samples; returns (accum[h,w,4], load ms).
+    devices: as in async_camera_move."""
     acc = np.zeros((h, w, 4), np.float32)
     ms = C.c_double()
-    rc = load().trh_render_scene(scene.h, w, h, frames, bounces, device_build, device, acc.ctypes.data, C.byref(ms))
+    d, dp, dn = _device_list(devices)
+    rc = load().trh_render_scene_on(scene.h, w, h, frames, bounces, device_build, device, dp, dn, acc.ctypes.data, C.byref(ms))
     if rc != 0:
         raise RuntimeError("trh_render_scene failed at step %d" % rc)
     return acc, ms.value
