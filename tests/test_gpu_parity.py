@@ -640,9 +640,37 @@ def test_continuation_bands_and_determinism(capi, O, cornell, kernel):
         c.close()
 
 
+def _rows_against_oracle(capi, O, c, scene, w, h, spp, bnc, img, rows, frac=TOL_FRAC):
+    """The full-size frame `img` of the shipped build on sampled row bands [(row0, n), ...] against the oracle within the stated
+    tolerance; then the same frame from the strict build on the same rows bit for bit.  (The oracle renders bands independently; the
+    whole frame would take it about a minute per config on the box's host threads.)"""
+    off = O.pixel_offsets(w, h)
+    acc = np.zeros((h, w, 4), np.float32)
+    for r0, n in rows:
+        O.render(scene, w, h, spp, bnc, row0=r0, rows=n, accum=acc, offsets=off)
+    got = np.concatenate([img[r0:r0 + n] for r0, n in rows])
+    ref = np.concatenate([acc[r0:r0 + n] for r0, n in rows])
+    rmse, frac_ok, worst = image_metrics(got, ref)
+    assert rmse <= TOL_RMSE and frac_ok >= frac, (rmse, frac_ok, worst)
+    O.set_trig_mode(O.TRIG_PORTABLE)
+    try:
+        acc[:] = 0
+        for r0, n in rows:
+            O.render(scene, w, h, spp, bnc, row0=r0, rows=n, accum=acc, offsets=off)
+        c.set_option(capi.OPT_STRICT, 1)
+        c.render(0, spp, bnc)
+        strict = c.read_accum()
+        for r0, n in rows:
+            assert np.array_equal(_bits(strict[r0:r0 + n]), _bits(acc[r0:r0 + n])), (r0, n)
+    finally:
+        O.set_trig_mode(O.TRIG_LIBM)
+        c.set_option(capi.OPT_STRICT, 0)
+
+
 def test_full_size_c2_properties(capi, O, cornell):
-    """Config C2 (1920x1080, 16 spp, 3 bounces) at full size: invariants of the whole frame plus an exact
-    comparison of 24 sampled rows against the oracle (the oracle renders bands independently)."""
+    """Config C2 (1920x1080, 16 spp, 3 bounces) at full size: invariants of the whole frame, and the WHOLE frame against the oracle
+    (all 1080 rows, 33 M paths; the oracle on the box's host threads needs a few seconds): the shipped build within the stated
+    tolerance, the strict build bit for bit with the oracle's ray counts."""
     w, h, spp, bnc = 1920, 1080, 16, 3
     c = make_ctx(O, cornell, w, h)
     try:
@@ -660,15 +688,19 @@ def test_full_size_c2_properties(capi, O, cornell):
         ys, _ = np.where((img[..., :3] == 1.0).all(-1))
         assert ys.size > 1000 and ys.min() > h // 2
         off = O.pixel_offsets(w, h)
-        acc = np.zeros((h, w, 4), np.float32)
-        rows = [(40, 8), (536, 8), (1000, 8)]
-        for r0, n in rows:
-            O.render(cornell, w, h, spp, bnc, row0=r0, rows=n, accum=acc, offsets=off)
-        got = np.concatenate([img[r0:r0 + n] for r0, n in rows])
-        ref = np.concatenate([acc[r0:r0 + n] for r0, n in rows])
-        rmse, frac_ok, worst = image_metrics(got, ref)
+        ref, _ = O.render(cornell, w, h, spp, bnc, offsets=off)
+        rmse, frac_ok, worst = image_metrics(img, ref)
         assert rmse <= TOL_RMSE and frac_ok >= TOL_FRAC, (rmse, frac_ok, worst)
+        O.set_trig_mode(O.TRIG_PORTABLE)
+        ref, rst = O.render(cornell, w, h, spp, bnc, offsets=off)
+        c.set_option(capi.OPT_STRICT, 1)
+        c.reset_stats()
+        c.render(0, spp, bnc)
+        assert np.array_equal(_bits(c.read_accum()), _bits(ref))
+        gs = c.stats()
+        assert (gs.primary_rays, gs.bounce_rays, gs.shadow_rays) == (rst.primary_rays, rst.bounce_rays, rst.shadow_rays)
     finally:
+        O.set_trig_mode(O.TRIG_LIBM)
         c.close()
 
 
@@ -691,15 +723,7 @@ def test_full_size_c3_and_c5_properties(capi, O, cornell):
         c.render(0, 100, bnc)
         c.render(100, spp - 100, bnc)
         assert np.array_equal(_bits(c.read_accum()), _bits(img))
-        off = O.pixel_offsets(w, h)
-        acc = np.zeros((h, w, 4), np.float32)
-        rows = [(300, 2), (700, 2)]
-        for r0, n in rows:
-            O.render(cornell, w, h, spp, bnc, row0=r0, rows=n, accum=acc, offsets=off)
-        got = np.concatenate([img[r0:r0 + n] for r0, n in rows])
-        ref = np.concatenate([acc[r0:r0 + n] for r0, n in rows])
-        rmse, frac_ok, worst = image_metrics(got, ref)
-        assert rmse <= TOL_RMSE and frac_ok >= TOL_FRAC, (rmse, frac_ok, worst)
+        _rows_against_oracle(capi, O, c, cornell, w, h, spp, bnc, img, [(300, 2), (700, 2), (1040, 2)])
     finally:
         c.close()
     # ---- C5
@@ -716,11 +740,8 @@ def test_full_size_c3_and_c5_properties(capi, O, cornell):
             row0, rows = band_rows(h, 8, r)
             c.render(0, spp, bnc, row0, rows)
         assert np.array_equal(_bits(c.read_accum()), _bits(full)) and c.stats().rays == st.rays
-        off = O.pixel_offsets(w, h)
-        acc = np.zeros((h, w, 4), np.float32)
-        O.render(cornell, w, h, spp, bnc, row0=1079, rows=2, accum=acc, offsets=off)   # straddles the band 3 / band 4 boundary
-        rmse, frac_ok, worst = image_metrics(full[1079:1081], acc[1079:1081])
-        assert rmse <= TOL_RMSE and frac_ok >= TOL_FRAC, (rmse, frac_ok, worst)
+        # two rows across every boundary between the eight bands, and two more near the bottom and the top
+        _rows_against_oracle(capi, O, c, cornell, w, h, spp, bnc, full, [(100, 2)] + [(270 * k - 1, 2) for k in range(1, 8)] + [(2050, 2)])
     finally:
         c.close()
 
@@ -1105,15 +1126,7 @@ def test_full_size_c4_properties(capi, O):
         assert np.array_equal(_bits(c.read_accum()), _bits(img)) and c.stats().rays == st.rays
         # sampled rows against the oracle (walks its own median-split BVH)
         scene = O.OracleScene.cornell_lattice(44)
-        off = O.pixel_offsets(w, h)
-        acc = np.zeros((h, w, 4), np.float32)
-        rows = [(200, 2), (540, 2), (900, 2)]
-        for r0, n in rows:
-            O.render(scene, w, h, spp, bnc, row0=r0, rows=n, accum=acc, offsets=off)
-        got = np.concatenate([img[r0:r0 + n] for r0, n in rows])
-        ref = np.concatenate([acc[r0:r0 + n] for r0, n in rows])
-        rmse, frac_ok, worst = image_metrics(got, ref)
-        assert rmse <= TOL_RMSE and frac_ok >= TOL_FRAC_C4, (rmse, frac_ok, worst)
+        _rows_against_oracle(capi, O, c, scene, w, h, spp, bnc, img, [(r0, 2) for r0 in (60, 200, 340, 540, 700, 900, 1030)], TOL_FRAC_C4)
     finally:
         c.close()
 
