@@ -516,6 +516,7 @@ struct SceneView {
     const float *htab;      // Halton group tables in LDS (trg_kernels.h kHtab), or nullptr
     trg::TexDesc tex;       // albedo textures in global memory (tex.uv == nullptr: none)
     uint32_t thr_entries;   // TRG_TRAV_LDS == 6: entries of the octant-threaded tree behind `nodes`
+    uint32_t rec_delta;     // HBM scene: byte distance from `nodes` to `tris` (the records follow the nodes in the blob)
 };
 struct Hit { float t; int prim; float u, v; };  // u, v = Moeller-Trumbore weights of vertex 1 and 2; prim = original index (LDS scene) or leaf record (HBM scene)
 struct Counters { uint32_t nodes, tris, wnodes, wtris; };  // per-lane work and wave-level iterations (first active lane counts)
@@ -540,8 +541,9 @@ TRG_DEV bool tri_test(const v4f a, const v4f b, const v4f c, V3 o, V3 d, float t
 // buffer: the 4-wide tree can need 3 x depth entries in the worst case, typical rays need about a dozen,
 // and LDS spent on never-used levels is occupancy lost.
 // The stack pointer a traversal carries is opaque: stk.first() is the empty stack, it moves by STK::unit per entry.
-// Without overflow it IS the LDS byte address of the next free entry (unit = BLOCK ints), so push and pop are a bare
-// ds_write_b32 / ds_read_b32 with no address arithmetic; with overflow it is the level index.
+// It IS the LDS byte address of the next free entry (unit = BLOCK ints), so push and pop are a bare ds_write_b32 / ds_read_b32
+// with no address arithmetic; with overflow one compare against a wave-uniform limit tells the levels that live in the scratch
+// (whose index is then recovered from the address: rare).
 typedef __attribute__((address_space(3))) int lds_int_t;
 constexpr int kNodeDone = (int)0x80000000;  // "traversal finished" marker in the node register (never a valid leaf code)
 // Level 0 of every stack holds a permanent SENTINEL (kNodeDone, written once per thread by init()): a traversal starts with its
@@ -553,23 +555,26 @@ struct LdsStackT {
     int *overflow;     // global scratch for the levels beyond klds (wave-uniform: stays in SGPRs), or nullptr
     uint32_t gcol;     // this thread's column in the scratch: workgroup * BLOCK + thread
     uint32_t gstride;  // elements between consecutive overflow levels
-    int klds;          // levels held in LDS (level 0 = the sentinel)
-    static constexpr int unit = OVERFLOW ? 1 : BLOCK * 4;
+    uint32_t lim;      // LDS byte address of level klds of thread 0's column (wave-uniform).  A column is BLOCK * 4 bytes wide, so for
+                       // every thread `sp >= lim` <=> level >= klds, and (sp - lim) / (BLOCK * 4) is the level's index in the scratch
+    static constexpr int unit = BLOCK * 4;
     TRG_DEV void set(unsigned char *smem, uint32_t stack_off, int *ovf, uint32_t klds_) {
-        lds = (uint32_t)(uintptr_t)(lds_int_t *)(reinterpret_cast<int *>(smem + stack_off) + threadIdx.x);
-        overflow = ovf; gcol = blockIdx.x * BLOCK + threadIdx.x; gstride = gridDim.x * BLOCK; klds = (int)klds_;
+        const uint32_t col0 = (uint32_t)(uintptr_t)(lds_int_t *)reinterpret_cast<int *>(smem + stack_off);
+        lds = col0 + threadIdx.x * 4u;
+        overflow = ovf; gcol = blockIdx.x * BLOCK + threadIdx.x; gstride = gridDim.x * BLOCK; lim = col0 + klds_ * (uint32_t)(BLOCK * 4);
         *(lds_int_t *)(uintptr_t)lds = kNodeDone;   // the sentinel at level 0
     }
-    TRG_DEV int first() const { return OVERFLOW ? 1 : (int)lds + BLOCK * 4; }
+    TRG_DEV int first() const { return (int)lds + BLOCK * 4; }
     TRG_DEV void push(int sp, int v) {
-        if (!OVERFLOW) *(lds_int_t *)(uintptr_t)(uint32_t)sp = v;
-        else if (sp < klds) *(lds_int_t *)(uintptr_t)(lds + (uint32_t)sp * (BLOCK * 4u)) = v;
-        else overflow[(size_t)((uint32_t)(sp - klds) * gstride + gcol)] = v;
+        if (!OVERFLOW || (uint32_t)sp < lim) *(lds_int_t *)(uintptr_t)(uint32_t)sp = v;
+        else overflow[(size_t)(((uint32_t)sp - lim) / (uint32_t)(BLOCK * 4) * gstride + gcol)] = v;
     }
+    // room(sp, n): the n entries from sp on are all in LDS; put(): a bare LDS store for such an entry (the branch-free pushes of wide_select)
+    TRG_DEV bool room(int sp, int n) const { return !OVERFLOW || (uint32_t)sp + (uint32_t)(n * unit) <= lim; }
+    TRG_DEV void put(int sp, int v) { *(lds_int_t *)(uintptr_t)(uint32_t)sp = v; }
     TRG_DEV int pop(int sp) {
-        if (!OVERFLOW) return *(lds_int_t *)(uintptr_t)(uint32_t)sp;
-        if (sp < klds) return *(lds_int_t *)(uintptr_t)(lds + (uint32_t)sp * (BLOCK * 4u));
-        return overflow[(size_t)((uint32_t)(sp - klds) * gstride + gcol)];
+        if (!OVERFLOW || (uint32_t)sp < lim) return *(lds_int_t *)(uintptr_t)(uint32_t)sp;
+        return overflow[(size_t)(((uint32_t)sp - lim) / (uint32_t)(BLOCK * 4) * gstride + gcol)];
     }
 };
 
@@ -723,8 +728,9 @@ TRG_DEV bool trav_tri_math(const v4f a, const v4f b, const v4f c, Trav &tv, bool
     const int prim = __float_as_int(a.w);
     bool take;
     if (REC) {
-        take = ok && (any || !tv.found || t < tv.best);
-        if (ok && !any && tv.found && t == tv.best) take = prim < __float_as_int(recs[(size_t)(uint32_t)tv.hit.prim * kRecV4].w);
+        const bool closer = any || !tv.found || t < tv.best;
+        take = ok && closer;
+        if (ok && !closer && t == tv.best) take = prim < __float_as_int(recs[(size_t)(uint32_t)tv.hit.prim * kRecV4].w);
     } else {
         take = ok && (any || !tv.found || t < tv.best || (t == tv.best && prim < tv.hit.prim));
     }
@@ -800,12 +806,23 @@ TRG_DEV void wide_select(float t0, float t1, float t2, float t3, int c0, int c1,
     TRG_CSWAP(t0, c0, t1, c1) TRG_CSWAP(t2, c2, t3, c3) TRG_CSWAP(t0, c0, t2, c2) TRG_CSWAP(t1, c1, t3, c3) TRG_CSWAP(t1, c1, t2, c2)
     const bool h4 = t3 < INFINITY, h3 = t2 < INFINITY, h2 = t1 < INFINITY, h0 = !(t0 < INFINITY);  // sorted: t_k finite <=> more than k hits
     int sp = tv.sp;
-    if (h4) stk.push(sp, c3);
-    sp += h4 ? STK::unit : 0;
-    if (h3) stk.push(sp, c2);
-    sp += h3 ? STK::unit : 0;
-    if (h2) stk.push(sp, c1);
-    sp += h2 ? STK::unit : 0;
+    if (stk.room(sp, 3)) {
+        // the slots above the top are scratch: store the three candidates where they would go and keep what was entered -- no
+        // branch, no per-push bounds test (a store at an unchanged sp is overwritten by the next one: LDS stores of a wave stay in order)
+        stk.put(sp, c3);
+        sp += h4 ? STK::unit : 0;
+        stk.put(sp, c2);
+        sp += h3 ? STK::unit : 0;
+        stk.put(sp, c1);
+        sp += h2 ? STK::unit : 0;
+    } else {   // within three entries of the end of the LDS levels: entry by entry, the deeper ones go to the scratch in memory
+        if (h4) stk.push(sp, c3);
+        sp += h4 ? STK::unit : 0;
+        if (h3) stk.push(sp, c2);
+        sp += h3 ? STK::unit : 0;
+        if (h2) stk.push(sp, c1);
+        sp += h2 ? STK::unit : 0;
+    }
     int next = c0;
     if (h0) {
         sp -= STK::unit;
@@ -838,7 +855,7 @@ TRG_DEV void trav_node4_math(const v4f q0, const v4f q1, const v4f q2, const v4f
         const float tny = (float)((ny >> (8 * k)) & 255u) * ay + by, tfy = (float)((fy >> (8 * k)) & 255u) * ay + by;
         const float tnz = (float)((nz >> (8 * k)) & 255u) * az + bz, tfz = (float)((fz >> (8 * k)) & 255u) * az + bz;
         const float tmin = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
-        const float tmax = fminf(fminf(tfx, tfy), fminf(tfz, tv.best));
+        const float tmax = fminf(fminf(tfx, tfy), min_raw(tfz, tv.best));   // (min_raw: trav_node_step_signed)
         // +inf = not entered.  An unused slot decodes to the inverted box (255, 0) and can never pass, so the child word
         // needs no check of its own (-4 % on C4)
         t[k] = (tmin <= tmax) ? tmin : INFINITY;
@@ -884,7 +901,10 @@ TRG_DEV void trav_step_wide(const SceneView &sc, Trav &tv, bool any, STK stk, Co
     const bool inner = tv.node >= 0;
     const uint32_t code = (uint32_t)~tv.node;
     const uint32_t first = code >> 3, left = code & 7u;
-    const v4f *ptr = inner ? sc.nodes + (size_t)tv.node * 4 : sc.tris + (size_t)first * kRecV4;
+    // one wave-uniform base + a 32-bit byte offset per lane (the scene blob is below 4 GiB and the records follow the nodes in it):
+    // the loads take the SGPR-base form, no 64-bit address arithmetic per lane
+    const uint32_t off = inner ? (uint32_t)tv.node * 64u : (code & ~7u) * (uint32_t)(kRecV4 * 16 / 8) + sc.rec_delta;
+    const v4f *ptr = reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(sc.nodes) + off);
     const v4f q0 = ptr[0], q1 = ptr[1], q2 = ptr[2];
     if (inner) {
         const v4f q3 = ptr[3];
@@ -895,7 +915,7 @@ TRG_DEV void trav_step_wide(const SceneView &sc, Trav &tv, bool any, STK stk, Co
         const bool do_pop = !stop && !more;
         const int sp = tv.sp - (do_pop ? STK::unit : 0);
         const int popped = stk.pop(sp);  // the sentinel at level 0 when nothing is pending
-        const int advanced = ~(int)(((first + 1u) << 3) | (left - 1u));
+        const int advanced = tv.node - 7;   // ~(((first + 1) << 3) | (left - 1)) for left >= 1: the next triangle of the leaf
         tv.node = stop ? kNodeDone : (more ? advanced : popped);
         tv.sp = sp;
     }

@@ -49,6 +49,7 @@ TRG_DEV SceneView scene_view(const trg::SceneDesc &sc, unsigned char *smem) {
     }
     v.tex.uv = nullptr; v.tex.ids = nullptr; v.tex.table = nullptr; v.tex.texels = nullptr;
     v.thr_entries = sc.thr_entries;
+    v.rec_delta = LDS_SCENE ? 0u : sc.off_fat - sc.off_nodes4;
     return v;
 }
 
