@@ -678,7 +678,10 @@ TRG_DEV void trav_node_step_signed(const SceneView &sc, Trav &tv, STK stk, Count
     const v4f X = *(const lds_v4f_t *)(uintptr_t)(uint32_t)(tv.node + tv.sx);
     const v4f Y = *(const lds_v4f_t *)(uintptr_t)(uint32_t)(tv.node + tv.sy);
     const v4f Z = *(const lds_v4f_t *)(uintptr_t)az_addr;
-    const int c0 = *(const lds_int_t *)(uintptr_t)(az_addr + 16u), c1 = *(const lds_int_t *)(uintptr_t)(az_addr + 20u);
+    typedef int v2i_t __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) v2i_t lds_v2i_t;
+    const v2i_t cc = *(const lds_v2i_t *)(uintptr_t)(az_addr + 16u);   // the child pair as ONE 8-byte read (2 LDS cycles; as ds_read2_b32: 4)
+    const int c0 = cc.x, c1 = cc.y;
     const float anx = X.x * tv.idx - tv.oix, afx = X.y * tv.idx - tv.oix, bnx = X.z * tv.idx - tv.oix, bfx = X.w * tv.idx - tv.oix;
     const float any_ = Y.x * tv.idy - tv.oiy, afy = Y.y * tv.idy - tv.oiy, bny = Y.z * tv.idy - tv.oiy, bfy = Y.w * tv.idy - tv.oiy;
     const float anz = Z.x * tv.idz - tv.oiz, afz = Z.y * tv.idz - tv.oiz, bnz = Z.z * tv.idz - tv.oiz, bfz = Z.w * tv.idz - tv.oiz;
