@@ -114,6 +114,9 @@ enum trg_option {
                                  it away from the image centre, so that an L2 serves the rays of one screen region (C4: 37 % less memory-side
                                  traffic, L2 hit rate 81 -> 86 %, but 14 % MORE time: the regions differ in cost and the dispatcher deals the
                                  XCDs their workgroups strictly in turn); -1 (default): image columns */
+    TRG_OPT_STACK_LDS_LEVELS = 13, /* scenes in HBM: levels of a thread's traversal stack kept in LDS (2..12, default 12; level 0 is the
+                                 sentinel); deeper levels live in a per-launch scratch in memory.  Never changes the image: a knob for
+                                 testing the scratch path and for trading LDS against it */
     TRG_OPT_FRAME_SPLIT = 7   /* TRG_KERNEL_DIRECT only: frame lanes per workgroup. 1: a pixel's frames run one after the other in one
                                  lane; 2 or 4: that many wavefronts share a pixel's frames (same result bit for bit; fills the chip
                                  when the pixel grid alone does not -- small windows, row bands of a multi-GPU job);

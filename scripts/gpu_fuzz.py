@@ -31,7 +31,7 @@ for case in range(cases):
     spp, bnc = int(rng.integers(1, 41)) if rng.random() < 0.25 else int(rng.integers(1, 9)), int(rng.integers(0, 7))
     opts = dict(force_global=int(rng.integers(0, 2)), fsplit=int(rng.choice([0, 1, 2, 4])), gpu_build=int(rng.integers(0, 4)) if s.ntris >= 2 else 0,
                 kernel=int(rng.choice([0, 0, 0, 1, 2])), in_flight=int(rng.choice([1, 4])), counters=int(rng.integers(0, 2)),
-                regen=int(rng.choice([-1, 0, 1])), tail=int(rng.choice([-1, 0, 1, 2])), tile_order=int(rng.choice([-1, 0, 1, 2, 4, 8])))
+                regen=int(rng.choice([-1, 0, 1])), tail=int(rng.choice([-1, 0, 1, 2])), tile_order=int(rng.choice([-1, 0, 1, 2, 4, 8])), stack_levels=int(rng.choice([12, 12, 2, 3, 6])))
     off = O.pixel_offsets(w, h, seed=int(rng.integers(1, 2 ** 31)))
     O.set_trig_mode(O.TRIG_LIBM if FAST else O.TRIG_PORTABLE)
     ref, rst = O.render(s, w, h, spp, bnc, offsets=off)
@@ -52,6 +52,7 @@ for case in range(cases):
         c.set_option(capi.OPT_REGEN, opts["regen"])
         c.set_option(capi.OPT_TAIL_BOUNCE, opts["tail"])
         c.set_option(capi.OPT_TILE_ORDER, opts["tile_order"])
+        c.set_option(capi.OPT_STACK_LDS_LEVELS, opts["stack_levels"])
         split = int(rng.integers(0, spp + 1))
         if split:
             c.render(0, split, bnc)

@@ -1625,6 +1625,44 @@ def test_tile_order_never_changes_the_image(capi, O, cornell, force_global):
             c.close()
 
 
+@pytest.mark.parametrize("builder", [0, 2])
+def test_stack_levels_in_lds_never_change_the_image(capi, O, builder):
+    """TRG_OPT_STACK_LDS_LEVELS: an HBM-resident scene keeps the first levels of a thread's traversal stack in LDS and the deeper ones in a
+    per-launch scratch in memory; where the line is drawn is a question of time only.  With 2 (everything but the sentinel in memory),
+    3, 5 and the default 12 levels in LDS a 3,000-triangle soup (host SAH and the deeper LBVH tree) gives the oracle's strict image and
+    ray counts bit for bit in the lock-step, frame-lane, regeneration and wavefront schedules -- the scratch path is otherwise only
+    reached by the few rays that hold more than eleven pending nodes."""
+    soup = _random_soup(O, 3000, 5)
+    w, h, spp, bnc = 96, 64, 3, 4
+    off = O.pixel_offsets(w, h)
+    O.set_trig_mode(O.TRIG_PORTABLE)
+    try:
+        ref, rst = O.render(soup, w, h, spp, bnc, offsets=off)
+    finally:
+        O.set_trig_mode(O.TRIG_LIBM)
+    b = soup.buffers()
+    c = capi.Context(w, h)
+    try:
+        c.set_option(capi.OPT_GPU_BUILD, builder)
+        c.load_scene(b["positions"], b["normals"], b["colors"], b["indices"], b["material_ids"])
+        assert c.stats().scene_in_lds == 0
+        c.set_uniforms(O.uniforms_bytes(O.make_uniforms(w, h)))
+        c.set_pixel_offsets(off)
+        c.set_option(capi.OPT_STRICT, 1)
+        for levels in (2, 3, 5, 12):
+            c.set_option(capi.OPT_STACK_LDS_LEVELS, levels)
+            for kernel, fsplit, regen in ((capi.KERNEL_DIRECT, 1, 0), (capi.KERNEL_DIRECT, 2, 0), (capi.KERNEL_DIRECT, 1, 1), (capi.KERNEL_DIRECT, 2, 1), (capi.KERNEL_WAVEFRONT, 1, 0)):
+                c.set_option(capi.OPT_KERNEL, kernel); c.set_option(capi.OPT_FRAME_SPLIT, fsplit); c.set_option(capi.OPT_REGEN, regen)
+                c.reset_stats()
+                c.render(0, spp, bnc)
+                assert np.array_equal(_bits(c.read_accum()), _bits(ref)) and c.stats().rays == rst.rays, (levels, kernel, fsplit, regen)
+        for bad in (1, 13):
+            with pytest.raises(capi.TrgError):
+                c.set_option(capi.OPT_STACK_LDS_LEVELS, bad)
+    finally:
+        c.close()
+
+
 def test_workgroups_are_dealt_round_robin_over_the_xcds(capi, O, cornell):
     """What the XCD-aware tile orders rely on for SPEED (never for results, and the default order does not use it): workgroup b of a launch
     runs on XCD (b + k) % 8 for one k per launch (MI355X_MICROARCH.md, workgroup dispatch).  Read back from HW_REG_XCC_ID.  The ids must

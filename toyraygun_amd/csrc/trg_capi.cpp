@@ -60,6 +60,7 @@ struct trg_ctx {
     uint32_t last_regen = 0;
     int opt_tail_levels = 0;   // TRG_OPT_TAIL_LEVELS: 0 = re-compact every second bounce after K, 1 = once at K only
     int opt_in_flight = 1;  // launches of this context the caller keeps in flight (TRG_OPT_LAUNCHES_IN_FLIGHT)
+    int opt_stack_levels = (int)TRG_STACK_LDS_LEVELS;   // TRG_OPT_STACK_LDS_LEVELS
     int opt_tile_order = -1;   // TRG_OPT_TILE_ORDER: -1 auto, 0 image columns centre-out, 1 / 2 / 4 / 8 XCD regions with that many column strips
     uint32_t last_xcd_cols = 0;
     double last_build_ms = 0.0;
@@ -166,7 +167,7 @@ static bool plan_lds_as(const trg_ctx *c, LdsPlan &p, bool lds_scene, bool pool,
         p.klds = levels;
     } else {
         levels = kWideHbm ? 3 * c->bvh_depth4 + 3 : c->bvh_depth + 3;  // the sentinel at level 0; 4-wide: up to three pending entries per level
-        p.klds = std::min(levels, kStackLdsLevels);
+        p.klds = std::min(levels, (uint32_t)c->opt_stack_levels);
     }
     p.overflow_levels = levels - p.klds;
     // the pool kernel does not use the Halton group tables at the end of the staged region: it stages (and pays for) less
@@ -1040,6 +1041,10 @@ int trg_set_option(trg_ctx *c, int option, int64_t value) {
     case TRG_OPT_REGEN:
         if (value < -1 || value > 1) return fail(c, TRG_ERR_INVALID, "trg_set_option: regeneration must be -1 (auto), 0 (off) or 1 (on)");
         c->opt_regen = (int)value;
+        break;
+    case TRG_OPT_STACK_LDS_LEVELS:
+        if (value < 2 || value > (int64_t)kStackLdsLevels) return fail(c, TRG_ERR_INVALID, "trg_set_option: 2..%u stack levels in LDS", kStackLdsLevels);
+        c->opt_stack_levels = (int)value;
         break;
     case TRG_OPT_TILE_ORDER:
         if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
