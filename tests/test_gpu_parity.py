@@ -362,7 +362,7 @@ def test_intersector_far_from_the_origin(capi, O, scale, shift, gpu_build):
         c.close()
 
 
-@pytest.mark.parametrize("n,seed", [(40, 11), (120, 12)])
+@pytest.mark.parametrize("n,seed", [(40, 11), (90, 12)])
 def test_lds_resident_soup_parity(capi, O, n, seed):
     """The same hostile soup small enough to be staged in LDS (sign-ordered BVH2 nodes): the intersector and the whole
     path, strict build bit-exact against the oracle, the LDS-resident and the forced-HBM (quantised 4-wide) traversal of

@@ -163,7 +163,9 @@ static bool plan_lds_as(const trg_ctx *c, LdsPlan &p, bool lds_scene, bool pool,
     if (p.lds_scene) {
         // the sentinel at level 0 + BVH2, near child first: at most one pending entry per level + the scratch slot above the top;
         // 4-wide LDS tree: up to three pending entries per level (its branch-free pushes write at most into those slots)
-        levels = kThreadedLds ? 1u : (kWideLds ? 3 * c->bvh_depth4 + 2 : c->bvh_depth + 3);   // (the threaded walk has no stack: only the sentinel level)
+        // (BVH2: leaves sit at depth <= bvh_depth, so inner nodes at depths 0 .. bvh_depth - 1 hold at most bvh_depth pending entries in levels
+        //  1 .. bvh_depth, and the step at an inner node of depth k stores its far child at level <= k + 1: bvh_depth + 1 levels are used, one is spare)
+        levels = kThreadedLds ? 1u : (kWideLds ? 3 * c->bvh_depth4 + 2 : c->bvh_depth + 2);   // (the threaded walk has no stack: only the sentinel level)
         p.klds = levels;
     } else {
         levels = kWideHbm ? 3 * c->bvh_depth4 + 3 : c->bvh_depth + 3;  // the sentinel at level 0; 4-wide: up to three pending entries per level
@@ -618,19 +620,28 @@ int host_scene_build(trg_ctx *c, const float *pos, const float *nrm, const float
             const float pz[4] = { n[2].x, n[2].y, n[2].z, n[2].w };
             int32_t ch[2];
             memcpy(ch, &n[3].x, 8);
-            for (int k = 0; k < 2; ++k)
-                if (ch[k] >= 0) ch[k] *= (int32_t)kLdsNodeBytes;
-            // X+ X- Y+ Y- at 0 / 16 / 32 / 48; Z+ at 64 and Z- at 96, each followed by the child pair (+ 8 bytes of padding)
-            const float *axes[3] = { px, py, pz };
-            const int at[3][2] = { { 0, 4 }, { 8, 12 }, { 16, 24 } };  // float index of the + and - copy
-            for (int a = 0; a < 3; ++a) {
-                const float *p = axes[a];
-                float *q = o + at[a][0], *r = o + at[a][1];
-                q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; q[3] = p[3];
-                r[0] = p[1]; r[1] = p[0]; r[2] = p[3]; r[3] = p[2];
+            for (int k = 0; k < 2; ++k) {
+                if (ch[k] >= 0) ch[k] *= (int32_t)kLdsNodeBytes;   // inner child: byte offset of its node
+                else {   // leaf child: the record index counted in 16-byte units (x 3), so that the leaf step needs no multiply
+                    const uint32_t code = ~(uint32_t)ch[k];
+                    ch[k] = (int32_t)~((((code >> 3) * 3u) << 3) | (code & 7u));
+                }
             }
-            memcpy(o + 20, ch, 8);
-            memcpy(o + 28, ch, 8);
+            // one 32-byte block [X copy | Y copy] per sign pair (sx + 2 sy) at 0 / 32 / 64 / 96 -- ONE address for both axes --, then
+            // Z+ at 128 and Z- at 160, each followed by the child pair (+ 8 bytes of padding); 192 bytes + 16 of padding
+            const float fwd[2][4] = { { px[0], px[1], px[2], px[3] }, { py[0], py[1], py[2], py[3] } };
+            const float rev[2][4] = { { px[1], px[0], px[3], px[2] }, { py[1], py[0], py[3], py[2] } };
+            for (int sy = 0; sy < 2; ++sy)
+                for (int sx = 0; sx < 2; ++sx) {
+                    float *q = o + (sx + 2 * sy) * 8;
+                    memcpy(q, sx ? rev[0] : fwd[0], 16);
+                    memcpy(q + 4, sy ? rev[1] : fwd[1], 16);
+                }
+            float *zp = o + 32, *zm = o + 40;
+            zp[0] = pz[0]; zp[1] = pz[1]; zp[2] = pz[2]; zp[3] = pz[3];
+            zm[0] = pz[1]; zm[1] = pz[0]; zm[2] = pz[3]; zm[3] = pz[2];
+            memcpy(o + 36, ch, 8);
+            memcpy(o + 44, ch, 8);
         }
     } else if (sc.n_nodes) {
         static_assert(kSignedLds || kWideLds || kLdsNodeBytes == 64u, "plain BVH2 nodes are 64 bytes");

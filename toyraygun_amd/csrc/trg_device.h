@@ -614,15 +614,15 @@ TRG_DEV void trav_begin(Trav &tv, V3 o, V3 d, float tmax, uint32_t rmask, int sp
     tv.found = false;
     tv.node = 0; tv.sp = sp0;  // sp0 = stk.first(): the empty stack
     // sign-ordered LDS nodes: LDS address of the slab copy to read per axis, for node 0 (node_base = LDS address of the
-    // node array).  X+ X- at +0 / +16, Y+ Y- at +32 / +48, Z+ Z- at +64 / +96 (each Z copy is followed by the child pair).
+    // node array; layout: trav_node_step_signed).
     if (wide_lds) {   // 4-wide LDS nodes: [lo4 | hi4 | lo4] per axis at +0 / +48 / +96, read at +16 for a negative direction
         tv.sx = (int)(node_base + ((__float_as_uint(dx) >> 31) << 4));
         tv.sy = (int)(node_base + 48u + ((__float_as_uint(dy) >> 31) << 4));
         tv.sz = (int)(node_base + 96u + ((__float_as_uint(dz) >> 31) << 4));
-    } else {
-        tv.sx = (int)(node_base + ((__float_as_uint(dx) >> 31) << 4));
-        tv.sy = (int)(node_base + 32u + ((__float_as_uint(dy) >> 31) << 4));
-        tv.sz = (int)(node_base + 64u + ((__float_as_uint(dz) >> 31) << 5));
+    } else {   // sign-ordered BVH2: the [X | Y] block of the sign pair at +0 / +32 / +64 / +96, Z+ Z- at +128 / +160
+        tv.sx = (int)(node_base + (((__float_as_uint(dx) >> 31) | ((__float_as_uint(dy) >> 31) << 1)) << 5));
+        tv.sy = 0;
+        tv.sz = (int)(node_base + 128u + ((__float_as_uint(dz) >> 31) << 5));
     }
 }
 
@@ -657,14 +657,17 @@ TRG_DEV void trav_node_math(const v4f n0, const v4f n1, const v4f n2, const v4f 
     tv.node = next; tv.sp = sp;
 }
 
-// The same step on a SIGN-ORDERED node (LDS-resident scenes, TRG_TRAV_LDS == 4).  A 144-byte node keeps, per axis,
+// The same step on a SIGN-ORDERED node (LDS-resident scenes, TRG_TRAV_LDS == 4).  A 208-byte node keeps, per axis,
 // the four slab planes of its two children twice: as (lo_a, hi_a, lo_b, hi_b) and as (hi_a, lo_a, hi_b, lo_b).  A
 // lane reads the copy that matches the sign of its ray direction (an LDS address fixed per ray, trav_begin), so
 // x = near plane, y = far plane without the 12 min/max that order them -- the values are the same floats the
-// min/max would pick (the slab product is monotonic in the plane), so hits are unchanged.  The child pair sits
-// behind BOTH Z copies, so it is read off the Z address too: three address adds per node in all.  Children are
-// byte offsets of nodes (>= 0) or leaf codes (< 0); 144 = 36 banks, so random nodes spread over 16 bank groups.
-constexpr int kSignedNodeBytes = 144;
+// min/max would pick (the slab product is monotonic in the plane), so hits are unchanged.  The X and Y copies of one
+// sign PAIR sit side by side (four 32-byte blocks), and the child pair sits behind BOTH Z copies, so a node costs two
+// address adds: one for X and Y, one for Z and the children.  Children are byte offsets of nodes (>= 0) or leaf codes
+// (< 0; the record index in them is pre-multiplied by 3 = counted in 16-byte units); 208 = 52 banks, so random nodes
+// spread over 16 bank groups.
+constexpr int kSignedNodeBytes = 208;
+constexpr int kLeafMul = (TRG_TRAV_LDS == 4) ? 1 : 3;   // float4 rows per unit of a leaf code's record index in an LDS-resident scene
 typedef __attribute__((address_space(3))) v4f lds_v4f_t;
 TRG_DEV float min_raw(float a, float b) {
     float r;
@@ -674,9 +677,9 @@ TRG_DEV float min_raw(float a, float b) {
 template <bool COUNT, int BLOCK, typename STK>
 TRG_DEV void trav_node_step_signed(const SceneView &sc, Trav &tv, STK stk, Counters &cnt) {
     if (COUNT) { cnt.nodes++; if (mbcnt64(__ballot(1)) == 0) cnt.wnodes++; }
-    const uint32_t az_addr = (uint32_t)(tv.node + tv.sz);
-    const v4f X = *(const lds_v4f_t *)(uintptr_t)(uint32_t)(tv.node + tv.sx);
-    const v4f Y = *(const lds_v4f_t *)(uintptr_t)(uint32_t)(tv.node + tv.sy);
+    const uint32_t az_addr = (uint32_t)(tv.node + tv.sz), axy_addr = (uint32_t)(tv.node + tv.sx);
+    const v4f X = *(const lds_v4f_t *)(uintptr_t)axy_addr;
+    const v4f Y = *(const lds_v4f_t *)(uintptr_t)(axy_addr + 16u);
     const v4f Z = *(const lds_v4f_t *)(uintptr_t)az_addr;
     typedef int v2i_t __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(3))) v2i_t lds_v2i_t;
@@ -759,11 +762,11 @@ template <bool COUNT>
 TRG_DEV bool trav_leaf_test(const SceneView &sc, Trav &tv, int leaf, bool any, Counters &cnt) {
     const uint32_t code = (uint32_t)~leaf;
     const uint32_t first = code >> 3, count = (code & 7u) + 1u;
-    const v4f *tr = sc.tris + first * 3;
+    const v4f *tr = sc.tris + first * kLeafMul;
     bool stop = trav_tri_math<COUNT>(tr[0], tr[1], tr[2], tv, any, cnt);
     if (!stop && count > 1u) stop = trav_tri_math<COUNT>(tr[3], tr[4], tr[5], tv, any, cnt);
     for (uint32_t k = 2; k < count && !stop; ++k) {
-        const v4f *t2 = sc.tris + (first + k) * 3;
+        const v4f *t2 = tr + k * 3;
         stop = trav_tri_math<COUNT>(t2[0], t2[1], t2[2], tv, any, cnt);
     }
     return stop;
@@ -775,11 +778,11 @@ TRG_DEV bool trav_leaf_step(const SceneView &sc, Trav &tv, bool any, STK stk, Co
     const uint32_t first = code >> 3, count = (code & 7u) + 1u;
     bool stop = false;
     {   // leaves of the host builder hold one or two triangles: those without a loop (-2 %); more only from other builders
-        const v4f *tr = sc.tris + first * 3;
+        const v4f *tr = sc.tris + first * kLeafMul;
         stop = trav_tri_math<COUNT>(tr[0], tr[1], tr[2], tv, any, cnt);
         if (!stop && count > 1u) stop = trav_tri_math<COUNT>(tr[3], tr[4], tr[5], tv, any, cnt);
         for (uint32_t k = 2; k < count && !stop; ++k) {
-            const v4f *t2 = sc.tris + (first + k) * 3;
+            const v4f *t2 = tr + k * 3;
             stop = trav_tri_math<COUNT>(t2[0], t2[1], t2[2], tv, any, cnt);
         }
     }

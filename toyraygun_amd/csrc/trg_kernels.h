@@ -19,7 +19,10 @@ constexpr int kWaves = kBlock / 64;
 static_assert(kBlock == 64 || kBlock == 128 || kBlock == 256, "workgroup must be 1, 2 or 4 wavefronts");
 constexpr int kCounterSlots = 64;  // ray counters are spread over 64 slots to avoid same-address atomics
 constexpr int kCounterWords = 8;   // primary, bounce, shadow, shaded, node_fetches, tri_tests, 2 spare
-constexpr uint32_t kMaxLdsScene = 40u * 1024u;  // scenes up to this size are staged in LDS per workgroup
+#ifndef TRG_MAX_LDS_SCENE_KB
+#define TRG_MAX_LDS_SCENE_KB 40
+#endif
+constexpr uint32_t kMaxLdsScene = TRG_MAX_LDS_SCENE_KB * 1024u;  // scenes up to this size are staged in LDS per workgroup
 // render_kernel on an HBM-resident scene: park throughput + radiance in LDS while a ray pair is traced (6 floats per thread next
 // to the 3 of the running average), and keep this many traversal-stack levels in LDS (deeper ones go to global scratch)
 #ifndef TRG_PARK_PATH
@@ -194,7 +197,7 @@ constexpr bool kWideLds = (TRG_TRAV_LDS == 5);   // sign-ordered 4-wide float no
 // near-to-far order with a skip link each (next position when the box is missed): no stack, no near / far select.  Only traverse() walks it
 // (the direct, frame-parallel and tail kernels); the pool and wavefront schedules are not available in that build.
 constexpr bool kThreadedLds = (TRG_TRAV_LDS == 6);
-constexpr uint32_t kLdsNodeBytes = kWideLds ? 160u : (kSignedLds ? 144u : 64u);
+constexpr uint32_t kLdsNodeBytes = kWideLds ? 160u : (kSignedLds ? 208u : 64u);   // (sign-ordered BVH2: 192 bytes used + 16 of padding, trg_device.h kSignedNodeBytes)
 static_assert(!(kSignedLds || kWideLds || kThreadedLds) || kWideHbm, "the LDS node layouts replace the BVH2 array: the HBM kernels must use the 4-wide tree");
 
 #define TRG_DECL_LAUNCHERS(SFX)                                                                                   \
