@@ -317,12 +317,17 @@ def run_group(args):
     from toyraygun_amd import capi
     n = args.gpus
     have = torch.cuda.device_count()
-    if have < n:
+    # TRG_BENCH_DEVICES="0,0": an explicit device list -- with TRG_GROUP_EXCHANGE=copy the contexts of a group may share a device, which
+    # rehearses this whole path (bands, host threads, exchange by peer copies, this function) on a one-GPU box; never a scaling number
+    devices = [int(x) for x in os.environ.get("TRG_BENCH_DEVICES", "").split(",") if x.strip()] or list(range(n))
+    if len(devices) != n:
+        raise SystemExit("bench.py --gpus %d: TRG_BENCH_DEVICES names %d device(s)" % (n, len(devices)))
+    if max(devices) >= have or min(devices) < 0 or (len(set(devices)) == n and have < n):
         raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (n, have))
     cfg = CONFIGS[args.config]
     W, H, SPP, BOUNCES = cfg["w"], cfg["h"], cfg["spp"], cfg["bounces"]
     buffers, uniforms = scene_buffers(cfg)
-    g = capi.Group(list(range(n)), W, H)
+    g = capi.Group(devices, W, H)
     try:
         g.load_scene(buffers["positions"], buffers["normals"], buffers["colors"], buffers["indices"], buffers["material_ids"])
         g.set_uniforms(uniforms)
@@ -351,6 +356,7 @@ def run_group(args):
         dt = timed(capi.GATHER_ALL, args.steps)
         dt_nogather = timed(capi.GATHER_NONE, args.steps)
         in_lds = bool(cst.scene_in_lds)
+        exchange = getattr(g, "exchange", capi.EXCHANGE_RCCL)
         sec = dt / args.steps
         rf = build_roofline(args.config, cst, rays_per_step, bytes_per_ray, mix, sec * 1e3, 1.0, sec * 1e3, kernel_ms_alone, None, use_imported=False)
         out = {
@@ -359,7 +365,9 @@ def run_group(args):
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["workload"], "name": args.config, "rays_per_step": rays_per_step,
-                       "sharding": "single process, trg_group: %d contexts + persistent host threads, bands of ceil(h / N) rows, one in-place ncclAllGather per frame over xGMI" % n,
+                       "sharding": "single process, trg_group: %d contexts + persistent host threads, bands of ceil(h / N) rows, %s" % (
+                           n, "one in-place ncclAllGather per frame over xGMI" if exchange == capi.EXCHANGE_RCCL else "bands exchanged by hipMemcpyPeerAsync + events (TRG_GROUP_EXCHANGE=copy or no librccl.so)"),
+                       "exchange": {capi.EXCHANGE_RCCL: "rccl", capi.EXCHANGE_COPY: "copy"}.get(exchange, "none"), "devices": devices,
                        "per_rank_rays_per_step": per_rank_rays,
                        "ms_per_step_without_gather": dt_nogather / args.steps * 1e3,
                        "gather_ms_per_step": max(0.0, (dt - dt_nogather) / args.steps * 1e3),

@@ -209,7 +209,11 @@ TRG_API int trg_fence_wait(trg_ctx *ctx, int slot);
  *     is built once and uploaded to every device.  A group of one device needs no RCCL (it is loaded with dlopen for G > 1) and no thread.
  *     NOT YET RUN ON MORE THAN ONE DEVICE: the development pool has single-GPU boxes, so n > 1 is covered by code review, the CPU
  *     rehearsals of tests/test_dist_gloo.py, and -- environment variable TRG_GROUP_FORCE_RCCL -- a group of one device that goes through
- *     RCCL all the same (dlopen, ncclCommInitAll, the in-place all-gather on the render's stream: a GPU test). */
+ *     RCCL all the same (dlopen, ncclCommInitAll, the in-place all-gather on the render's stream: a GPU test).
+ *     Environment variable TRG_GROUP_EXCHANGE=copy (also the fallback when librccl.so cannot be loaded): the bands move by
+ *     hipMemcpyPeerAsync ordered by events instead of RCCL.  Such a group needs no communicator, so its devices need not be distinct:
+ *     n contexts on ONE device run the whole n > 1 machinery (bands, host threads, uploads, fences, gather) on a single-GPU box --
+ *     the GPU tests do that for n = 2, 3 and 8 -- everything but the RCCL calls themselves. */
 typedef struct trg_group trg_group;
 enum trg_gather {
     TRG_GATHER_NONE = 0,  /* every device keeps only its own band */
@@ -221,6 +225,8 @@ TRG_API int trg_group_create(trg_group **out, const int *devices, int n, uint32_
 TRG_API void trg_group_destroy(trg_group *g);
 TRG_API const char *trg_group_last_error(trg_group *g); /* g may be NULL: error of the last failed trg_group_create */
 TRG_API int trg_group_size(trg_group *g);
+enum trg_exchange { TRG_EXCHANGE_NONE = 0, TRG_EXCHANGE_RCCL = 1, TRG_EXCHANGE_COPY = 2 };
+TRG_API int trg_group_exchange(trg_group *g);          /* how the bands travel: nothing to exchange (one device), RCCL, or peer copies */
 TRG_API trg_ctx *trg_group_ctx(trg_group *g, int rank); /* the context of one device (options, stats); owned by the group */
 TRG_API int trg_group_load_scene(trg_group *g, const float *positions3, const float *normals3, const float *colors3, const uint32_t *indices,
                                  const uint32_t *material_ids, uint32_t n_verts, uint32_t n_tris); /* replicated on every device */

@@ -7,6 +7,8 @@ tail -4 gpurun_out/r3b/pytest.log
 ( time timeout -k 10 600 python bench.py ) > gpurun_out/r3b/bench_default.json 2> gpurun_out/r3b/bench_default.err; echo "bench rc $?"
 tail -3 gpurun_out/r3b/bench_default.err
 timeout -k 10 120 python bench.py --gpus 2 --no-cpu-baseline > gpurun_out/r3b/bench_g2.out 2>&1; echo "bench --gpus 2 rc $? (expected non-zero on a one-GPU box)"; tail -2 gpurun_out/r3b/bench_g2.out
+# the same invocation rehearsed on this one GPU: 8 contexts on device 0, bands exchanged by peer copies (not a scaling number)
+TRG_GROUP_EXCHANGE=copy TRG_BENCH_DEVICES=0,0,0,0,0,0,0,0 timeout -k 10 120 python bench.py --gpus 8 --no-cpu-baseline > gpurun_out/r3b/bench_g8_rehearsal.json 2> gpurun_out/r3b/bench_g8_rehearsal.err; echo "bench --gpus 8 rehearsal rc $?"
 python - <<'PY'
 import json
 for l in open("gpurun_out/r3b/bench_default.json"):

@@ -1359,6 +1359,85 @@ def test_device_group_c_abi(capi, O, cornell, force_global):
         capi.Group([0, 0], 16, 16)
 
 
+def test_bench_single_process_group_path_rehearsed_on_one_device(capi, monkeypatch, capsys):
+    """`python bench.py --gpus N` invoked plainly (what a driver without a launcher does) takes the single-process trg_group path.  Rehearsed
+    here end to end on ONE device: TRG_BENCH_DEVICES names device 0 N times and TRG_GROUP_EXCHANGE=copy lets the contexts share it.  The JSON
+    line must come out whole, the bands' ray counts must add up to the frame's, and the value must be a real rate -- not a scaling number."""
+    import json
+    import bench
+    for k in ("RANK", "WORLD_SIZE", "MASTER_PORT", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("TRG_GROUP_EXCHANGE", "copy")
+    for n in (2, 8):
+        monkeypatch.setenv("TRG_BENCH_DEVICES", ",".join(["0"] * n))
+        bench.main(["--gpus", str(n), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+        out = json.loads([l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1])
+        cfgo = out["config"]
+        assert out["n_gpus"] == n and cfgo["exchange"] == "copy" and cfgo["devices"] == [0] * n
+        assert len(cfgo["per_rank_rays_per_step"]) == n and sum(cfgo["per_rank_rays_per_step"]) == cfgo["rays_per_step"]
+        assert 100e6 < cfgo["rays_per_step"] < 120e6 and out["value"] > 1000 and out["ms_per_step"] > 0
+        assert "bound" in out["roofline"] and cfgo["gather_ms_per_step"] >= 0
+
+
+@pytest.mark.parametrize("force_global", [0, 1])
+def test_device_group_of_several_contexts_on_one_device(capi, O, cornell, force_global, monkeypatch):
+    """The n > 1 machinery of trg_group_* on a single-GPU box: with TRG_GROUP_EXCHANGE=copy the bands travel by hipMemcpyPeerAsync ordered by
+    events instead of RCCL, a group needs no communicator, and its contexts may share a device.  Groups of 2, 3 and 8 contexts on device 0 --
+    row bands of ceil(h / n) rows (93 rows: never a multiple), one host thread per context, the scene uploaded n times, gather to all / to a
+    root / none, asynchronous frames behind group fences with the accumulation continued across launches -- give the plain context's
+    frame bit for bit on every rank that is to hold it, and the ray counters add up.  (What this does NOT run: the RCCL calls; those run
+    for one rank in test_device_group_exchange_through_rccl_on_one_device.)"""
+    monkeypatch.setenv("TRG_GROUP_EXCHANGE", "copy")
+    w, h, spp, bnc = 200, 93, 5, 3
+    ref_ctx = make_ctx(O, cornell, w, h)
+    try:
+        ref_ctx.set_option(capi.OPT_STRICT, 1)
+        ref_ctx.set_option(capi.OPT_FORCE_GLOBAL, force_global)
+        ref_ctx.reset_stats()
+        ref_ctx.render(0, spp, bnc)
+        ref, rst = ref_ctx.read_accum(), ref_ctx.stats()
+    finally:
+        ref_ctx.close()
+    b = cornell.buffers()
+    for n in (2, 3, 8):
+        g = capi.Group([0] * n, w, h)
+        try:
+            assert g.n == n and g.exchange == capi.EXCHANGE_COPY
+            g.load_scene(b["positions"], b["normals"], b["colors"], b["indices"], b["material_ids"])
+            g.set_uniforms(O.uniforms_bytes(O.make_uniforms(w, h)))
+            g.set_pixel_offsets_seed()
+            g.set_option(capi.OPT_STRICT, 1)
+            g.set_option(capi.OPT_FORCE_GLOBAL, force_global)
+            for mode, root in ((capi.GATHER_ALL, 0), (capi.GATHER_ROOT, n - 1), (capi.GATHER_NONE, 0)):
+                g.reset_stats()
+                g.render(0, spp, bnc, gather=mode, root=root)
+                g.sync()
+                assert g.stats().rays == rst.rays
+                for r in (range(n) if mode == capi.GATHER_ALL else ([root] if mode == capi.GATHER_ROOT else [])):
+                    assert np.array_equal(_bits(g.read_accum(r)), _bits(ref)), (n, mode, r)
+                for r in range(n):
+                    r0, nr = capi.band_rows(h, n, r)
+                    assert np.array_equal(_bits(g.read_accum(r)[r0:r0 + nr]), _bits(ref[r0:r0 + nr])), (n, mode, r, "own band")
+            # asynchronous: two launches that continue one accumulation, each followed by its exchange, three in flight behind fences
+            g.set_option(capi.OPT_TIMING, 0)
+            for rep in range(3):
+                g.fence_wait(rep % 3)
+                g.render(0, 2, bnc, gather=capi.GATHER_ALL)
+                g.render(2, spp - 2, bnc, gather=capi.GATHER_ALL)
+                g.fence_record(rep % 3)
+            g.sync()
+            for r in range(n):
+                assert np.array_equal(_bits(g.read_accum(r)), _bits(ref)), (n, "async", r)
+        finally:
+            g.close()
+    monkeypatch.setenv("TRG_GROUP_EXCHANGE", "bogus")
+    with pytest.raises(capi.TrgError):
+        capi.Group([0], 16, 16)
+    monkeypatch.setenv("TRG_GROUP_EXCHANGE", "rccl")
+    with pytest.raises(capi.TrgError):
+        capi.Group([0, 0], 16, 16)      # a communicator needs distinct devices
+
+
 def test_device_group_exchange_through_rccl_on_one_device(capi, O, cornell, monkeypatch):
     """The part of the multi-GPU exchange a single-GPU box CAN run ("the exchange was never run on hardware"): with
     TRG_GROUP_FORCE_RCCL a group of one device loads RCCL, creates its communicator with ncclCommInitAll and enqueues the in-place
@@ -1558,7 +1637,7 @@ def test_async_frames_keep_their_uniforms(capi, O, cornell):
         c.close()
 
 
-def test_plugin_on_a_device_group(capi, O):
+def test_plugin_on_a_device_group(capi, O, monkeypatch):
     """HipRenderer::setDevices: the plugin on a device group (trg_group_*), also a group of one -- the frame loop then goes through
     trg_group_fence_wait / trg_group_render / trg_group_fence_record, the scene through trg_group_load_scene and the textures
     through trg_group_load_textures.  Same frames as the plain renderer bit for bit: the asynchronous loop with a camera move in
@@ -1587,6 +1666,15 @@ def test_plugin_on_a_device_group(capi, O):
     assert not np.array_equal(_bits(b), _bits(untextured))
     with pytest.raises(RuntimeError):
         host.render_scene(hs, 160, 120, 1, 3, devices=[0, 0])     # a device listed twice: init() fails, nothing is rendered
+    # ... unless the bands travel by copies (TRG_GROUP_EXCHANGE=copy): then three contexts on this one device run the plugin's n > 1 path
+    # -- bands gathered on the first context, which reads back -- for the asynchronous loop, the device-built HBM scene and the textures
+    monkeypatch.setenv("TRG_GROUP_EXCHANGE", "copy")
+    grouped3, _ = host.async_camera_move(w, h, fa, fb, eye_b, bnc, devices=[0, 0, 0])
+    assert np.array_equal(_bits(grouped3), _bits(plain))
+    got, _ = host.render_scene(lattice, 160, 120, 4, 3, device_build=1, devices=[0, 0])
+    assert np.array_equal(_bits(got), _bits(ref))
+    b3, _ = host.render_scene(hs, 160, 120, 3, 3, devices=[0, 0, 0])
+    assert np.array_equal(_bits(a), _bits(b3))
 
 
 # ------------------------------------------------------------------ round 3: tile order, leaf records

@@ -586,6 +586,14 @@ def test_bench_runs_plainly_with_several_gpus(built, monkeypatch, capsys):
     with pytest.raises(SystemExit) as e:
         bench.main(["--gpus", "2", "--no-cpu-baseline"])
     assert "only 1 GPU" in str(e.value)
+    monkeypatch.setenv("TRG_BENCH_DEVICES", "0,0")   # the one-GPU rehearsal: an explicit device list (contexts sharing a device)
+    bench.main(["--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"])
+    out = json.loads([l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1])
+    assert out["config"]["devices"] == [0, 0] and ("create", [0, 0], 1920, 1080) in calls
+    monkeypatch.setenv("TRG_BENCH_DEVICES", "0")
+    with pytest.raises(SystemExit):
+        bench.main(["--gpus", "2", "--no-cpu-baseline"])
+    monkeypatch.delenv("TRG_BENCH_DEVICES")
     monkeypatch.setenv("RANK", "0"); monkeypatch.setenv("MASTER_PORT", "1"); monkeypatch.setenv("WORLD_SIZE", "1")
     with pytest.raises(SystemExit) as e:   # under a launcher the world size must match
         bench.main(["--gpus", "2", "--no-cpu-baseline"])

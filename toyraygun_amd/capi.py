@@ -88,6 +88,7 @@ _SYMBOLS = [
     ("trg_group_destroy", None, [_P]),
     ("trg_group_last_error", C.c_char_p, [_P]),
     ("trg_group_size", C.c_int, [_P]),
+    ("trg_group_exchange", C.c_int, [_P]),
     ("trg_group_ctx", _P, [_P, C.c_int]),
     ("trg_group_load_scene", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint32, C.c_uint32]),
     ("trg_group_load_textures", C.c_int, [_P, _P, _P, C.c_uint32, C.POINTER(_P), _P, _P, C.c_uint32]),
@@ -309,6 +310,7 @@ class Context:
 
 
 GATHER_NONE, GATHER_ALL, GATHER_ROOT = 0, 1, 2
+EXCHANGE_NONE, EXCHANGE_RCCL, EXCHANGE_COPY = 0, 1, 2
 
 
 def band_rows(height, n, rank):
@@ -331,6 +333,11 @@ class Group:
             raise TrgError(rc, (self.L.trg_group_last_error(None) or b"").decode())
         self.g = g
         self.n = len(devices)
+
+    @property
+    def exchange(self):
+        """How the bands travel: EXCHANGE_NONE (one device), EXCHANGE_RCCL or EXCHANGE_COPY (TRG_GROUP_EXCHANGE=copy / no librccl.so)."""
+        return self.L.trg_group_exchange(self.g)
 
     def close(self):
         if getattr(self, "g", None):
@@ -392,6 +399,11 @@ class Group:
         st = Stats()
         self._chk(self.L.trg_group_get_stats(self.g, C.byref(st)))
         return st
+
+    def reset_stats(self):
+        for r in range(self.n):
+            if self.L.trg_reset_stats(self.L.trg_group_ctx(self.g, r)) != OK:
+                raise TrgError(ERR_INVALID, "trg_reset_stats failed for rank %d" % r)
 
     def rank_stats(self, rank):
         """trg_get_stats of one device's context (trg_group_ctx)."""

@@ -11,6 +11,12 @@
 //
 // RCCL is loaded with dlopen when a group of more than one device is created, so the single-GPU library has no link-time
 // dependency on it.
+//
+// The COPY exchange (round 3; environment variable TRG_GROUP_EXCHANGE=copy, and the fallback when librccl.so cannot be loaded): the same bands
+// moved with hipMemcpyPeerAsync on the destination's stream, ordered by events -- a band is copied once its owner has rendered it, and an owner
+// does not start its next frame before every copy of its band has been taken.  No communicator, so the devices of such a group need not
+// be distinct: a group of n contexts on ONE device runs the whole n > 1 machinery (bands, worker threads, scene uploads, fences, gather)
+// on a single-GPU box -- which is what the GPU tests do -- everything but the RCCL calls themselves.
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
@@ -68,6 +74,8 @@ struct trg_group {
     std::vector<trg_ctx *> ctx;
     std::vector<float *> frame;                // per device: n * band rows x w float4 (padded full frame), bound as its accumulation buffer
     std::vector<ncclComm_t> comm;
+    bool copy_exchange = false;                // bands move by hipMemcpyPeerAsync + events instead of RCCL
+    std::vector<hipEvent_t> rendered, copied;  // copy exchange: rank r's band is complete / rank r has taken its copies of the others' bands
     std::unique_ptr<trg::DeviceWorkers> workers;   // one persistent host thread per device (none for a group of one)
     std::string err;
 };
@@ -103,6 +111,7 @@ void trg_band_rows(uint32_t height, uint32_t n, uint32_t r, uint32_t *row0, uint
 
 const char *trg_group_last_error(trg_group *g) { return g ? g->err.c_str() : g_group_create_err.c_str(); }
 int trg_group_size(trg_group *g) { return g ? g->n : 0; }
+int trg_group_exchange(trg_group *g) { return !g ? 0 : (g->copy_exchange ? TRG_EXCHANGE_COPY : (g->comm.empty() ? TRG_EXCHANGE_NONE : TRG_EXCHANGE_RCCL)); }
 trg_ctx *trg_group_ctx(trg_group *g, int rank) { return (g && rank >= 0 && rank < g->n) ? g->ctx[rank] : nullptr; }
 
 void trg_group_destroy(trg_group *g) {
@@ -113,6 +122,11 @@ void trg_group_destroy(trg_group *g) {
     }
     for (size_t r = 0; r < g->comm.size(); ++r)
         if (g->comm[r]) (void)g_rccl.CommDestroy(g->comm[r]);
+    for (size_t r = 0; r < g->rendered.size(); ++r) {
+        (void)hipSetDevice(g->devices[r]);
+        if (g->rendered[r]) (void)hipEventDestroy(g->rendered[r]);
+        if (r < g->copied.size() && g->copied[r]) (void)hipEventDestroy(g->copied[r]);
+    }
     for (int r = 0; r < g->n; ++r) {
         if (r < (int)g->ctx.size() && g->ctx[r]) trg_destroy(g->ctx[r]);
         if (r < (int)g->frame.size() && g->frame[r]) { (void)hipSetDevice(g->devices[r]); (void)hipFree(g->frame[r]); }
@@ -123,9 +137,13 @@ void trg_group_destroy(trg_group *g) {
 int trg_group_create(trg_group **out, const int *devices, int n, uint32_t width, uint32_t height) {
     if (!out || !devices || n < 1 || n > 64 || width == 0 || height == 0) return gfail(nullptr, TRG_ERR_INVALID, "trg_group_create: bad arguments");
     *out = nullptr;
+    const char *xenv = getenv("TRG_GROUP_EXCHANGE");
+    if (xenv && strcmp(xenv, "copy") != 0 && strcmp(xenv, "rccl") != 0) return gfail(nullptr, TRG_ERR_INVALID, "trg_group_create: TRG_GROUP_EXCHANGE must be rccl or copy");
+    bool copy_exchange = xenv && strcmp(xenv, "copy") == 0;
     for (int a = 0; a < n; ++a)
         for (int b = a + 1; b < n; ++b)
-            if (devices[a] == devices[b]) return gfail(nullptr, TRG_ERR_INVALID, "trg_group_create: device %d listed twice", devices[a]);
+            if (devices[a] == devices[b] && !copy_exchange)   // (an RCCL communicator needs distinct devices; the copy exchange does not)
+                return gfail(nullptr, TRG_ERR_INVALID, "trg_group_create: device %d listed twice", devices[a]);
     trg_group *g = new (std::nothrow) trg_group;
     if (!g) return gfail(nullptr, TRG_ERR_NOMEM, "trg_group_create: out of host memory");
     g->n = n; g->w = width; g->h = height; g->band = (height + (uint32_t)n - 1) / (uint32_t)n;
@@ -147,9 +165,14 @@ int trg_group_create(trg_group **out, const int *devices, int n, uint32_t width,
     }
     // (TRG_GROUP_FORCE_RCCL: a group of ONE device goes through RCCL too -- dlopen, ncclCommInitAll, the in-place all-gather on the render's
     // stream -- so that as much of the exchange as one GPU can exercise is exercised by the GPU tests of a single-GPU box)
-    if (n > 1 || getenv("TRG_GROUP_FORCE_RCCL")) {
+    if (!copy_exchange && (n > 1 || getenv("TRG_GROUP_FORCE_RCCL"))) {
         std::string err;
-        if (!g_rccl.load(err)) { gfail(nullptr, TRG_ERR_DEVICE, "trg_group_create: %s", err.c_str()); trg_group_destroy(g); return TRG_ERR_DEVICE; }
+        if (!g_rccl.load(err)) {
+            if (getenv("TRG_GROUP_FORCE_RCCL") || xenv) { gfail(nullptr, TRG_ERR_DEVICE, "trg_group_create: %s", err.c_str()); trg_group_destroy(g); return TRG_ERR_DEVICE; }
+            copy_exchange = true;   // no librccl.so on this machine: the bands move by peer copies
+        }
+    }
+    if (!copy_exchange && (n > 1 || getenv("TRG_GROUP_FORCE_RCCL"))) {
         g->comm.assign(n, nullptr);
         const ncclResult_t nr = g_rccl.CommInitAll(g->comm.data(), n, g->devices.data());
         if (nr != ncclSuccess) {
@@ -158,6 +181,24 @@ int trg_group_create(trg_group **out, const int *devices, int n, uint32_t width,
             trg_group_destroy(g);
             return TRG_ERR_DEVICE;
         }
+    }
+    g->copy_exchange = copy_exchange && n > 1;
+    if (g->copy_exchange) {
+        g->rendered.assign(n, nullptr); g->copied.assign(n, nullptr);
+        for (int r = 0; r < n; ++r) {
+            hipError_t e = hipSetDevice(devices[r]);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&g->rendered[r], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&g->copied[r], hipEventDisableTiming);
+            if (e != hipSuccess) { gfail(nullptr, TRG_ERR_DEVICE, "trg_group_create: device %d: %s", devices[r], hipGetErrorString(e)); trg_group_destroy(g); return TRG_ERR_DEVICE; }
+            for (int p = 0; p < n; ++p) {   // direct copies over xGMI where the devices can reach each other (otherwise the runtime stages them)
+                int can = 0;
+                if (devices[p] != devices[r] && hipDeviceCanAccessPeer(&can, devices[r], devices[p]) == hipSuccess && can) {
+                    const hipError_t pe = hipDeviceEnablePeerAccess(devices[p], 0);
+                    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+                }
+            }
+        }
+        (void)hipGetLastError();
     }
     // the devices' host threads: started once, each bound to its device; a frame is handed to them through a condition variable
     g->workers.reset(new (std::nothrow) trg::DeviceWorkers(n, [g](int r) { (void)hipSetDevice(g->devices[r]); }));
@@ -213,7 +254,41 @@ int trg_group_render(trg_group *g, uint32_t frameIndexBegin, uint32_t spp, uint3
             return trg_render(g->ctx[r], frameIndexBegin, spp, bounces, row0, rows);
         }))
         return rc;
-    if (g->comm.empty() || gather == TRG_GATHER_NONE) return TRG_OK;
+    if (gather == TRG_GATHER_NONE) return TRG_OK;
+    if (g->copy_exchange) {
+        // the same exchange by copies: destination d takes band p from its owner once p has rendered it (event), on d's stream; then no
+        // owner goes on (its next frame accumulates into its band in place) before every destination has taken its copy
+        const size_t count = (size_t)g->band * g->w * 4u, bytes = count * sizeof(float);
+        hipError_t e = hipSuccess;
+        for (int r = 0; r < g->n && e == hipSuccess; ++r) {
+            e = hipSetDevice(g->devices[r]);
+            if (e == hipSuccess) e = hipEventRecord(g->rendered[r], static_cast<hipStream_t>(trg::ctx_current_stream(g->ctx[r])));
+        }
+        for (int d = 0; d < g->n && e == hipSuccess; ++d) {
+            if (gather == TRG_GATHER_ROOT && d != root) continue;
+            hipStream_t s = static_cast<hipStream_t>(trg::ctx_current_stream(g->ctx[d]));
+            e = hipSetDevice(g->devices[d]);
+            for (int p = 0; p < g->n && e == hipSuccess; ++p) {
+                if (p == d) continue;
+                e = hipStreamWaitEvent(s, g->rendered[p], 0);
+                if (e == hipSuccess)
+                    e = g->devices[d] == g->devices[p]
+                            ? hipMemcpyAsync(g->frame[d] + (size_t)p * count, g->frame[p] + (size_t)p * count, bytes, hipMemcpyDeviceToDevice, s)
+                            : hipMemcpyPeerAsync(g->frame[d] + (size_t)p * count, g->devices[d], g->frame[p] + (size_t)p * count, g->devices[p], bytes, s);
+            }
+            if (e == hipSuccess) e = hipEventRecord(g->copied[d], s);
+        }
+        for (int p = 0; p < g->n && e == hipSuccess; ++p) {
+            e = hipSetDevice(g->devices[p]);
+            for (int d = 0; d < g->n && e == hipSuccess; ++d) {
+                if (d == p || (gather == TRG_GATHER_ROOT && d != root)) continue;
+                e = hipStreamWaitEvent(static_cast<hipStream_t>(trg::ctx_current_stream(g->ctx[p])), g->copied[d], 0);
+            }
+        }
+        if (e != hipSuccess) return gfail(g, TRG_ERR_DEVICE, "trg_group_render: copy exchange: %s", hipGetErrorString(e));
+        return TRG_OK;
+    }
+    if (g->comm.empty()) return TRG_OK;
     // the one exchange of the frame, enqueued behind each device's render: on the stream that render was launched on (the context's
     // current stream -- trg_set_stream's if the caller set one through trg_group_ctx, the context's own otherwise)
     const size_t count = (size_t)g->band * g->w * 4u;   // floats per band
