@@ -277,7 +277,7 @@ def run_torch(config_name, steps, warmup, env, use_imported=True):
     kernel_ms = sum(launch_ms) / max(len(launch_ms), 1)
     concurrency = max(1.0, sum(launch_ms) / (dt * 1e3))
     if distributed:
-        t = torch.tensor([dt, rays_local, kernel_ms / concurrency], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt, rays_local, kernel_ms / concurrency], dtype=torch.float64, device=dev if env.get("backend") != "gloo" else "cpu")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
@@ -298,7 +298,7 @@ def run_torch(config_name, steps, warmup, env, use_imported=True):
             "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["workload"], "name": config_name,
-                       "rays_per_step": rays_total / steps, "sharding": "row bands + RCCL all-gather, one process per GPU (gather of step k overlaps the renders that follow)" if distributed else "none",
+                       "rays_per_step": rays_total / steps, "sharding": ("row bands + RCCL all-gather, one process per GPU (gather of step k overlaps the renders that follow)" if env.get("backend") != "gloo" else "row bands, one process per rank, bands exchanged through host memory over gloo (TRG_BENCH_BACKEND=gloo: rehearsal / no RCCL)") if distributed else "none",
                        "pipeline": ("%d frames in flight on alternating streams: later steps fill the CUs the tail of step k leaves idle "
                                     "(roofline.kernel_ms = average launch duration while they overlap; kernel_alone_ms = one launch by itself)" % len(r.render_streams)) if getattr(r, "_overlap", False) else "serial launches",
                        "kernel": kernel_name(st, in_lds),
@@ -404,12 +404,24 @@ def main(argv=None):
     import torch
     distributed = world > 1
     dist = None
+    # TRG_BENCH_BACKEND=gloo + TRG_BENCH_DEVICES="0,0": the launched multi-rank path rehearsed on a one-GPU box -- the ranks share device 0
+    # (NCCL refuses such a communicator) and exchange their bands through host memory; never a scaling number
+    backend = os.environ.get("TRG_BENCH_BACKEND", "nccl")
+    if backend not in ("nccl", "gloo"):
+        raise SystemExit("TRG_BENCH_BACKEND must be nccl or gloo")
+    devmap = [int(x) for x in os.environ.get("TRG_BENCH_DEVICES", "").split(",") if x.strip()]
+    if devmap and len(devmap) != world:
+        raise SystemExit("TRG_BENCH_DEVICES names %d device(s) for %d rank(s)" % (len(devmap), world))
+    device_index = devmap[local_rank] if devmap else local_rank
     if distributed or launched:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    env = dict(dist=dist, distributed=distributed, rank=rank, world=world, local_rank=local_rank)
+        torch.cuda.set_device(device_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group("gloo")
+    env = dict(dist=dist, distributed=distributed, rank=rank, world=world, local_rank=device_index, backend=backend if (distributed or launched) else None)
 
     out = run_torch(args.config, args.steps, args.warmup, env)
     if rank == 0 and world == 1 and args.config == "c2" and not args.no_secondary:

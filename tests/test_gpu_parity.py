@@ -1359,6 +1359,28 @@ def test_device_group_c_abi(capi, O, cornell, force_global):
         capi.Group([0, 0], 16, 16)
 
 
+def test_bench_launched_multi_rank_path_rehearsed_on_one_device(capi, tmp_path):
+    """The command the driver's scaling run uses -- `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` -- with two ranks
+    on this ONE device: TRG_BENCH_DEVICES=0,0 maps both ranks to device 0 and TRG_BENCH_BACKEND=gloo replaces the RCCL communicator NCCL
+    refuses for ranks that share a GPU (the bands then go through host memory).  Everything else is the real path: rank environment, one
+    context per process rendering its band, barrier + max-over-ranks timing, the all-reduced ray count, ONE JSON line from rank 0."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TRG_BENCH_BACKEND="gloo", TRG_BENCH_DEVICES="0,0", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+                        os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["unit"] == "Mrays/s" and out["value"] > 100
+    assert 100e6 < out["config"]["rays_per_step"] < 120e6      # both bands counted: the whole C2 frame
+    assert "gloo" in out["config"]["sharding"] and "cpu_baseline" not in out
+
+
 def test_bench_single_process_group_path_rehearsed_on_one_device(capi, monkeypatch, capsys):
     """`python bench.py --gpus N` invoked plainly (what a driver without a launcher does) takes the single-process trg_group path.  Rehearsed
     here end to end on ONE device: TRG_BENCH_DEVICES names device 0 N times and TRG_GROUP_EXCHANGE=copy lets the contexts share it.  The JSON

@@ -44,6 +44,13 @@ def gather_bands(full, world, rank, group=None, root=None):
         return full
     if root is None and os.environ.get("TRG_GATHER") == "root":
         root = 0
+    if full.is_cuda and dist.get_backend(group) == "gloo":
+        # no RCCL in this process group (a machine without it, or the one-GPU rehearsal of bench.py's launched path, where the ranks share a
+        # device and NCCL refuses a communicator): the bands go through host memory -- correct, slow, never what a scaling number is taken with
+        host = full.cpu()   # (waits for the current stream, which is ordered behind the render)
+        gather_bands(host, world, rank, group, root)
+        full.copy_(host)
+        return full
     if root is not None:
         h = full.shape[0]
         bands = [band_rows(h, world, r) for r in range(world)]
