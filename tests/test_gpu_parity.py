@@ -1364,12 +1364,15 @@ def test_bench_launched_multi_rank_path_rehearsed_on_one_device(capi, tmp_path):
     on this ONE device: TRG_BENCH_DEVICES=0,0 maps both ranks to device 0 and TRG_BENCH_BACKEND=gloo replaces the RCCL communicator NCCL
     refuses for ranks that share a GPU (the bands then go through host memory).  Everything else is the real path: rank environment, one
     context per process rendering its band, barrier + max-over-ranks timing, the all-reduced ray count, ONE JSON line from rank 0."""
-    import json, os, subprocess, sys
+    import json, os, socket, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:   # a free port for the rendezvous
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     env = dict(os.environ, TRG_BENCH_BACKEND="gloo", TRG_BENCH_DEVICES="0,0", MASTER_ADDR="127.0.0.1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
                         os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=280)
     assert p.returncode == 0, p.stderr[-2000:]
