@@ -2,7 +2,8 @@
 bounces and option combinations; the strict build must match the oracle bit for bit, ray counts included.
 python scripts/gpu_fuzz.py [cases] [seed] [fast]   (fast: the shipped build against the libm oracle within the stated tolerance,
 images of at least 32x32 pixels)"""
-import sys, time; sys.path.insert(0, ".")
+import os, sys, time; sys.path.insert(0, ".")
+os.environ.setdefault("TRG_GROUP_EXCHANGE", "copy")   # device groups of several contexts on this one GPU (bands by peer copies)
 import numpy as np
 from toyraygun_amd import capi
 from oracle import pyoracle as O
@@ -32,17 +33,22 @@ for case in range(cases):
     opts = dict(force_global=int(rng.integers(0, 2)), fsplit=int(rng.choice([0, 1, 2, 4])), gpu_build=int(rng.integers(0, 4)) if s.ntris >= 2 else 0,
                 kernel=int(rng.choice([0, 0, 0, 1, 2])), in_flight=int(rng.choice([1, 4])), counters=int(rng.integers(0, 2)),
                 regen=int(rng.choice([-1, 0, 1])), tail=int(rng.choice([-1, 0, 1, 2])), tile_order=int(rng.choice([-1, 0, 1, 2, 4, 8])), stack_levels=int(rng.choice([12, 12, 2, 3, 6])))
-    off = O.pixel_offsets(w, h, seed=int(rng.integers(1, 2 ** 31)))
+    oseed = int(rng.integers(1, 2 ** 31))
+    off = O.pixel_offsets(w, h, seed=oseed)
+    opts["group"] = int(rng.choice([0, 0, 0, 2, 3, 5]))   # 0: a plain context; n: a device group of n contexts on device 0 (row bands, possibly empty ones)
     O.set_trig_mode(O.TRIG_LIBM if FAST else O.TRIG_PORTABLE)
     ref, rst = O.render(s, w, h, spp, bnc, offsets=off)
     O.set_trig_mode(O.TRIG_LIBM)
     b = s.buffers()
-    c = capi.Context(w, h)
+    c = capi.Group([0] * opts["group"], w, h) if opts["group"] else capi.Context(w, h)
     try:
         c.set_option(capi.OPT_GPU_BUILD, opts["gpu_build"])
         c.load_scene(b["positions"], b["normals"], b["colors"], b["indices"], b["material_ids"])
         c.set_uniforms(O.uniforms_bytes(O.make_uniforms(w, h)))
-        c.set_pixel_offsets(off)
+        if opts["group"]:
+            c.set_pixel_offsets_seed(oseed)
+        else:
+            c.set_pixel_offsets(off)
         c.set_option(capi.OPT_STRICT, 0 if FAST else 1)
         c.set_option(capi.OPT_FORCE_GLOBAL, opts["force_global"])
         c.set_option(capi.OPT_FRAME_SPLIT, opts["fsplit"])
@@ -58,7 +64,9 @@ for case in range(cases):
             c.render(0, split, bnc)
         if spp - split:
             c.render(split, spp - split, bnc)
-        img, st = c.read_accum(), c.stats()
+        if opts["group"]:
+            c.sync()
+        img, st = (c.read_accum(int(rng.integers(0, opts["group"]))) if opts["group"] else c.read_accum()), c.stats()
         if FAST:
             d = np.linalg.norm(img[..., :3].astype(np.float64) - ref[..., :3], axis=-1)
             nr = np.linalg.norm(ref[..., :3].astype(np.float64), axis=-1)
