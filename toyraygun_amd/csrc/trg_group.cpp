@@ -259,6 +259,8 @@ int trg_group_render(trg_group *g, uint32_t frameIndexBegin, uint32_t spp, uint3
         // the same exchange by copies: destination d takes band p from its owner once p has rendered it (event), on d's stream; then no
         // owner goes on (its next frame accumulates into its band in place) before every destination has taken its copy
         const size_t count = (size_t)g->band * g->w * 4u, bytes = count * sizeof(float);
+        int caller_device = -1;
+        (void)hipGetDevice(&caller_device);   // (the calls below select devices on the CALLER's thread: put its device back afterwards)
         hipError_t e = hipSuccess;
         for (int r = 0; r < g->n && e == hipSuccess; ++r) {
             e = hipSetDevice(g->devices[r]);
@@ -285,6 +287,7 @@ int trg_group_render(trg_group *g, uint32_t frameIndexBegin, uint32_t spp, uint3
                 e = hipStreamWaitEvent(static_cast<hipStream_t>(trg::ctx_current_stream(g->ctx[p])), g->copied[d], 0);
             }
         }
+        if (caller_device >= 0) (void)hipSetDevice(caller_device);
         if (e != hipSuccess) return gfail(g, TRG_ERR_DEVICE, "trg_group_render: copy exchange: %s", hipGetErrorString(e));
         return TRG_OK;
     }
