@@ -11,7 +11,7 @@ if len(sys.argv) == 1:
     for d in (1, 2, 4, 0):
         subprocess.run([sys.executable, __file__, str(d)], env=dict(os.environ, GPU_MAX_HW_QUEUES="8"))
     sys.exit(0)
-depth = int(sys.argv[1]); fs = 0
+depth = int(sys.argv[1]); fs = int(os.environ.get("FS", "0"))   # FS: frame-split override (0 = automatic)
 for pipelined in (depth != 1,):
     r = DistributedRenderer(W, H, 0, pipelined=pipelined, depth=depth or None)
     r.load_scene(b); r.ctx.set_uniforms(host.uniforms(W, H)[0]); r.ctx.set_pixel_offsets_seed()
