@@ -233,9 +233,9 @@ def run_torch(config_name, steps, warmup, env, use_imported=True):
     r.ctx.set_option(capi.OPT_TIMING, 1)
     r.ctx.set_option(capi.OPT_COUNTERS, 1)
     r.ctx.reset_stats()
-    r.ctx.render(0, SPP, BOUNCES, r.row0, r.rows)
+    r.launch_band(0, SPP, BOUNCES)
     cst = r.ctx.stats()
-    bytes_per_ray, mix = algorithmic_bytes_per_ray(cst, r.rows * W * SPP)
+    bytes_per_ray, mix = algorithmic_bytes_per_ray(cst, r.owned_rows * W * SPP)
     rays_per_launch = cst.rays
     lane_util_nodes = cst.node_fetches / (64.0 * cst.wave_node_iters * (1 if cst.scene_in_lds else 2)) if cst.wave_node_iters else None
     r.ctx.set_option(capi.OPT_COUNTERS, 0)
@@ -254,7 +254,7 @@ def run_torch(config_name, steps, warmup, env, use_imported=True):
     # serialise the pipeline inside the timed region (and there several launches overlap on purpose).
     r.ctx.reset_stats()
     for _ in range(3):
-        r.ctx.render(0, SPP, BOUNCES, r.row0, r.rows)
+        r.launch_band(0, SPP, BOUNCES)
     pst = r.ctx.stats()
     kernel_ms_alone = pst.total_render_ms / max(pst.renders, 1)
     r.ctx.set_option(capi.OPT_TIMING, 0)
@@ -298,7 +298,8 @@ def run_torch(config_name, steps, warmup, env, use_imported=True):
             "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["workload"], "name": config_name,
-                       "rays_per_step": rays_total / steps, "sharding": ("row bands + RCCL all-gather, one process per GPU (gather of step k overlaps the renders that follow)" if env.get("backend") != "gloo" else "row bands, one process per rank, bands exchanged through host memory over gloo (TRG_BENCH_BACKEND=gloo: rehearsal / no RCCL)") if distributed else "none",
+                       "rays_per_step": rays_total / steps, "sharding": (("%s + RCCL all-gather, one process per GPU (gather of step k overlaps the renders that follow)" if env.get("backend") != "gloo" else "%s, one process per rank, bands exchanged through host memory over gloo (TRG_BENCH_BACKEND=gloo: rehearsal / no RCCL)")
+                                    % ("interleaved 8-row micro-bands (rank r renders bands r, r + N, ...; compact frame, unpacked after the gather)" if r.interleaved else "contiguous row bands")) if distributed else "none",
                        "pipeline": ("%d frames in flight on alternating streams: later steps fill the CUs the tail of step k leaves idle "
                                     "(roofline.kernel_ms = average launch duration while they overlap; kernel_alone_ms = one launch by itself)" % len(r.render_streams)) if getattr(r, "_overlap", False) else "serial launches",
                        "kernel": kernel_name(st, in_lds),
@@ -309,13 +310,15 @@ def run_torch(config_name, steps, warmup, env, use_imported=True):
     return out
 
 
-def run_group(args):
+def run_group(args, n=None, use_imported=False):
     """`--gpus N` without a launcher: ONE process, trg_group_* (one context + one host thread per device, row bands, one
-    in-place ncclAllGather per frame over xGMI).  Same JSON line; `config.sharding` names the design, `gather_ms_per_step` is the
-    exchange (steps with the all-gather minus steps without it)."""
+    in-place ncclAllGather per frame over xGMI).  Same method as the N = 1 headline (run_torch): TRG_PIPE_DEPTH (4) frames in flight per
+    device -- frame i renders on stream i % 4 into buffer i % 4, its exchange follows on the device's exchange stream and overlaps the
+    renders behind it (trg_group_set_pipeline) -- HIP events around every launch on its own stream, no host sync inside the timed
+    region.  Same JSON line; `config.bands` carries what each rank did: rays, the band's launch alone, its launches in the pipeline."""
     import torch   # device count only: nothing here initialises the GPU before the library does
     from toyraygun_amd import capi
-    n = args.gpus
+    n = n or args.gpus
     have = torch.cuda.device_count()
     # TRG_BENCH_DEVICES="0,0": an explicit device list -- with TRG_GROUP_EXCHANGE=copy the contexts of a group may share a device, which
     # rehearses this whole path (bands, host threads, exchange by peer copies, this function) on a one-GPU box; never a scaling number
@@ -324,6 +327,7 @@ def run_group(args):
         raise SystemExit("bench.py --gpus %d: TRG_BENCH_DEVICES names %d device(s)" % (n, len(devices)))
     if max(devices) >= have or min(devices) < 0 or (len(set(devices)) == n and have < n):
         raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (n, have))
+    shared = len(set(devices)) < n
     cfg = CONFIGS[args.config]
     W, H, SPP, BOUNCES = cfg["w"], cfg["h"], cfg["spp"], cfg["bounces"]
     buffers, uniforms = scene_buffers(cfg)
@@ -332,50 +336,90 @@ def run_group(args):
         g.load_scene(buffers["positions"], buffers["normals"], buffers["colors"], buffers["indices"], buffers["material_ids"])
         g.set_uniforms(uniforms)
         g.set_pixel_offsets_seed()
-        # counters pass (untimed, synchronous): rays per step and the algorithmic bytes per ray, summed over the bands
+        # interleaved 8-row micro-bands even out what the bands cost (TRG_BANDS=contiguous: rows [g*B, (g+1)*B) per device)
+        interleaved = n > 1 and os.environ.get("TRG_BANDS", "interleaved") != "contiguous"
+        g.set_bands(capi.BANDS_INTERLEAVED if interleaved else capi.BANDS_CONTIGUOUS)
+        # counters pass (untimed, one buffer, synchronous): rays per step and the algorithmic bytes per ray, summed over the bands
         g.set_option(capi.OPT_COUNTERS, 1)
         g.render(0, SPP, BOUNCES, capi.GATHER_NONE)
         g.sync()
         cst = g.stats()
         bytes_per_ray, mix = algorithmic_bytes_per_ray(cst, H * W * SPP)
         rays_per_step = float(cst.rays)
-        per_rank_rays = g.rank_rays() if hasattr(g, "rank_rays") else None
+        per_rank_rays = g.rank_rays()
         g.set_option(capi.OPT_COUNTERS, 0)
-        kernel_ms_alone = cst.last_render_ms      # slowest device, its band alone (HIP events)
+        # every band's launch ALONE on its device (HIP events around the launch; the ranks run at the same time, each on its own GPU)
+        g.reset_stats()
+        for _ in range(3):
+            g.render(0, SPP, BOUNCES, capi.GATHER_NONE)
+        alone = []
+        for r in range(n):
+            st = g.rank_stats(r)
+            alone.append(st.total_render_ms / max(st.renders, 1))
+        kernel_ms_alone = max(alone)
+        depth = 1 if os.environ.get("TRG_BENCH_SERIAL") else int(os.environ.get("TRG_PIPE_DEPTH", "4"))
         g.set_option(capi.OPT_TIMING, 0)          # asynchronous from here on: a step only enqueues
+        g.set_pipeline(depth)
+        fences = min(8, 2 * depth)                # host run-ahead bound (MetalRenderer.mm:377: a semaphore of three)
 
-        def timed(gather, k):
+        def timed(gather, k, timeit=False):
             g.sync()
+            g.time_launches(timeit)
             t0 = time.perf_counter()
-            for _ in range(k):
+            for i in range(k):
+                g.fence_wait(i % fences)
                 g.render(0, SPP, BOUNCES, gather)
+                g.fence_record(i % fences)
             g.sync()
-            return time.perf_counter() - t0
+            dt_ = time.perf_counter() - t0
+            g.time_launches(False)
+            return dt_
 
+        timed(capi.GATHER_NONE, depth)            # priming: every render stream's per-launch scratch exists before anything is timed
         timed(capi.GATHER_ALL, max(args.warmup, 1))
-        dt = timed(capi.GATHER_ALL, args.steps)
+        g.reset_stats()
+        dt = timed(capi.GATHER_ALL, args.steps, timeit=True)
+        launch = [g.launch_ms(r) for r in range(n)]
         dt_nogather = timed(capi.GATHER_NONE, args.steps)
         in_lds = bool(cst.scene_in_lds)
-        exchange = getattr(g, "exchange", capi.EXCHANGE_RCCL)
-        sec = dt / args.steps
-        rf = build_roofline(args.config, cst, rays_per_step, bytes_per_ray, mix, sec * 1e3, 1.0, sec * 1e3, kernel_ms_alone, None, use_imported=False)
+        exchange = g.exchange
+        st0 = g.rank_stats(0)
+        piped = [sum(l) / max(len(l), 1) for l in launch]               # mean launch duration per rank while its frames overlap
+        conc = [max(1.0, sum(l) / (dt * 1e3)) for l in launch]          # launches of a rank in flight on average
+        eff = [p / c for p, c in zip(piped, conc)]                      # device time per launch and rank
+        slow = max(range(n), key=lambda r: eff[r])
+        rf = build_roofline(args.config, cst, rays_per_step, bytes_per_ray, mix, piped[slow], conc[slow], eff[slow], kernel_ms_alone, None,
+                            use_imported=use_imported and n == 1)
+
+        def spread(v):
+            m = sum(v) / len(v)
+            return {"per_rank": [round(x, 4) for x in v], "slowest": max(v), "mean": m, "max_over_mean": (max(v) / m) if m > 0 else None}
         out = {
             "metric": "Mrays/s (primary+shadow+bounce) at %dx%d" % (W, H),
             "value": rays_per_step * args.steps / dt / 1e6, "unit": "Mrays/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["workload"], "name": args.config, "rays_per_step": rays_per_step,
-                       "sharding": "single process, trg_group: %d contexts + persistent host threads, bands of ceil(h / N) rows, %s" % (
-                           n, "one in-place ncclAllGather per frame over xGMI" if exchange == capi.EXCHANGE_RCCL else "bands exchanged by hipMemcpyPeerAsync + events (TRG_GROUP_EXCHANGE=copy or no librccl.so)"),
-                       "exchange": {capi.EXCHANGE_RCCL: "rccl", capi.EXCHANGE_COPY: "copy"}.get(exchange, "none"), "devices": devices,
+                       "sharding": "single process, trg_group: %d contexts + persistent host threads, %s, %s" % (
+                           n, "interleaved 8-row micro-bands (device g renders bands g, g + N, ...; compact frame, unpacked after the exchange)" if interleaved else "bands of ceil(h / N) rows",
+                           "one in-place ncclAllGather per frame over xGMI" if exchange == capi.EXCHANGE_RCCL else
+                           ("no exchange (one device)" if exchange == capi.EXCHANGE_NONE else "bands exchanged by hipMemcpyPeerAsync + events (TRG_GROUP_EXCHANGE=copy or no librccl.so)")),
+                       "pipeline": ("%d frames in flight per device on alternating streams, the exchange of frame i on the device's exchange stream behind the "
+                                    "renders that follow (trg_group_set_pipeline)" % depth) if depth > 1 else "serial launches, the exchange behind each render on its stream",
+                       "exchange": {capi.EXCHANGE_RCCL: "rccl", capi.EXCHANGE_COPY: "copy"}.get(exchange, "none"), "exchange_note": g.exchange_note or None,
+                       "devices": devices,
                        "per_rank_rays_per_step": per_rank_rays,
+                       "bands": {"rays": spread([float(x) for x in per_rank_rays]),
+                                 "kernel_alone_ms": spread(alone), "kernel_ms_in_pipeline": spread(piped), "device_ms_per_launch": spread(eff),
+                                 "note": ("the contexts SHARE a device (rehearsal): their `alone` launches ran side by side on it" if shared else
+                                          "HIP events per rank on the stream of each launch; alone = 3 launches per band with nothing else on its GPU")},
                        "ms_per_step_without_gather": dt_nogather / args.steps * 1e3,
                        "gather_ms_per_step": max(0.0, (dt - dt_nogather) / args.steps * 1e3),
-                       "kernel": "per-band launches of the configuration's megakernel" + ("<LDS scene>" if in_lds else "<HBM scene>") + " (fast build)",
+                       "kernel": ("per-band launches of: " if n > 1 else "") + kernel_name(st0, in_lds),
                        "triangles": int(len(buffers["material_ids"])), "scene_bytes": int(cst.scene_bytes)},
             "roofline": rf,
         }
-        print(json.dumps(out), flush=True)
+        return out
     finally:
         g.close()
 
@@ -396,8 +440,14 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ  # under torch.distributed.run (also with N = 1)
-    if args.gpus > 1 and not launched:
-        return run_group(args)   # plain invocation: the single-process design of SURVEY 8(e); nothing is re-executed
+    if not launched and (args.gpus > 1 or os.environ.get("TRG_BENCH_GROUP")):
+        # plain invocation: the single-process design of SURVEY 8(e); nothing is re-executed.  (TRG_BENCH_GROUP=1: N = 1 through the same
+        # group path, to check it against the headline)
+        out = run_group(args, use_imported=True)
+        if args.gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.config)
+        print(json.dumps(out), flush=True)
+        return
     if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d, or plainly (no launcher) for the single-process group" % (args.gpus, world, args.gpus))
 
@@ -424,6 +474,7 @@ def main(argv=None):
     env = dict(dist=dist, distributed=distributed, rank=rank, world=world, local_rank=device_index, backend=backend if (distributed or launched) else None)
 
     out = run_torch(args.config, args.steps, args.warmup, env)
+    secondary_failed = []
     if rank == 0 and world == 1 and args.config == "c2" and not args.no_secondary:
         # the configurations where the roofline question lives, timed in the same (driver-witnessed) run: same method, fewer steps
         sec = {}
@@ -433,8 +484,10 @@ def main(argv=None):
                 sec[name] = {"value": s["value"], "unit": s["unit"], "ms_per_step": s["ms_per_step"], "steps": k, "warmup": wu,
                              "kernel_alone_ms": s["roofline"]["kernel_alone_ms"], "workload": s["config"]["workload"], "kernel": s["config"]["kernel"],
                              "rays_per_step": s["config"]["rays_per_step"], "roofline": s["roofline"]}
-            except Exception as e:   # a secondary leg never takes the headline down with it
+            except Exception as e:   # the headline is still printed -- and the run then ends NON-ZERO: a failed leg is not a green run
                 sec[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+                secondary_failed.append(name)
+                break                # (a device error leaves the context in doubt: no further leg on it)
         out["secondary"] = sec
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
@@ -443,6 +496,9 @@ def main(argv=None):
     if distributed or launched:
         dist.barrier()
         dist.destroy_process_group()
+    if secondary_failed:
+        sys.stderr.write("bench.py: secondary leg(s) failed: %s\n" % ", ".join(secondary_failed))
+        sys.exit(1)
 
 
 if __name__ == "__main__":

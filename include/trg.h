@@ -179,6 +179,18 @@ TRG_API int trg_set_pixel_offsets_seed(trg_ctx *ctx, uint32_t seed); /* offset(x
  *     scratch; announce how many with TRG_OPT_LAUNCHES_IN_FLIGHT so that the schedule is chosen for throughput). */
 TRG_API int trg_render(trg_ctx *ctx, uint32_t frameIndexBegin, uint32_t spp, uint32_t bounces, uint32_t row0, uint32_t rows);
 
+/* --- INTERLEAVED row bands for multi-GPU jobs (round 4; SURVEY 8e's micro-bands): contiguous bands of the Cornell box differ in cost (the
+ *     million-triangle scene at 8 GPUs: slowest band 1.2 x the mean), bands dealt round robin do not.  Rank r of n renders the 8-row
+ *     MICRO-BANDS r, r + n, r + 2n ... of the image (8 rows = the sub-tile of one wavefront) and stores them COMPACTLY in rows
+ *     [store_row0, store_row0 + rows) of the bound accumulation buffer: local row l is image row ((l / 8) * n + r) * 8 + l % 8.
+ *     trg_microband_rows gives `rows` of a rank and the common `stride_rows` = 8 * ceil(ceil(h / 8) / n): with store_row0 = r * stride_rows
+ *     the ranks' bands tile a buffer of n * stride_rows rows that an in-place all-gather completes, and trg_unpack_bands turns that
+ *     compact frame into the image (a streaming kernel on the context's current stream; `image` has width*height float4, `compact`
+ *     n * stride_rows rows).  Same arithmetic per pixel as trg_render: the unpacked frame is bit-identical.  Direct megakernel only. */
+TRG_API void trg_microband_rows(uint32_t height, uint32_t n, uint32_t rank, uint32_t *rows, uint32_t *stride_rows); /* host-only arithmetic */
+TRG_API int trg_render_bands(trg_ctx *ctx, uint32_t frameIndexBegin, uint32_t spp, uint32_t bounces, uint32_t n_ranks, uint32_t rank, uint32_t store_row0);
+TRG_API int trg_unpack_bands(trg_ctx *ctx, const void *compact_device, void *image_device, uint32_t n_ranks);
+
 /* --- read back the accumulation target (what the reference hands to its blit pass,
  *     MetalRenderer.mm:538): width*height*4 floats, host memory. */
 TRG_API int trg_read_accum(trg_ctx *ctx, float *rgba);
@@ -242,7 +254,34 @@ TRG_API int trg_group_sync(trg_group *g);
 /* frames in flight for a group (MetalRenderer.mm:33,377,385-387): trg_fence_record / trg_fence_wait on every device's stream */
 TRG_API int trg_group_fence_record(trg_group *g, int slot);
 TRG_API int trg_group_fence_wait(trg_group *g, int slot);
-TRG_API int trg_group_read_accum(trg_group *g, int rank, float *rgba); /* width*height*4 floats of device `rank`'s frame buffer */
+TRG_API int trg_group_read_accum(trg_group *g, int rank, float *rgba); /* width*height*4 floats of device `rank`'s frame buffer (of the LAST trg_group_render) */
+/* --- frames in flight per device (round 4).  Consecutive trg_group_render calls that produce INDEPENDENT images (benchmark steps, the
+ *     frames of an animation: frameIndexBegin = 0 each) may overlap: with depth k every device gets k frame buffers, k render streams and one
+ *     exchange stream; call i renders on stream i % k into buffer i % k, its exchange follows on the exchange stream behind an event,
+ *     and re-use of a buffer waits ON THE DEVICE for the exchange that read it -- the render of call i + 1 overlaps the tail of render i and
+ *     exchange i (what MetalRenderer.mm:33,377,385-387 bounds to three frames).  depth 1 (default) = one buffer, the accumulation
+ *     continued in place across calls (the plugin's progressive mode), the exchange on the render's stream.  The call waits for the
+ *     group to drain and switches TRG_OPT_TIMING off for depth > 1 (a pipelined group only enqueues; time its launches with
+ *     trg_group_time_launches).  The host side of the pipeline is bounded with the group fences. */
+TRG_API int trg_group_set_pipeline(trg_group *g, int depth /* 1..8 */);
+TRG_API int trg_group_pipeline_depth(trg_group *g);
+/* per-launch device times without a host sync: on != 0 brackets every trg_render of every rank with HIP events on the stream it runs
+ * on; trg_group_launch_ms waits for the rank's device work, returns the durations recorded since the last read (oldest first, at most
+ * cap of them in ms_out; *n = how many there were) and forgets them.  Overlapping launches share the device: each lasts longer than alone. */
+TRG_API int trg_group_time_launches(trg_group *g, int on);
+TRG_API int trg_group_launch_ms(trg_group *g, int rank, double *ms_out, uint32_t cap, uint32_t *n);
+/* --- how the rows are dealt to the devices (round 4).  TRG_BANDS_CONTIGUOUS (default): device g renders rows [g*B, (g+1)*B).
+ *     TRG_BANDS_INTERLEAVED: device g renders the 8-row micro-bands g, g + G, g + 2G ... (trg_render_bands) compactly into its slice of the
+ *     frame buffer, the exchange completes the compact frame and trg_unpack_bands turns it into the image on the exchange stream (one
+ *     more w x h buffer per frame slot and device).  Evens out the cost of the bands (C2 at 8 GPUs: slowest / mean 1.05 -> measured in
+ *     DESIGN.md; the million-triangle scene 1.2 ->).  trg_group_read_accum / trg_group_postprocess return the image either way; the
+ *     contexts' own trg_read_accum sees the COMPACT buffer of an interleaved group.  Waits for the group to drain. */
+enum trg_bands { TRG_BANDS_CONTIGUOUS = 0, TRG_BANDS_INTERLEAVED = 1 };
+TRG_API int trg_group_set_bands(trg_group *g, int mode);
+TRG_API int trg_group_bands(trg_group *g);
+TRG_API int trg_group_postprocess(trg_group *g, int rank, uint8_t *rgba8, int flip_y); /* trg_postprocess of device `rank`'s last frame */
+/* why the exchange is not the one asked for ("" when it is): e.g. librccl.so could not be loaded and the bands move by peer copies */
+TRG_API const char *trg_group_exchange_note(trg_group *g);
 TRG_API int trg_group_get_stats(trg_group *g, trg_stats *out);         /* ray counters summed over the devices, times of the slowest one */
 
 /* --- stage-level entry points used by the parity tests (each isolates one SURVEY 8a row) */

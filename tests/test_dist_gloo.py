@@ -121,3 +121,68 @@ def test_c_abi_row_band_layout_rehearsal(O):
                 rootbuf[src * count:(src + 1) * count] = flat[src][src * count:(src + 1) * count]
         assert np.array_equal(rootbuf.reshape(G * B, w, 4)[:h].view(np.uint32), full.view(np.uint32))
         assert rays == fst.rays
+
+
+def test_microband_rule_and_unpack_layout():
+    """INTERLEAVED bands (trg_render_bands / trg_unpack_bands, round 4): dist.microband_rows is trg_microband_rows; the ranks' micro-bands
+    partition the image rows; trg_unpack_bands' index map (dist.unpack_bands_reference) is the inverse of the compact placement."""
+    from toyraygun_amd import capi
+    from toyraygun_amd.dist import MICRO_BAND_ROWS, microband_rows, unpack_bands_reference
+    capi.load()
+    for h in (1, 5, 8, 9, 93, 135, 1080, 2160):
+        for world in (1, 2, 3, 4, 8, 11):
+            rule = [microband_rows(h, world, r) for r in range(world)]
+            assert rule == [capi.microband_rows(h, world, r) for r in range(world)], (h, world)
+            stride = rule[0][1]
+            assert all(s == stride for _, s in rule) and stride % MICRO_BAND_ROWS == 0 and all(n <= stride for n, _ in rule)
+            nmb = -(-h // MICRO_BAND_ROWS)
+            assert sum(n for n, _ in rule) == nmb * MICRO_BAND_ROWS           # every micro-band has exactly one owner
+            # place image row y where its owner stores it, then unpack: the identity
+            img = np.arange(h, dtype=np.int64)
+            compact = np.full(world * stride, -1, np.int64)
+            for y in range(h):
+                mb = y // MICRO_BAND_ROWS
+                r, l = mb % world, (mb // world) * MICRO_BAND_ROWS + y % MICRO_BAND_ROWS
+                assert l < rule[r][0]
+                assert compact[r * stride + l] == -1
+                compact[r * stride + l] = y
+            assert np.array_equal(unpack_bands_reference(compact, h, world), img)
+    assert microband_rows(1080, 8, 0) == (136, 136) and microband_rows(1080, 8, 7) == (128, 136) and microband_rows(93, 3, 2) == (32, 32)
+
+
+def _interleaved_worker(rank, world, port, h, w, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pyoracle as O
+    from toyraygun_amd.dist import MICRO_BAND_ROWS, gather_bands, microband_rows, unpack_bands_reference
+    scene = O.OracleScene.cornell_box()
+    rows, stride = microband_rows(h, world, rank)
+    compact = np.zeros((world * stride, w, 4), np.float32)
+    acc = np.zeros((h, w, 4), np.float32)
+    nmb = -(-h // MICRO_BAND_ROWS)
+    for k, mb in enumerate(range(rank, nmb, world)):          # the oracle renders this rank's micro-bands; stored as trg_render_bands stores them
+        y0, n = mb * MICRO_BAND_ROWS, min(MICRO_BAND_ROWS, h - mb * MICRO_BAND_ROWS)
+        O.render(scene, w, h, 2, 3, row0=y0, rows=n, accum=acc, nthreads=2)
+        compact[rank * stride + k * MICRO_BAND_ROWS: rank * stride + k * MICRO_BAND_ROWS + n] = acc[y0:y0 + n]
+    full = torch.from_numpy(compact)
+    gather_bands(full, world, rank)                            # equal slices of `stride` rows: the in-place all-gather
+    np.save(os.path.join(out_dir, "rank%d.npy" % rank), unpack_bands_reference(full.numpy(), h, world))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,h", [(2, 32), (3, 37)])
+def test_interleaved_bands_equal_single(tmp_path, world, h, O):
+    """The launched multi-rank path with interleaved micro-bands, rehearsed over gloo with the oracle as the per-rank renderer: compact
+    bands, ONE in-place all-gather of equal slices, the unpack -- every rank ends with the unsharded frame bit for bit."""
+    w = 40
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_interleaved_worker, args=(world, port, h, w, str(tmp_path)), nprocs=world, join=True)
+    ref, _ = O.render(O.OracleScene.cornell_box(), w, h, 2, 3)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), "rank%d.npy" % r))
+        assert np.array_equal(got, ref), "rank %d frame differs from the unsharded render" % r

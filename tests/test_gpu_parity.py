@@ -1500,6 +1500,199 @@ def test_device_group_exchange_through_rccl_on_one_device(capi, O, cornell, monk
         g.close()
 
 
+def _group_ready(capi, O, cornell, devices, w, h, force_global=0):
+    b = cornell.buffers()
+    g = capi.Group(devices, w, h)
+    g.load_scene(b["positions"], b["normals"], b["colors"], b["indices"], b["material_ids"])
+    g.set_uniforms(O.uniforms_bytes(O.make_uniforms(w, h)))
+    g.set_pixel_offsets_seed()
+    g.set_option(capi.OPT_STRICT, 1)
+    g.set_option(capi.OPT_FORCE_GLOBAL, force_global)
+    return g
+
+
+@pytest.mark.parametrize("bands", ["contiguous", "interleaved"])
+@pytest.mark.parametrize("force_global", [0, 1])
+def test_pipelined_device_group(capi, O, cornell, force_global, bands, monkeypatch):
+    """trg_group_set_pipeline (round 4): k frame buffers and render streams + one exchange stream per device, frame i on stream i % k, its
+    exchange behind it on the exchange stream, slot re-use ordered on the device by events.  Groups of 1, 2, 3 and 8 contexts on device 0
+    (copy exchange), depth 3: sequences of 1..8 DIFFERENT frames enqueued without any host wait -- the slots wrap around, exchanges of
+    older frames are still in flight when their slot is rendered again -- must end with the plain context's last frame bit for bit on
+    every rank that is to hold it; HIP-event launch times come back one per frame and rank; the host-side fences bound the run-ahead;
+    back at depth 1 the progressive accumulation continues in place as before."""
+    monkeypatch.setenv("TRG_GROUP_EXCHANGE", "copy")
+    w, h, bnc = 200, 93, 3
+    spps = [1, 2, 3, 1, 3, 2, 2, 1]            # frame i of a sequence = frames [0, spps[i]) of the picture: consecutive images differ
+    ref_ctx = make_ctx(O, cornell, w, h)
+    refs = {}
+    try:
+        ref_ctx.set_option(capi.OPT_STRICT, 1)
+        ref_ctx.set_option(capi.OPT_FORCE_GLOBAL, force_global)
+        for spp in (1, 2, 3, 5):
+            ref_ctx.render(0, spp, bnc)
+            refs[spp] = ref_ctx.read_accum()
+    finally:
+        ref_ctx.close()
+    for n in (1, 2, 3, 8):
+        g = _group_ready(capi, O, cornell, [0] * n, w, h, force_global)
+        try:
+            with pytest.raises(capi.TrgError):
+                g.set_pipeline(0)
+            with pytest.raises(capi.TrgError):
+                g.set_bands(7)
+            g.set_bands(capi.BANDS_INTERLEAVED if bands == "interleaved" else capi.BANDS_CONTIGUOUS)
+            g.set_pipeline(3)
+            assert g.pipeline_depth == 3 and g.bands == (capi.BANDS_INTERLEAVED if bands == "interleaved" else capi.BANDS_CONTIGUOUS)
+            with pytest.raises(capi.TrgError):
+                g.set_option(capi.OPT_TIMING, 1)          # a pipelined group only enqueues
+            for mode, root in ((capi.GATHER_ALL, 0), (capi.GATHER_ROOT, n - 1)):
+                for L in (1, 2, 3, 4, 5, 8):
+                    g.time_launches(True)
+                    for i in range(L):
+                        g.render(0, spps[i], bnc, gather=mode, root=root)
+                    ref = refs[spps[L - 1]]
+                    for r in (range(n) if mode == capi.GATHER_ALL else [root]):
+                        assert np.array_equal(_bits(g.read_accum(r)), _bits(ref)), (n, mode, L, r)
+                    for r in range(n):
+                        ms = g.launch_ms(r)
+                        assert len(ms) == L and all(t > 0 for t in ms), (n, r, ms)
+                        assert g.launch_ms(r) == []
+                    g.time_launches(False)
+            # the run-ahead bound: at most two frames enqueued beyond what has finished
+            for i in range(7):
+                g.fence_wait(i % 2)
+                g.render(0, spps[i], bnc, gather=capi.GATHER_ALL)
+                g.fence_record(i % 2)
+            g.fence_wait(0); g.fence_wait(1)
+            for r in range(n):
+                assert np.array_equal(_bits(g.read_accum(r)), _bits(refs[spps[6]])), (n, "fenced", r)
+            g.reset_stats()
+            g.render(0, 2, bnc, gather=capi.GATHER_NONE)
+            g.render(0, 3, bnc, gather=capi.GATHER_NONE)
+            one = g.stats().rays                           # (waits for every render stream of every rank)
+            assert one > 0
+            # back to one buffer: the accumulation is continued in place across launches
+            g.set_pipeline(1)
+            g.render(0, 2, bnc, gather=capi.GATHER_ALL)
+            g.render(2, 3, bnc, gather=capi.GATHER_ALL)
+            g.sync()
+            for r in range(n):
+                assert np.array_equal(_bits(g.read_accum(r)), _bits(refs[5])), (n, "progressive", r)
+            pp = g.postprocess(0)                          # N1 on the group's frame (the unpacked image of an interleaved group)
+            assert pp.shape == (h, w, 4) and pp[..., 3].min() == 255 and pp[..., :3].max() > 0
+        finally:
+            g.close()
+
+
+def test_pipelined_group_exchange_through_rccl_on_one_device(capi, O, cornell, monkeypatch):
+    """The RCCL side of the pipeline as far as ONE GPU can run it (TRG_GROUP_FORCE_RCCL: a communicator of one rank): the in-place
+    ncclAllGather / the grouped send-recv go to the device's exchange stream behind the `rendered` event, the slot's next render waits
+    for the `taken` event -- five frames over three slots without a host wait, the last one bit for bit."""
+    monkeypatch.setenv("TRG_GROUP_FORCE_RCCL", "1")
+    w, h, bnc = 120, 45, 3
+    ref_ctx = make_ctx(O, cornell, w, h)
+    try:
+        ref_ctx.set_option(capi.OPT_STRICT, 1)
+        ref_ctx.render(0, 2, bnc)
+        ref = ref_ctx.read_accum()
+    finally:
+        ref_ctx.close()
+    g = _group_ready(capi, O, cornell, [0], w, h)
+    try:
+        assert g.exchange == capi.EXCHANGE_RCCL and g.exchange_note == ""
+        g.set_pipeline(3)
+        for mode in (capi.GATHER_ALL, capi.GATHER_ROOT):
+            for spp in (1, 3, 1, 3, 2):
+                g.render(0, spp, bnc, gather=mode, root=0)
+            g.fence_record(0); g.fence_wait(0)
+            assert np.array_equal(_bits(g.read_accum(0)), _bits(ref)), mode
+    finally:
+        g.close()
+
+
+def test_device_group_on_distinct_devices(capi, O, cornell, monkeypatch):
+    """the cross-device calls -- hipMemcpyPeerAsync between two GPUs, stream waits on another device's events, and an RCCL
+    communicator of more than one rank -- run only where there are two devices.  On such a machine: distinct devices, both exchanges,
+    one buffer and pipelined, every gather mode, bit for bit against the plain context.  (Skipped on the single-GPU development boxes;
+    the driver's multi-GPU node runs it.)"""
+    import torch
+    ndev = torch.cuda.device_count()
+    if ndev < 2:
+        pytest.skip("needs two GPUs (this box has %d)" % ndev)
+    w, h, bnc = 200, 93, 3
+    ref_ctx = make_ctx(O, cornell, w, h)
+    try:
+        ref_ctx.set_option(capi.OPT_STRICT, 1)
+        ref_ctx.render(0, 2, bnc)
+        ref = ref_ctx.read_accum()
+    finally:
+        ref_ctx.close()
+    for exchange in ("copy", "rccl"):
+        monkeypatch.setenv("TRG_GROUP_EXCHANGE", exchange)
+        for n in sorted({2, min(ndev, 8)}):
+            g = _group_ready(capi, O, cornell, list(range(n)), w, h)
+            try:
+                assert g.exchange == (capi.EXCHANGE_COPY if exchange == "copy" else capi.EXCHANGE_RCCL)
+                for depth in (1, 3):
+                    g.set_pipeline(depth)
+                    for mode, root in ((capi.GATHER_ALL, 0), (capi.GATHER_ROOT, n - 1)):
+                        for spp in (1, 3, 1, 2):
+                            g.render(0, spp, bnc, gather=mode, root=root)
+                        for r in (range(n) if mode == capi.GATHER_ALL else [root]):
+                            assert np.array_equal(_bits(g.read_accum(r)), _bits(ref)), (exchange, n, depth, mode, r)
+                assert torch.cuda.current_device() == 0      # the group leaves the caller's device alone
+            finally:
+                g.close()
+
+
+@pytest.mark.parametrize("schedule", ["lds", "lds_fp2", "lds_fp4", "lds_tail", "hbm", "hbm_regen", "hbm_fp2"])
+def test_interleaved_bands_render_the_same_frame(capi, O, cornell, schedule):
+    """trg_render_bands / trg_unpack_bands (round 4, SURVEY 8e's micro-bands): rank r of n renders the 8-row micro-bands r, r + n, ... of the
+    image compactly into its slice of a bound buffer; all ranks' slices + the unpack give the plain context's frame BIT FOR BIT and the
+    ray counts add up -- for every kernel a band can resolve to (frame-serial, frame lanes, tail compaction, HBM lock step, path
+    regeneration), heights that are no multiple of 8, more ranks than micro-bands, and with the accumulation continued across launches."""
+    import torch
+    from toyraygun_amd.dist import unpack_bands_reference
+    w, bnc = 150, (6 if schedule == "lds_tail" else 3)
+    for h, n in ((93, 3), (93, 8), (40, 2), (21, 5)):
+        c = make_ctx(O, cornell, w, h)
+        try:
+            c.set_option(capi.OPT_STRICT, 1)
+            c.set_option(capi.OPT_FORCE_GLOBAL, 1 if schedule.startswith("hbm") else 0)
+            c.set_option(capi.OPT_REGEN, 1 if schedule == "hbm_regen" else 0)
+            c.set_option(capi.OPT_FRAME_SPLIT, {"lds_fp2": 2, "lds_fp4": 4, "hbm_fp2": 2}.get(schedule, 1))
+            c.set_option(capi.OPT_TAIL_BOUNCE, 2 if schedule == "lds_tail" else 0)
+            c.reset_stats()
+            c.render(0, 2, bnc)
+            c.render(2, 3, bnc)
+            ref, rays = c.read_accum(), c.stats().rays
+            with pytest.raises(capi.TrgError):
+                c.render_bands(0, 1, bnc, n, n, 0)                     # rank out of range
+            rows0, stride = capi.microband_rows(h, n, 0)
+            if n * stride > h:
+                with pytest.raises(capi.TrgError):
+                    c.render_bands(0, 1, bnc, n, n - 1, (n - 1) * stride + 8)   # does not fit the context's own buffer
+            compact = torch.zeros((n * stride, w, 4), dtype=torch.float32, device="cuda")
+            image = torch.full((h, w, 4), -1.0, dtype=torch.float32, device="cuda")
+            c.bind_accum(compact.data_ptr())
+            c.reset_stats()
+            for r in range(n):
+                c.render_bands(0, 2, bnc, n, r, r * stride)
+            for r in reversed(range(n)):                                # the continuation reads the compact band back
+                c.render_bands(2, 3, bnc, n, r, r * stride)
+            assert c.stats().rays == rays, (schedule, h, n)
+            c.unpack_bands(compact.data_ptr(), image.data_ptr(), n)
+            c.sync()
+            got = image.cpu().numpy()
+            assert np.array_equal(_bits(got), _bits(ref)), (schedule, h, n)
+            assert np.array_equal(_bits(unpack_bands_reference(compact.cpu().numpy(), h, n)), _bits(ref))
+            c.bind_accum(None)
+            st = c.stats()
+            assert st.last_regen == (1 if schedule == "hbm_regen" else 0) and st.scene_in_lds == (0 if schedule.startswith("hbm") else 1)
+        finally:
+            c.close()
+
+
 def _checker_texture(n, cells, a, b, seed):
     rng = np.random.default_rng(seed)
     yy, xx = np.mgrid[0:n, 0:n]

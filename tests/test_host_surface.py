@@ -560,14 +560,29 @@ def test_bench_runs_plainly_with_several_gpus(built, monkeypatch, capsys):
         def set_uniforms(self, u): pass
         def set_pixel_offsets_seed(self, seed=0): pass
         def set_option(self, o, v): calls.append(("opt", o, v))
-        def render(self, f0, spp, b, gather=capi.GATHER_ALL, root=0): calls.append(("render", gather))
+        exchange, exchange_note = capi.EXCHANGE_RCCL, ""
+        def render(self, f0, spp, b, gather=capi.GATHER_ALL, root=0):
+            calls.append(("render", gather))
+            if self.timing: self.timed += 1
         def sync(self): pass
         def stats(self):
             st = capi.Stats()
             st.primary_rays, st.bounce_rays, st.shadow_rays, st.shaded_hits = 1000, 500, 700, 600
             st.node_fetches, st.tri_tests, st.wave_node_iters, st.scene_in_lds, st.scene_bytes, st.last_render_ms = 9000, 3000, 100, 1, 9900, 0.5
+            st.total_render_ms, st.renders, st.last_frame_split = 1.5, 3, 1
             return st
+        def rank_stats(self, r): return self.stats()
+        def reset_stats(self): pass
         def rank_rays(self): return [1100, 1100]
+        def set_pipeline(self, depth): calls.append(("pipeline", depth))
+        def set_bands(self, mode): calls.append(("bands", mode))
+        def fence_wait(self, slot): pass
+        def fence_record(self, slot): pass
+        timing, timed = False, 0
+        def time_launches(self, on=True): self.timing = bool(on)
+        def launch_ms(self, rank):
+            k, self.timed = (self.timed if rank == self.n - 1 else None), (0 if rank == self.n - 1 else self.timed)
+            return [0.25] * (k if k is not None else self.timed)
         def close(self): calls.append(("close",))
 
     monkeypatch.setattr(capi, "Group", FakeGroup)
@@ -581,7 +596,12 @@ def test_bench_runs_plainly_with_several_gpus(built, monkeypatch, capsys):
     assert "single process" in out["config"]["sharding"] and out["config"]["per_rank_rays_per_step"] == [1100, 1100]
     assert out["config"]["gather_ms_per_step"] >= 0 and "bound" in out["roofline"]   # (the stand-in renders in no time: its rates mean nothing)
     assert ("create", [0, 1], 1920, 1080) in calls and ("close",) in calls
-    assert sum(1 for c in calls if c == ("render", capi.GATHER_ALL)) == 1 + 3 and sum(1 for c in calls if c == ("render", capi.GATHER_NONE)) == 1 + 3
+    assert ("pipeline", 4) in calls and "4 frames in flight" in out["config"]["pipeline"]
+    assert ("bands", capi.BANDS_INTERLEAVED) in calls and "interleaved" in out["config"]["sharding"]
+    bands = out["config"]["bands"]
+    assert len(bands["kernel_alone_ms"]["per_rank"]) == 2 and bands["kernel_ms_in_pipeline"]["max_over_mean"] == 1.0 and bands["rays"]["per_rank"] == [1100.0, 1100.0]
+    # gathered: warm-up 1 + timed 3; without the exchange: counters 1 + alone 3 + priming 4 + timed 3
+    assert sum(1 for c in calls if c == ("render", capi.GATHER_ALL)) == 1 + 3 and sum(1 for c in calls if c == ("render", capi.GATHER_NONE)) == 1 + 3 + 4 + 3
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
     with pytest.raises(SystemExit) as e:
         bench.main(["--gpus", "2", "--no-cpu-baseline"])

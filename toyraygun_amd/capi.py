@@ -101,6 +101,17 @@ _SYMBOLS = [
     ("trg_group_fence_wait", C.c_int, [_P, C.c_int]),
     ("trg_group_read_accum", C.c_int, [_P, C.c_int, _P]),
     ("trg_group_get_stats", C.c_int, [_P, C.POINTER(Stats)]),
+    ("trg_group_set_pipeline", C.c_int, [_P, C.c_int]),
+    ("trg_group_pipeline_depth", C.c_int, [_P]),
+    ("trg_group_time_launches", C.c_int, [_P, C.c_int]),
+    ("trg_group_launch_ms", C.c_int, [_P, C.c_int, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
+    ("trg_group_exchange_note", C.c_char_p, [_P]),
+    ("trg_group_set_bands", C.c_int, [_P, C.c_int]),
+    ("trg_group_bands", C.c_int, [_P]),
+    ("trg_group_postprocess", C.c_int, [_P, C.c_int, _P, C.c_int]),
+    ("trg_microband_rows", None, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("trg_render_bands", C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    ("trg_unpack_bands", C.c_int, [_P, _P, _P, C.c_uint32]),
     ("trg_trace", C.c_int, [_P, _P, C.c_size_t, C.c_int, _P]),
     ("trg_halton", C.c_int, [_P, _P, _P, C.c_size_t, _P]),
     ("trg_halton_table", C.c_int, [_P, _P, _P, C.c_size_t, _P]),
@@ -222,6 +233,15 @@ class Context:
         rows = self.h - row0 if rows is None else rows
         self._chk(self.L.trg_render(self.h_ctx, frame_begin, spp, bounces, row0, rows))
 
+    def render_bands(self, frame_begin, spp, bounces, n_ranks, rank, store_row0):
+        """trg_render_bands: the 8-row micro-bands rank, rank + n_ranks, ... of the image, stored compactly from row store_row0 of the
+        bound accumulation buffer (microband_rows gives the rows and the ranks' common stride)."""
+        self._chk(self.L.trg_render_bands(self.h_ctx, frame_begin, spp, bounces, n_ranks, rank, store_row0))
+
+    def unpack_bands(self, compact_ptr, image_ptr, n_ranks):
+        """trg_unpack_bands: compact frame of n_ranks interleaved bands (device pointer) -> image rows (device pointer), on the context's stream."""
+        self._chk(self.L.trg_unpack_bands(self.h_ctx, C.c_void_p(int(compact_ptr)), C.c_void_p(int(image_ptr)), n_ranks))
+
     def read_accum(self):
         out = np.empty((self.h, self.w, 4), np.float32)
         self._chk(self.L.trg_read_accum(self.h_ctx, _ptr(out)))
@@ -310,6 +330,7 @@ class Context:
 
 
 GATHER_NONE, GATHER_ALL, GATHER_ROOT = 0, 1, 2
+BANDS_CONTIGUOUS, BANDS_INTERLEAVED = 0, 1
 EXCHANGE_NONE, EXCHANGE_RCCL, EXCHANGE_COPY = 0, 1, 2
 
 
@@ -317,6 +338,13 @@ def band_rows(height, n, rank):
     """trg_band_rows: rows [row0, row0 + rows) of device `rank` of `n` (bands of ceil(height / n) rows; host-only)."""
     a, b = C.c_uint32(), C.c_uint32()
     load().trg_band_rows(height, n, rank, C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def microband_rows(height, n, rank):
+    """trg_microband_rows: (rows of rank's interleaved band, the ranks' common stride in rows) -- 8-row micro-bands rank, rank + n, ..."""
+    a, b = C.c_uint32(), C.c_uint32()
+    load().trg_microband_rows(height, n, rank, C.byref(a), C.byref(b))
     return a.value, b.value
 
 
@@ -389,6 +417,43 @@ class Group:
 
     def sync(self):
         self._chk(self.L.trg_group_sync(self.g))
+
+    def set_pipeline(self, depth):
+        """`depth` independent frames in flight per device (trg_group_set_pipeline): depth frame buffers and render streams + one
+        exchange stream per device; 1 = the progressive one-buffer mode."""
+        self._chk(self.L.trg_group_set_pipeline(self.g, int(depth)))
+
+    @property
+    def pipeline_depth(self):
+        return self.L.trg_group_pipeline_depth(self.g)
+
+    @property
+    def exchange_note(self):
+        """Why the exchange is not the one asked for ("" when it is): the RCCL -> peer-copy fallback says so here."""
+        return (self.L.trg_group_exchange_note(self.g) or b"").decode()
+
+    def set_bands(self, mode):
+        """BANDS_CONTIGUOUS (rows [g*B, (g+1)*B) per device) or BANDS_INTERLEAVED (8-row micro-bands dealt round robin, trg_render_bands)."""
+        self._chk(self.L.trg_group_set_bands(self.g, int(mode)))
+
+    @property
+    def bands(self):
+        return self.L.trg_group_bands(self.g)
+
+    def postprocess(self, rank=0, flip_y=True):
+        out = np.empty((self.h, self.w, 4), np.uint8)
+        self._chk(self.L.trg_group_postprocess(self.g, rank, _ptr(out), 1 if flip_y else 0))
+        return out
+
+    def time_launches(self, on=True):
+        self._chk(self.L.trg_group_time_launches(self.g, 1 if on else 0))
+
+    def launch_ms(self, rank, cap=4096):
+        """Durations (ms) of rank's launches since the last read, from HIP events on the streams they ran on (waits for the rank)."""
+        buf = (C.c_double * cap)()
+        n = C.c_uint32(0)
+        self._chk(self.L.trg_group_launch_ms(self.g, rank, buf, cap, C.byref(n)))
+        return [buf[k] for k in range(min(n.value, cap))]
 
     def read_accum(self, rank=0):
         out = np.empty((self.h, self.w, 4), np.float32)

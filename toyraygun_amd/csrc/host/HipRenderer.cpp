@@ -218,14 +218,13 @@ void HipRenderer::setOffsetSeed(uint32_t seed) {
 }
 bool HipRenderer::readAccumulation(float *rgbaOut) {
     if (!m_ctx || !flush()) return false;
-    if (m_group && trg_group_sync(m_group) != TRG_OK) return false;   // the gather onto device 0
+    if (m_group) return trg_group_read_accum(m_group, 0, rgbaOut) == TRG_OK;   // waits for the gather onto device 0 (and the unpack of interleaved bands)
     return trg_read_accum(m_ctx, rgbaOut) == TRG_OK;
 }
 bool HipRenderer::savePNG(const char *path) {
     if (!m_ctx || !flush()) return false;
-    if (m_group && trg_group_sync(m_group) != TRG_OK) return false;
     std::vector<uint8_t> rgba((size_t)m_width * m_height * 4);
-    if (trg_postprocess(m_ctx, rgba.data(), 1) != TRG_OK) return false;
+    if ((m_group ? trg_group_postprocess(m_group, 0, rgba.data(), 1) : trg_postprocess(m_ctx, rgba.data(), 1)) != TRG_OK) return false;
     return trg_host::write_png_rgba8(path, rgba.data(), m_width, m_height);
 }
 double HipRenderer::getLastRenderMs() const {

@@ -786,13 +786,51 @@ int trg_set_pixel_offsets_seed(trg_ctx *c, uint32_t seed) {
     return TRG_OK;
 }
 
+void trg_microband_rows(uint32_t height, uint32_t n, uint32_t r, uint32_t *rows, uint32_t *stride_rows) {
+    const uint32_t nmb = (height + kMicroBandRows - 1u) / kMicroBandRows;          // micro-bands of the image
+    const uint32_t mine = (n && r < n && nmb > r) ? (nmb - r + n - 1u) / n : 0u;   // micro-bands r, r + n, ... below nmb
+    if (rows) *rows = mine * kMicroBandRows;
+    if (stride_rows) *stride_rows = n ? ((nmb + n - 1u) / n) * kMicroBandRows : nmb * kMicroBandRows;
+}
+
+// frames [frame_begin, frame_begin + spp) over rows [row0, row0 + rows) of the accumulation buffer: image rows of the same numbers
+// (il_n <= 1), or the micro-bands il_r, il_r + il_n, ... of the image stored compactly from row0 on (trg_render_bands)
+static int render_impl(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces, uint32_t row0, uint32_t rows, uint32_t il_n, uint32_t il_r);
+
 int trg_render(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces, uint32_t row0, uint32_t rows) {
     if (!c) return TRG_ERR_INVALID;
+    if (row0 > c->h || rows > c->h - row0) return fail(c, TRG_ERR_INVALID, "trg_render: rows [%u,%u) outside the image (height %u)", row0, row0 + rows, c->h);
+    return render_impl(c, frame_begin, spp, bounces, row0, rows, 0u, 0u);
+}
+
+int trg_render_bands(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces, uint32_t n_ranks, uint32_t rank, uint32_t store_row0) {
+    if (!c) return TRG_ERR_INVALID;
+    if (n_ranks == 0 || rank >= n_ranks) return fail(c, TRG_ERR_INVALID, "trg_render_bands: rank %u of %u", rank, n_ranks);
+    uint32_t rows = 0, stride = 0;
+    trg_microband_rows(c->h, n_ranks, rank, &rows, &stride);
+    // the compact band must fit the buffer it goes to: the context's own one has the image's rows; a caller-owned one (trg_bind_accum) is the
+    // caller's to size -- n_ranks * stride rows hold every rank's band
+    if (c->accum == c->accum_own && (uint64_t)store_row0 + rows > c->h)
+        return fail(c, TRG_ERR_INVALID, "trg_render_bands: rows [%u,%u) do not fit the context's own accumulation buffer (height %u): bind one of n * stride rows", store_row0, store_row0 + rows, c->h);
+    return render_impl(c, frame_begin, spp, bounces, store_row0, rows, n_ranks, rank);
+}
+
+int trg_unpack_bands(trg_ctx *c, const void *compact, void *image, uint32_t n_ranks) {
+    if (!c || !compact || !image || n_ranks == 0 || compact == image) return TRG_ERR_INVALID;
+    if ((((uintptr_t)compact) | ((uintptr_t)image)) & 15u) return fail(c, TRG_ERR_INVALID, "trg_unpack_bands: pointers must be 16-byte aligned");
+    HIPCHK(c, hipSetDevice(c->device));
+    uint32_t stride = 0;
+    trg_microband_rows(c->h, n_ranks, 0, nullptr, &stride);
+    const hipError_t e = launch_unpack_bands_fast(static_cast<const float *>(compact), static_cast<float *>(image), c->w, c->h, n_ranks, stride, c->stream);
+    if (e != hipSuccess) return fail(c, TRG_ERR_DEVICE, "trg_unpack_bands: launch failed: %s", hipGetErrorString(e));
+    return TRG_OK;
+}
+
+static int render_impl(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces, uint32_t row0, uint32_t rows, uint32_t il_n, uint32_t il_r) {
     if (!c->scene_loaded) return fail(c, TRG_ERR_INVALID, "trg_render: no scene loaded");
     if (!c->have_uniforms) return fail(c, TRG_ERR_INVALID, "trg_render: uniforms not set");
     if (!c->have_offsets) return fail(c, TRG_ERR_INVALID, "trg_render: pixel offsets not set");
     if (bounces > TRG_MAX_BOUNCES) return fail(c, TRG_ERR_RANGE, "trg_render: %u bounces > TRG_MAX_BOUNCES (%u)", bounces, TRG_MAX_BOUNCES);
-    if (row0 > c->h || rows > c->h - row0) return fail(c, TRG_ERR_INVALID, "trg_render: rows [%u,%u) outside the image (height %u)", row0, row0 + rows, c->h);
     if ((uint64_t)frame_begin + spp > 0xFFFFFFFFull) return fail(c, TRG_ERR_INVALID, "trg_render: frame range overflows");
     if (spp == 0 || rows == 0) { c->last_ms = 0.0; return TRG_OK; }
     HIPCHK(c, hipSetDevice(c->device));
@@ -804,6 +842,8 @@ int trg_render(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces,
         if (int rc = plan_lds(c, probe)) return rc;
         kernel = (!probe.lds_scene && TRG_WAVEFRONT_FOR_HBM) ? TRG_KERNEL_WAVEFRONT : TRG_KERNEL_DIRECT;
     }
+    if (il_n > 1u && kernel != TRG_KERNEL_DIRECT)
+        return fail(c, TRG_ERR_INVALID, "trg_render_bands: interleaved bands are rendered by the direct megakernel only (TRG_OPT_KERNEL %d)", kernel);
     if (kernel == TRG_KERNEL_WAVEFRONT) {
         if (c->opt_timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
         if (int rc = render_wavefront(c, frame_begin, spp, bounces, row0, rows, slot)) return rc;
@@ -847,6 +887,7 @@ int trg_render(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces,
     p.frame_begin = frame_begin; p.spp = spp; p.bounces = bounces; p.row0 = row0; p.rows = rows;
     p.stack_off = plan.stack_off; p.red_off = plan.red_off; p.pool_off = plan.pool_off;
     p.fsplit = fsplit; p.fp_rounds = fp_rounds; p.acc_off = plan.acc_off;
+    p.il_n = il_n > 1u ? il_n : 0u; p.il_r = il_n > 1u ? il_r : 0u;
     p.tex = c->tex;
     // workgroup tile: 16x16 pixels, or (4/fsplit) 8x8 sub-tiles side by side when the frames are split over waves
     const uint32_t tile_w = fsplit > 1 ? 8u * (kWaves / fsplit) : (uint32_t)kTileW, tile_h = fsplit > 1 ? 8u : (uint32_t)kTileH;

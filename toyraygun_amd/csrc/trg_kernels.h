@@ -95,7 +95,13 @@ struct RenderParams {
     // workgroup -> tile (trg_kernels.hip block_tile): tiles_x x tiles_y tiles of the launch; xcd_cols = 0: image columns from the centre
     // outwards; 1, 2, 4, 8: the workgroups of one XCD (blockIdx.x % 8) own one of xcd_cols x (8 / xcd_cols) contiguous screen regions
     uint32_t tiles_y, xcd_cols;
+    // INTERLEAVED row bands (trg_render_bands; SURVEY 8e's micro-bands, 8 rows each): il_n > 1 = this launch renders the micro-bands
+    // il_r, il_r + il_n, il_r + 2 il_n ... of the image and stores them COMPACTLY: local row l (micro-band l / 8 of this rank) is image
+    // row ((l / 8) * il_n + il_r) * 8 + l % 8 for the camera ray and the pixel's Halton offset, and row row0 + l of the accumulation
+    // buffer.  il_n <= 1: rows [row0, row0 + rows) of the image, stored where they are.
+    uint32_t il_n, il_r;
 };
+constexpr uint32_t kMicroBandRows = 8;   // = the rows of a wavefront's 8x8 sub-tile: a wavefront never straddles two micro-bands
 constexpr uint32_t kXcds = 8;   // XCDs of an MI355X: workgroups are dealt round-robin over them (MI355X_MICROARCH.md, workgroup dispatch)
 
 // Workgroup slot -> tile of a launch over tiles_x x tiles_y tiles (any bijection onto the tiles is correct; this is about time only).
@@ -228,6 +234,8 @@ static_assert(!(kSignedLds || kWideLds || kThreadedLds) || kWideHbm, "the LDS no
     hipError_t launch_postprocess_##SFX(const float *accum, uint32_t w, uint32_t h, uint8_t *rgba8, int flip_y,  \
                                         hipStream_t s);                                                          \
     hipError_t launch_offsets_##SFX(uint32_t seed, uint32_t n, uint32_t *out, hipStream_t s);                   \
+    hipError_t launch_unpack_bands_##SFX(const float *compact, float *image, uint32_t w, uint32_t h, uint32_t n, uint32_t B, \
+                                         hipStream_t s);                                                        \
     hipError_t launch_xcc_probe_##SFX(uint32_t n_blocks, uint32_t *out, hipStream_t s);
 
 TRG_DECL_LAUNCHERS(fast)

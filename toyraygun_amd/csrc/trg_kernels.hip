@@ -71,6 +71,15 @@ TRG_DEV bool block_tile(const trg::RenderParams &p, uint32_t slot, uint32_t &bx,
     return trg::tile_of_slot(p.tiles_x, p.tiles_y, p.xcd_cols, slot, bx, by);
 }
 
+// storage row (row of the accumulation buffer) -> image row (trg_kernels.h RenderParams::il_n): the identity unless the launch renders
+// interleaved micro-bands.  For the first row of a wavefront's sub-tile the result is wave-uniform (scalar arithmetic), and the
+// sub-tile's other rows follow it (8-row micro-bands = sub-tile height).
+TRG_DEV uint32_t image_row(const trg::RenderParams &p, uint32_t y_store) {
+    if (p.il_n <= 1u) return y_store;
+    const uint32_t l = y_store - p.row0;
+    return ((l / trg::kMicroBandRows) * p.il_n + p.il_r) * trg::kMicroBandRows + (l % trg::kMicroBandRows);
+}
+
 // The shading event of one bounce (primaryHit, Raytracing.metal:115-215) for the lane's current ray and its
 // nearest-hit record: updates throughput / radiance / path state, moves the ray to the continuation ray and
 // returns the shadow ray to trace.  Shared by both loop shapes of render_kernel.
@@ -261,7 +270,8 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES : TRG_EXP_WA
     uint32_t bx, by;
     if (!block_tile(p, blockIdx.x, bx, by)) return;   // (a padding slot of the XCD-aware order)
     const uint32_t x0 = bx * trg::kTileW + (wave % (trg::kTileW / 8)) * 8;           // wave-uniform
-    const uint32_t y0 = p.row0 + by * trg::kTileH + (wave / (trg::kTileW / 8)) * 8;  // wave-uniform
+    const uint32_t y0 = p.row0 + by * trg::kTileH + (wave / (trg::kTileW / 8)) * 8;  // wave-uniform: row of the accumulation buffer
+    const uint32_t y0i = image_row(p, y0);                                            // wave-uniform: row of the image (interleaved bands)
     bool valid;
     uint32_t offset = 0u;
     v4f *accum = reinterpret_cast<v4f *>(p.accum);
@@ -273,10 +283,10 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES : TRG_EXP_WA
     V3 acc = mk(0.0f, 0.0f, 0.0f);
     {
         const uint32_t lane = lane_id();
-        const uint32_t x = x0 + (lane & 7), y = y0 + (lane >> 3);
-        valid = (x < p.u.width) && (y < p.row0 + p.rows) && (y < p.u.height);
+        const uint32_t x = x0 + (lane & 7), y = y0 + (lane >> 3), yi = y0i + (lane >> 3);
+        valid = (x < p.u.width) && (y < p.row0 + p.rows) && (yi < p.u.height);
         const uint32_t pix = y * p.u.width + x;
-        if (valid) offset = p.offsets[pix];
+        if (valid) offset = p.offsets[yi * p.u.width + x];
         if (valid && p.frame_begin > 0) { const v4f a = accum[pix]; acc = mk(a.x, a.y, a.z); }
         if (PARK) { park[0] = acc.x; park[trg::kBlock] = acc.y; park[2 * trg::kBlock] = acc.z; }
         if (TRG_PARK_OFFSET && path_park) { path_park[6 * trg::kBlock] = __int_as_float((int)offset); offset = 0u; }
@@ -292,7 +302,7 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES : TRG_EXP_WA
         // frame and were spilled to scratch at 8 waves/SIMD (profiles/r01: 13 scratch stores per pixel = the 3.4x write
         // amplification, 8 scratch reloads per frame).  Recomputing them costs a dozen VALU instructions per frame.
         const uint32_t lane_f = lane_id_opaque();
-        const uint32_t xf = x0 + (lane_f & 7), yf = y0 + (lane_f >> 3);
+        const uint32_t xf = x0 + (lane_f & 7), yf = y0i + (lane_f >> 3);
         const V3 rad = path_radiance<LDS_SCENE, COUNT>(p, sc, stk, xf, yf, offset, f, valid, light_color, pc, cnt, path_park);
         if (PARK) acc = mk(park[0], park[trg::kBlock], park[2 * trg::kBlock]);
         // Accumulate.metal:19-39
@@ -368,6 +378,7 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES_FP : TRG_EXP
     uint32_t bx, by;                                         // tile order as render_kernel
     if (!block_tile(p, blockIdx.x, bx, by)) return;
     const uint32_t x0 = (bx * subt + sub) * 8u, y0 = p.row0 + by * 8u;   // wave-uniform
+    const uint32_t y0i = image_row(p, y0);                                // row of the image (interleaved bands)
     bool valid;
     uint32_t offset = 0u;
     v4f *accum = reinterpret_cast<v4f *>(p.accum);
@@ -378,10 +389,10 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES_FP : TRG_EXP
     lds_float_t *path_park = PARK ? (lds_float_t *)(reinterpret_cast<float *>(smem + p.acc_off) + threadIdx.x) : nullptr;
     {
         const uint32_t lane = lane_id();
-        const uint32_t x = x0 + (lane & 7), y = y0 + (lane >> 3);
-        valid = (x < p.u.width) && (y < p.row0 + p.rows) && (y < p.u.height);
+        const uint32_t x = x0 + (lane & 7), y = y0 + (lane >> 3), yi = y0i + (lane >> 3);
+        valid = (x < p.u.width) && (y < p.row0 + p.rows) && (yi < p.u.height);
         const uint32_t pix = y * p.u.width + x;
-        if (valid) offset = p.offsets[pix];
+        if (valid) offset = p.offsets[yi * p.u.width + x];
         if (fl == 0 && valid && p.frame_begin > 0) { const v4f a = accum[pix]; acc = mk(a.x, a.y, a.z); }
         if (PARK) { path_park[6 * trg::kBlock] = __int_as_float((int)offset); offset = 0u; }
     }
@@ -399,7 +410,7 @@ __global__ __launch_bounds__(trg::kBlock, LDS_SCENE ? TRG_EXP_WAVES_FP : TRG_EXP
             const uint64_t i = rel + (uint64_t)r * F + fl;
             if (i >= p.spp) break;   // wave-uniform
             const uint32_t lane_f = lane_id_opaque();
-            const V3 rad = path_radiance<LDS_SCENE, COUNT>(p, sc, stk, x0 + (lane_f & 7), y0 + (lane_f >> 3), offset, p.frame_begin + (uint32_t)i, valid, light_color, pc, cnt, path_park);
+            const V3 rad = path_radiance<LDS_SCENE, COUNT>(p, sc, stk, x0 + (lane_f & 7), y0i + (lane_f >> 3), offset, p.frame_begin + (uint32_t)i, valid, light_color, pc, cnt, path_park);
             float *slot = park + (size_t)(r * F + fl) * 3u * npx + sub * 64u + lane_id_opaque();
             slot[0] = rad.x; slot[npx] = rad.y; slot[2u * npx] = rad.z;
         }
@@ -721,6 +732,17 @@ __global__ void postprocess_kernel(const v4f *accum, uint32_t w, uint32_t h, uin
     rgba8[i] = packed;
 }
 
+// interleaved row bands -> image rows (trg_unpack_bands): the gathered COMPACT frame holds rank r's micro-bands r, r + n, r + 2n ... in
+// rows [r * B, r * B + its rows); image row y = micro-band y / 8 belongs to rank (y / 8) % n, local micro-band (y / 8) / n.
+// 16 B read + 16 B write per pixel, HBM-streaming.
+__global__ void unpack_bands_kernel(const v4f *compact, v4f *image, uint32_t w, uint32_t h, uint32_t n, uint32_t B) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= w * h) return;
+    const uint32_t y = i / w, x = i - y * w;
+    const uint32_t mb = y / trg::kMicroBandRows, r = mb % n, l = (mb / n) * trg::kMicroBandRows + y % trg::kMicroBandRows;
+    image[i] = compact[(size_t)(r * B + l) * w + x];
+}
+
 // which XCD does workgroup b run on?  (HW_REG_XCC_ID, bits 3:0; MI355X_MICROARCH.md "Workgroup dispatch, XCD placement")
 __global__ void xcc_probe_kernel(uint32_t *out) {
     uint32_t id;
@@ -870,6 +892,13 @@ hipError_t SFX(launch_postprocess)(const float *accum, uint32_t w, uint32_t h, u
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(postprocess_kernel, dim3((n + 255) / 256), dim3(256), 0, s, reinterpret_cast<const v4f *>(accum), w, h,
                        reinterpret_cast<uint32_t *>(rgba8), flip_y);
+    return hipGetLastError();
+}
+
+hipError_t SFX(launch_unpack_bands)(const float *compact, float *image, uint32_t w, uint32_t h, uint32_t n, uint32_t B, hipStream_t s) {
+    const uint32_t px = w * h;
+    if (px == 0) return hipSuccess;
+    hipLaunchKernelGGL(unpack_bands_kernel, dim3((px + 255) / 256), dim3(256), 0, s, reinterpret_cast<const v4f *>(compact), reinterpret_cast<v4f *>(image), w, h, n, B);
     return hipGetLastError();
 }
 

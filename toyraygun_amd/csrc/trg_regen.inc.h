@@ -198,11 +198,12 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
                             // consecutive jobs = the pixels of one 8x8 sub-tile, sub-tile after sub-tile, frame after frame
                             const uint32_t pl = TRG_RG_JOB % (uint32_t)trg::kBlock, sub = pl >> 6;
                             const uint32_t x = x0 + (sub % (trg::kTileW / 8)) * 8u + (pl & 7u), y = y0 + (sub / (trg::kTileW / 8)) * 8u + ((pl >> 3) & 7u);
-                            job_valid = (x < p.u.width) && (y < p.row0 + p.rows) && (y < p.u.height);
+                            const uint32_t yi = image_row(p, y);   // (interleaved bands: the image row of this row of the accumulation buffer)
+                            job_valid = (x < p.u.width) && (y < p.row0 + p.rows) && (yi < p.u.height);
                             if (job_valid) {
-                                park[trg::kBlock] = __int_as_float((int)p.offsets[y * p.u.width + x]);
+                                park[trg::kBlock] = __int_as_float((int)p.offsets[yi * p.u.width + x]);
                                 V3 o, d;
-                                raygen<false>(TRG_RG_U, x, y, TRG_RG_HIDX, o, d, nullptr);
+                                raygen<false>(TRG_RG_U, x, yi, TRG_RG_HIDX, o, d, nullptr);
                                 park[3 * trg::kBlock] = 1.0f; park[4 * trg::kBlock] = 1.0f; park[5 * trg::kBlock] = 1.0f;   // ray.color
                                 park[6 * trg::kBlock] = 0.0f; park[7 * trg::kBlock] = 0.0f; park[8 * trg::kBlock] = 0.0f;   // the frame's texel
                                 primary_ray = true;   // (taking the job has reset the event count)
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(trg::kBlock) void regen_accumulate_kernel(const trg
     const uint32_t pl = threadIdx.x, sub = pl >> 6;
     const uint32_t x = bx * trg::kTileW + (sub % (trg::kTileW / 8)) * 8u + (pl & 7u);
     const uint32_t y = p.row0 + by * trg::kTileH + (sub / (trg::kTileW / 8)) * 8u + ((pl >> 3) & 7u);
-    const bool valid = (x < p.u.width) && (y < p.row0 + p.rows) && (y < p.u.height);
+    const bool valid = (x < p.u.width) && (y < p.row0 + p.rows) && (image_row(p, y) < p.u.height);
     const uint32_t n_valid = (uint32_t)__syncthreads_count(valid ? 1 : 0);   // every valid pixel logged every frame of the chunk
     const uint32_t F = p.fsplit, frames_max = (p.spp + F - 1u) / F;
     for (uint32_t fl = 0; fl < F; ++fl) {   // the logs of the tile's frame lanes

@@ -76,14 +76,15 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES) void render_head_kernel
         return;
     }
     const uint32_t x0 = bx * trg::kTileW + (wave % (trg::kTileW / 8)) * 8;
-    const uint32_t y0 = p.row0 + by * trg::kTileH + (wave / (trg::kTileW / 8)) * 8;
+    const uint32_t y0 = p.row0 + by * trg::kTileH + (wave / (trg::kTileW / 8)) * 8;   // row of the accumulation buffer
+    const uint32_t y0i = image_row(p, y0);                                             // row of the image (interleaved bands)
     bool valid;
     uint32_t offset = 0u;
     {
         const uint32_t lane = lane_id();
-        const uint32_t x = x0 + (lane & 7), y = y0 + (lane >> 3);
-        valid = (x < p.u.width) && (y < p.row0 + p.rows) && (y < p.u.height);
-        if (valid) offset = p.offsets[y * p.u.width + x];
+        const uint32_t x = x0 + (lane & 7), y = y0 + (lane >> 3), yi = y0i + (lane >> 3);
+        valid = (x < p.u.width) && (y < p.row0 + p.rows) && (yi < p.u.height);
+        if (valid) offset = p.offsets[yi * p.u.width + x];
     }
     PathCounters pc; pc.primary = 0; pc.bounce = 0; pc.shadow = 0; pc.shaded = 0;
     Counters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.wnodes = 0; cnt.wtris = 0;
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES) void render_head_kernel
         const uint32_t xf = x0 + (lane_f & 7), yf = y0 + (lane_f >> 3);
         asm volatile("" : "+s"(up));
         V3 o, d;
-        raygen<TAB>(*(const trg_uniforms *)up, xf, yf, offset + f, o, d, sc.htab);
+        raygen<TAB>(*(const trg_uniforms *)up, xf, y0i + (lane_f >> 3), offset + f, o, d, sc.htab);
         V3 thr = mk(1.0f, 1.0f, 1.0f), rad = mk(0.0f, 0.0f, 0.0f);
         bool active = valid, primary_ray = true;
         pc.primary += wave_count(active);
@@ -168,7 +169,12 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES) void render_tail_kernel
             fl = fbits & 0x7FFFFFFFu; primary_ray = (fbits >> 31) != 0u;
             const v4f r4 = radbuf[(size_t)fl * p.tail_band_pixels + pl];
             rad = mk(r4.x, r4.y, r4.z);
-            offset = p.offsets[p.row0 * p.u.width + pl];
+            if (p.il_n <= 1u) {
+                offset = p.offsets[p.row0 * p.u.width + pl];
+            } else {   // interleaved bands: `pl` counts pixels of the compact band; the Halton offsets are indexed by image pixel
+                const uint32_t l = pl / p.u.width;
+                offset = p.offsets[image_row(p, p.row0 + l) * p.u.width + (pl - l * p.u.width)];
+            }
         }
         // `frame` must be wave-uniform for path_segment_lds (Halton index = offset + frame): the entries of one round may belong
         // to different frames, so the per-lane frame rides in `offset` and the uniform part is zero

@@ -36,6 +36,27 @@ def band_rows(height, world, rank):
     return row0, row1 - row0
 
 
+MICRO_BAND_ROWS = 8   # trg_kernels.h kMicroBandRows: the height of a wavefront's sub-tile
+
+
+def microband_rows(height, world, rank):
+    """(rows of rank's INTERLEAVED band, the ranks' common stride in rows): rank renders the 8-row micro-bands rank, rank + world, ... of the
+    image and stores them compactly in rows [rank * stride, rank * stride + rows) of a (world * stride)-row buffer -- the rule of
+    trg_microband_rows (include/trg.h; tests assert they agree)."""
+    nmb = -(-height // MICRO_BAND_ROWS)
+    mine = -(-(nmb - rank) // world) if nmb > rank else 0
+    return mine * MICRO_BAND_ROWS, -(-nmb // world) * MICRO_BAND_ROWS
+
+
+def unpack_bands_reference(compact, height, world):
+    """What trg_unpack_bands computes, in numpy / torch indexing (tests, CPU rehearsals): image row y <- compact row r * stride + l with
+    r = (y // 8) % world, l = (y // 8 // world) * 8 + y % 8."""
+    _, stride = microband_rows(height, world, 0)
+    ys = list(range(height))
+    src = [((y // MICRO_BAND_ROWS) % world) * stride + (y // MICRO_BAND_ROWS // world) * MICRO_BAND_ROWS + y % MICRO_BAND_ROWS for y in ys]
+    return compact[src]
+
+
 def gather_bands(full, world, rank, group=None, root=None):
     """All-gather the row bands of `full` ([h, w, 4] float32, this rank's band already filled) in place.
     root = r: gather to rank r only (the other ranks keep just their own band) -- one eighth of the traffic when only
@@ -99,7 +120,7 @@ def gather_bands(full, world, rank, group=None, root=None):
 class DistributedRenderer:
     """Row-band sharded renderer over an initialised process group (one rank per GPU)."""
 
-    def __init__(self, width, height, device_index, group=None, pipelined=False, depth=None):
+    def __init__(self, width, height, device_index, group=None, pipelined=False, depth=None, interleaved=None):
         from . import capi
         self.capi = capi
         self.group = group
@@ -108,6 +129,14 @@ class DistributedRenderer:
         self.w, self.h = width, height
         self.device = torch.device("cuda", device_index)
         self.row0, self.rows = band_rows(height, self.world, self.rank)
+        # INTERLEAVED bands (trg_render_bands): 8-row micro-bands dealt round robin even out what the bands cost (contiguous bands of C2 at 8
+        # GPUs: slowest / mean 1.05, of the million-triangle scene 1.2).  The band is rendered compactly into this rank's slice of a
+        # (world * stride)-row buffer, the in-place all-gather completes the compact frame, trg_unpack_bands turns it into the image on
+        # the communication stream.  Default: on for more than one rank (TRG_BANDS=contiguous turns it off).
+        if interleaved is None:
+            interleaved = self.world > 1 and os.environ.get("TRG_BANDS", "interleaved") != "contiguous"
+        self.interleaved = bool(interleaved)
+        self.il_rows, self.il_stride = microband_rows(height, self.world, self.rank)
         if depth is None:
             # frames in flight: 2 hide the tail of a launch that fills the chip; a small band (a fraction of one resident set
             # of workgroups) needs more to fill it at all.  4 is never worse than 2 (C2 ms per step, 2 -> 4 in flight: full
@@ -117,13 +146,15 @@ class DistributedRenderer:
         torch.cuda.set_device(self.device)
         self.ctx = capi.Context(width, height, device=device_index)
         # torch owns the frames (so RCCL can see them); the kernel writes into them through trg_bind_accum
-        self.frames = [torch.zeros((height, width, 4), dtype=torch.float32, device=self.device)
-                       for _ in range(depth if pipelined else 1)]
+        nslots = depth if pipelined else 1
+        if self.interleaved:
+            self.compact = [torch.zeros((self.world * self.il_stride, width, 4), dtype=torch.float32, device=self.device) for _ in range(nslots)]
+        self.frames = [torch.zeros((height, width, 4), dtype=torch.float32, device=self.device) for _ in range(nslots)]
         self.render_streams = [torch.cuda.Stream(self.device) for _ in range(depth if pipelined else 1)]
         self.render_stream = self.render_streams[0]
         self.comm_stream = torch.cuda.Stream(self.device) if pipelined else self.render_stream
         self.ctx.set_stream(self.render_stream.cuda_stream)
-        self.ctx.bind_accum(self.frames[0].data_ptr())
+        self.ctx.bind_accum((self.compact if self.interleaved else self.frames)[0].data_ptr())
         self._step = 0
         self._gathered = [None] * len(self.frames)  # event: last gather into frames[i] has finished
         self.frame = self.frames[0]
@@ -150,9 +181,10 @@ class DistributedRenderer:
         i = self._step % len(self.frames)
         self._step += 1
         frame = self.frames[i]
+        target = self.compact[i] if self.interleaved else frame      # what the kernel writes: the compact band buffer, or the image itself
         rs = self.render_streams[i] if getattr(self, "_overlap", False) else self.render_stream
         if len(self.frames) > 1:
-            self.ctx.bind_accum(frame.data_ptr())
+            self.ctx.bind_accum(target.data_ptr())
             if rs is not self._last_stream:
                 self.ctx.set_stream(rs.cuda_stream)
                 self._last_stream = rs
@@ -161,24 +193,55 @@ class DistributedRenderer:
         if self.time_launches:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(rs)
-            self.ctx.render(frame_begin, spp, bounces, self.row0, self.rows)
+            self._launch(frame_begin, spp, bounces)
             e1.record(rs)
             self._timed.append((e0, e1))
         else:
-            self.ctx.render(frame_begin, spp, bounces, self.row0, self.rows)
-        if gather and self._needs_gather:
+            self._launch(frame_begin, spp, bounces)
+        gathered = gather and self._needs_gather
+        if gathered:
             if self.comm_stream is not rs:
                 done = torch.cuda.Event()
                 done.record(rs)
                 self.comm_stream.wait_event(done)
             with torch.cuda.stream(self.comm_stream):
-                gather_bands(frame, self.world, self.rank, self.group)
+                gather_bands(target, self.world, self.rank, self.group)   # (a compact frame always has equal bands: in place)
+                if self.interleaved:
+                    self._unpack(target, frame, self.comm_stream, rs)
                 if len(self.frames) > 1:
                     ev = torch.cuda.Event()
                     ev.record(self.comm_stream)
                     self._gathered[i] = ev
+        elif self.interleaved:
+            self._unpack(target, frame, rs, rs)       # this rank's micro-bands alone, right behind the render
         self.frame = frame
         return frame
+
+    @property
+    def owned_rows(self):
+        """Image rows this rank renders (its contiguous band, or the rows of its micro-bands that lie inside the image)."""
+        if not self.interleaved:
+            return self.rows
+        nmb = -(-self.h // MICRO_BAND_ROWS)
+        return sum(min(MICRO_BAND_ROWS, self.h - j * MICRO_BAND_ROWS) for j in range(self.rank, nmb, self.world))
+
+    def launch_band(self, frame_begin, spp, bounces):
+        """This rank's band into the currently bound buffer on the context's current stream, nothing else (counters / launch-alone passes)."""
+        self._launch(frame_begin, spp, bounces)
+
+    def _launch(self, frame_begin, spp, bounces):
+        if self.interleaved:
+            self.ctx.render_bands(frame_begin, spp, bounces, self.world, self.rank, self.rank * self.il_stride)
+        else:
+            self.ctx.render(frame_begin, spp, bounces, self.row0, self.rows)
+
+    def _unpack(self, compact, frame, on, back_to):
+        """trg_unpack_bands on stream `on` (the context launches on its current stream: switched for the call, a host-side pointer)."""
+        if on is not back_to:
+            self.ctx.set_stream(on.cuda_stream)
+        self.ctx.unpack_bands(compact.data_ptr(), frame.data_ptr(), self.world)
+        if on is not back_to:
+            self.ctx.set_stream(back_to.cuda_stream)
 
     def launch_ms(self):
         """Durations (ms) of the launches rendered while time_launches was set, from events on their own streams; call after
