@@ -117,6 +117,9 @@ enum trg_option {
     TRG_OPT_STACK_LDS_LEVELS = 13, /* scenes in HBM: levels of a thread's traversal stack kept in LDS (2..12, default 12; level 0 is the
                                  sentinel); deeper levels live in a per-launch scratch in memory.  Never changes the image: a knob for
                                  testing the scratch path and for trading LDS against it */
+    TRG_OPT_TAIL_SORT = 14,   /* tail compaction: before a tail launch reads them, the queued paths of a tile are sorted by the octant of their direction
+                                 (1), or by octant + the cell of their origin in a 2^3 (2) / 4^3 (3) grid over the scene box, so that the 64 lanes of a
+                                 tail wavefront start alike; 0 (default) = queue order.  Same image bit for bit (a path's arithmetic is its own) */
     TRG_OPT_FRAME_SPLIT = 7   /* TRG_KERNEL_DIRECT only: frame lanes per workgroup. 1: a pixel's frames run one after the other in one
                                  lane; 2 or 4: that many wavefronts share a pixel's frames (same result bit for bit; fills the chip
                                  when the pixel grid alone does not -- small windows, row bands of a multi-GPU job);
@@ -323,6 +326,13 @@ TRG_API int trg_debug_build_bvh4q(const float *positions3, const uint32_t *indic
 TRG_API int trg_debug_leaf_records(const float *positions3, const float *normals3, const float *colors3, const uint32_t *indices,
                                    const uint32_t *material_ids, uint32_t n_verts, uint32_t n_tris, float *records32_out, uint32_t records_cap,
                                    uint32_t *n_records);
+
+/* host-only: the PLANE form of the triangle records (round 4) -- what the shipped build's triangle test reads on an LDS-resident scene, exactly
+ * as trg_load_scene lays it out: per record of trg_debug_build_bvh 12 floats (n.xyz d0 | n1.xyz d1 | n2.xyz d2: t = (d0 - n.o) / (n.dir),
+ * P = o + t dir, u = n1.P + d1 = weight of vertex 1, v = n2.P + d2 = weight of vertex 2) and one u16 = (original index << 2) | (material id & 3).
+ * A degenerate triangle gets planes no ray passes.  Pass NULL outputs to query the count. */
+TRG_API int trg_debug_plane_records(const float *positions3, const uint32_t *indices, const uint32_t *material_ids, uint32_t n_verts, uint32_t n_tris,
+                                    float *planes12_out, uint16_t *meta_out, uint32_t records_cap, uint32_t *n_records);
 
 /* host-only: the tile (bx, by) workgroup slot `slot` of a launch over tiles_x x tiles_y tiles renders under tile order `order` (0, 1, 2, 4, 8:
  * TRG_OPT_TILE_ORDER), exactly as the kernels compute it.  Returns 1, 0 for a padding slot of an XCD-aware order (or a slot beyond the

@@ -154,10 +154,12 @@ def test_intersector(capi, O, cornell, ctx256, force_global):
         ctx256.set_option(capi.OPT_STRICT, 0)
         fast = ctx256.trace(rays)
         diff = fast["primitiveIndex"] != ref["primitiveIndex"]
+        # (the plane-form test of LDS-resident scenes, round 4: 129 of these 60,264 rays pick another primitive than the oracle, the
+        #  Moeller-Trumbore form 106 -- every one of them within 3e-7 of an edge in double precision: scripts/gpu_tri_test_accuracy.py)
         if diff.any():
             _, _, margin = O.nearest_f64(cornell, rays[diff])
-            assert (margin < 1e-4).all()
-        assert diff.mean() < 2e-3
+            assert (margin < 1e-5).all()
+        assert diff.mean() < 3e-3
         same = ~diff & (ref["primitiveIndex"] >= 0)
         np.testing.assert_allclose(fast["distance"][same], ref["distance"][same], rtol=3e-6, atol=3e-6)
         np.testing.assert_allclose(fast["coordinates"][same], ref["coordinates"][same], rtol=0, atol=2e-5)
@@ -1808,6 +1810,16 @@ def test_tail_compaction_is_bit_exact(capi, O, cornell, k, bounces, spp):
         for r0, n in ((0, 50), (50, 63), (113, 37)):
             c.render(a, spp - a, bounces, r0, n)
         assert np.array_equal(_bits(c.read_accum()), _bits(ref))
+        # TRG_OPT_TAIL_SORT (round 4): a tile's queued paths sorted by direction octant (+ origin cell) before every tail launch -- the
+        # order of the paths changes, the arithmetic of a path does not
+        for mode in (1, 2, 3):
+            c.set_option(capi.OPT_TAIL_SORT, mode)
+            c.reset_stats()
+            c.render(0, spp, bounces)
+            assert np.array_equal(_bits(c.read_accum()), _bits(ref)) and c.stats().rays == rst.rays, ("sorted", mode)
+        with pytest.raises(capi.TrgError):
+            c.set_option(capi.OPT_TAIL_SORT, 4)
+        c.set_option(capi.OPT_TAIL_SORT, 0)
         # off = the plain kernel; auto picks it for deep paths only
         c.set_option(capi.OPT_TAIL_BOUNCE, 0)
         c.render(0, spp, bounces)
@@ -1913,7 +1925,7 @@ def test_tile_order_never_changes_the_image(capi, O, cornell, force_global):
         try:
             c.set_option(capi.OPT_FORCE_GLOBAL, force_global)
             c.set_option(capi.OPT_STRICT, 1)
-            for order in (0, 1, 2, 4, 8, -1):
+            for order in (0, 1, 2, 4, 8, 17, 18, 20, 24, -1):
                 c.set_option(capi.OPT_TILE_ORDER, order)
                 for fsplit, regen in ((1, 0), (2, 0), (4, 1), (1, 1)):
                     c.set_option(capi.OPT_FRAME_SPLIT, fsplit)

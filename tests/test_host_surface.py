@@ -702,7 +702,7 @@ def test_every_tile_order_is_a_bijection(built):
     L = capi.load()
     n, bx, by = C.c_uint32(), C.c_uint32(), C.c_uint32()
     for tx, ty in ((120, 68), (1, 1), (7, 3), (13, 1), (2, 9), (240, 135), (5, 5), (64, 2)):
-        for order in (0, 1, 2, 4, 8):
+        for order in (0, 1, 2, 4, 8, 17, 18, 20, 24):
             assert L.trg_debug_tile_of_slot(tx, ty, order, 0, C.byref(n), None, None) >= 0
             slots = n.value
             seen, per_xcd = set(), {}
@@ -717,6 +717,14 @@ def test_every_tile_order_is_a_bijection(built):
             assert L.trg_debug_tile_of_slot(tx, ty, order, slots, None, None, None) == 0
             if order == 0:
                 assert slots == tx * ty
+            elif order >= 16:
+                # stripes of S tile rows dealt round robin: XCD x owns exactly the rows whose group number is x mod 8, all columns of them
+                S = order - 16
+                assert slots <= (ty + 8 * S) * tx
+                for x, tiles in per_xcd.items():
+                    assert all((t[1] // S) % 8 == x for t in tiles)
+                    assert len(tiles) == tx * sum(1 for r in range(ty) if (r // S) % 8 == x)
+                    assert tiles[0][0] == (tx - 1) // 2                 # starts at the centre column
             else:
                 assert slots <= tx * ty + 8 * (tx + ty + 1)          # padding: at most a column + a row of tiles per region
                 for tiles in per_xcd.values():                        # one rectangle per XCD, filled completely
@@ -726,6 +734,64 @@ def test_every_tile_order_is_a_bijection(built):
                     left = [t[0] for t in per_xcd[0]]                 # strip left of the centre: starts at the centre column, ends at the edge
                     assert left[0] == tx // 2 - 1 and left[-1] == 0
     assert L.trg_debug_tile_of_slot(4, 4, 3, 0, None, None, None) < 0
+
+
+def test_plane_records_are_the_triangles(built, O):
+    """The PLANE form of the triangle records (round 4: the shipped build's triangle test on LDS-resident scenes, trg_device.h
+    tri_test_planes) against the Moeller-Trumbore records of the same build, in float64: the first plane is the unit supporting
+    plane, the second and third give the weights of vertex 1 and vertex 2 (0 / 1 / 0 and 0 / 0 / 1 at the corners), the u16 carries
+    the original index and the two mask bits; the test evaluated in float64 on random rays picks the hits of an independent
+    Moeller-Trumbore; a degenerate triangle can never be hit."""
+    from toyraygun_amd import capi
+    box = O.OracleScene.cornell_box()
+    rng = np.random.default_rng(5)
+    soup = O.OracleScene()
+    eye = np.eye(4, dtype=np.float32)
+    for k in range(60):
+        tri = (rng.uniform(-1, 1, 3) + rng.normal(0, 0.2, (3, 3))).astype(np.float32)
+        soup.add_geometry(tri, [0, 1, 2], eye, (0.5, 0.5, 0.5), 1 + k % 2)
+    soup.add_geometry(np.array([[0, 0, 0], [1, 1, 1], [2, 2, 2]], np.float32), [0, 1, 2], eye, (0.5, 0.5, 0.5), 1)   # zero area
+    for scene in (box, soup):
+        b = scene.buffers()
+        _, tris, _ = capi.debug_build_bvh(b["positions"], b["indices"], b["material_ids"])
+        planes, meta = capi.debug_plane_records(b["positions"], b["indices"], b["material_ids"])
+        assert planes.shape == (tris.shape[0], 12) and meta.shape == (tris.shape[0],)
+        prim, mask = tris[:, 3].view(np.uint32), tris[:, 7].view(np.uint32)
+        assert np.array_equal(meta, ((prim << 2) | (mask & 3)).astype(np.uint16))
+        assert sorted(prim.tolist()) == list(range(scene.ntris))
+        v0, e1, e2 = tris[:, 0:3].astype(np.float64), tris[:, 4:7].astype(np.float64), tris[:, 8:11].astype(np.float64)
+        P = planes.astype(np.float64)
+        area = np.linalg.norm(np.cross(e1, e2), axis=1)
+        ok = area > 0
+        assert (~ok).sum() == (1 if scene is soup else 0)
+        assert np.array_equal(planes[~ok], np.tile(np.array([0, 0, 0, 1, 0, 0, 0, -1, 0, 0, 0, -1], np.float32), ((~ok).sum(), 1)))
+        n, d0, n1, d1, n2, d2 = P[ok, 0:3], P[ok, 3], P[ok, 4:7], P[ok, 7], P[ok, 8:11], P[ok, 11]
+        a, b1, b2 = v0[ok], v0[ok] + e1[ok], v0[ok] + e2[ok]
+        scale = 1.0 + np.abs(a).max()
+        assert np.allclose(np.linalg.norm(n, axis=1), 1.0, atol=1e-6)
+        for corner, (wu, wv) in ((a, (0, 0)), (b1, (1, 0)), (b2, (0, 1))):
+            assert np.allclose((n * corner).sum(1), d0, atol=3e-6 * scale)
+            size = np.maximum(np.linalg.norm(n1, axis=1), np.linalg.norm(n2, axis=1)) * scale
+            assert np.all(np.abs((n1 * corner).sum(1) + d1 - wu) <= 4e-7 * size + 1e-6)
+            assert np.all(np.abs((n2 * corner).sum(1) + d2 - wv) <= 4e-7 * size + 1e-6)
+        # the test itself, in float64, against Moeller-Trumbore on the same triangles
+        o = rng.uniform(-1.5, 1.5, (400, 3)); d = rng.normal(size=(400, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+        for k in range(P.shape[0]):
+            den = P[k, 0:3] @ d.T
+            with np.errstate(divide="ignore", invalid="ignore"):
+                t = -((P[k, 0:3] @ o.T) - P[k, 3]) / den
+                X = o + t[:, None] * d
+                u, v = X @ P[k, 4:7] + P[k, 7], X @ P[k, 8:11] + P[k, 11]
+                hit = (u >= 0) & (v >= 0) & (u + v <= 1) & (t >= 0)
+                pv = np.cross(d, e2[k]); det = pv @ e1[k]; tv = o - v0[k]
+                mu = (tv * pv).sum(1) / det; q = np.cross(tv, e1[k]); mv = (d * q).sum(1) / det; mt = (q @ e2[k]) / det
+                mhit = (mu >= 0) & (mv >= 0) & (mu + mv <= 1) & (mt >= 0)
+                edge = np.minimum.reduce([np.abs(mu), np.abs(mv), np.abs(1 - mu - mv), np.abs(mt)]) < 1e-4   # fp32 planes: undecided this close to an edge
+            assert np.array_equal(hit[~edge], mhit[~edge]), k
+            both = hit & mhit & ~edge
+            assert np.allclose(t[both], mt[both], rtol=1e-4, atol=1e-5) and np.allclose(u[both], mu[both], atol=1e-4) and np.allclose(v[both], mv[both], atol=1e-4)
+            if not ok[k]:
+                assert not hit.any()
 
 
 def test_leaf_records_carry_each_triangles_geometry_and_attributes(built, O):

@@ -16,7 +16,7 @@ HIP_SO = os.environ.get("TRG_HIP_SO") or os.path.join(LIB_DIR, "libtoyraygun_hip
 OK = 0
 ERR_INVALID, ERR_NOMEM, ERR_DEVICE, ERR_NODEV, ERR_RANGE = -22, -12, -5, -19, -34
 OPT_STRICT, OPT_COUNTERS, OPT_FORCE_GLOBAL, OPT_TIMING, OPT_KERNEL, OPT_GPU_BUILD, OPT_FRAME_SPLIT, OPT_LAUNCHES_IN_FLIGHT = 1, 2, 3, 4, 5, 6, 7, 8
-OPT_TAIL_BOUNCE, OPT_TAIL_LEVELS, OPT_REGEN, OPT_TILE_ORDER, OPT_STACK_LDS_LEVELS = 9, 10, 11, 12, 13
+OPT_TAIL_BOUNCE, OPT_TAIL_LEVELS, OPT_REGEN, OPT_TILE_ORDER, OPT_STACK_LDS_LEVELS, OPT_TAIL_SORT = 9, 10, 11, 12, 13, 14
 KERNEL_DIRECT, KERNEL_POOL, KERNEL_WAVEFRONT, KERNEL_AUTO = 0, 1, 2, -1
 MATERIAL_DEFAULT, MATERIAL_EMISSIVE = 1, 2
 MAX_BOUNCES = 15
@@ -106,6 +106,7 @@ _SYMBOLS = [
     ("trg_group_time_launches", C.c_int, [_P, C.c_int]),
     ("trg_group_launch_ms", C.c_int, [_P, C.c_int, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
     ("trg_group_exchange_note", C.c_char_p, [_P]),
+    ("trg_debug_plane_records", C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
     ("trg_group_set_bands", C.c_int, [_P, C.c_int]),
     ("trg_group_bands", C.c_int, [_P]),
     ("trg_group_postprocess", C.c_int, [_P, C.c_int, _P, C.c_int]),
@@ -480,6 +481,23 @@ class Group:
 
     def rank_rays(self):
         return [int(self.rank_stats(r).rays) for r in range(self.n)]
+
+
+def debug_plane_records(positions, indices, material_ids):
+    """Host-only (no GPU): the plane form of the triangle records -- (planes[n,12] float32, meta[n] uint16) in the record order of debug_build_bvh."""
+    L = load()
+    pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+    idx = np.ascontiguousarray(indices, np.uint32).reshape(-1)
+    mat = np.ascontiguousarray(material_ids, np.uint32).reshape(-1)
+    n = C.c_uint32()
+    rc = L.trg_debug_plane_records(_ptr(pos), _ptr(idx), _ptr(mat), pos.shape[0], mat.shape[0], None, None, 0, C.byref(n))
+    if rc != OK:
+        raise TrgError(rc, "trg_debug_plane_records")
+    planes, meta = np.zeros((n.value, 12), np.float32), np.zeros(n.value, np.uint16)
+    rc = L.trg_debug_plane_records(_ptr(pos), _ptr(idx), _ptr(mat), pos.shape[0], mat.shape[0], _ptr(planes), _ptr(meta), n.value, C.byref(n))
+    if rc != OK:
+        raise TrgError(rc, "trg_debug_plane_records")
+    return planes, meta
 
 
 def debug_build_bvh(positions, indices, material_ids):

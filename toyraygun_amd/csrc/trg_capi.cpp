@@ -61,6 +61,8 @@ struct trg_ctx {
     int opt_tail_levels = 0;   // TRG_OPT_TAIL_LEVELS: 0 = re-compact every second bounce after K, 1 = once at K only
     int opt_in_flight = 1;  // launches of this context the caller keeps in flight (TRG_OPT_LAUNCHES_IN_FLIGHT)
     int opt_stack_levels = (int)TRG_STACK_LDS_LEVELS;   // TRG_OPT_STACK_LDS_LEVELS
+    int opt_tail_sort = 0;     // TRG_OPT_TAIL_SORT: 0 off, 1 direction octant, 2 / 3 octant + origin cell of a 2^3 / 4^3 grid
+    float scene_lo[3] = { 0.f, 0.f, 0.f }, scene_hi[3] = { 1.f, 1.f, 1.f };   // bounds of the loaded scene (tail sort: the origin grid)
     int opt_tile_order = -1;   // TRG_OPT_TILE_ORDER: -1 auto, 0 image columns centre-out, 1 / 2 / 4 / 8 XCD regions with that many column strips
     uint32_t last_xcd_cols = 0;
     double last_build_ms = 0.0;
@@ -106,12 +108,15 @@ static bool plan_scene_layout(uint64_t n_nodes, uint32_t node_bytes, uint64_t nt
     const uint64_t off_normals = align16_64(off_tris + nt_rec * 48ull);
     const uint64_t off_colors = align16_64(off_normals + attr_tris * 36ull);
     const uint64_t off_mats = align16_64(off_colors + attr_tris * 36ull);
-    const uint64_t off_htab = align16_64(off_mats + attr_tris * 4ull);
+    const uint64_t off_meta = align16_64(off_mats + attr_tris * 4ull);                  // u16 per record (before the Halton tables: the pool kernel stages up to them)
+    const uint64_t off_htab = align16_64(off_meta + nt_rec * 2ull);
     const uint64_t stage_end = align16_64(off_htab + (with_htab ? kHtabBytes : 0u));
     const uint64_t off_nodes4 = (stage_end + 127ull) & ~127ull;  // 64-byte nodes, two per 128-byte line
     const uint64_t off_fat = (off_nodes4 + n_nodes4 * kQ4NodeBytes + 127ull) & ~127ull;   // one record per 128-byte line
-    total = off_fat + n_fat * kFatRecBytes + 128ull;
+    const uint64_t off_tris_alt = off_fat + n_fat * kFatRecBytes;                          // the plane records of an LDS-sized scene (16-byte aligned)
+    total = off_tris_alt + nt_rec * 48ull + 128ull;
     if (total > kBlobLimit) return false;
+    sc.off_meta = (uint32_t)off_meta; sc.off_tris_alt = (uint32_t)off_tris_alt;
     sc.off_nodes = (uint32_t)off_nodes; sc.off_tris = (uint32_t)off_tris; sc.off_normals = (uint32_t)off_normals;
     sc.off_colors = (uint32_t)off_colors; sc.off_mats = (uint32_t)off_mats; sc.off_htab = (uint32_t)off_htab;
     sc.off_nodes4 = (uint32_t)off_nodes4;
@@ -135,6 +140,39 @@ static void fill_fat_record(unsigned char *dst, const F4 *rec48, const float *nr
         memset(o + 12, 0, 72);
     }
     o[30] = 0.0f; o[31] = 0.0f;
+}
+
+// The PLANE form of one triangle (trg_device.h tri_test_planes; shipped build, LDS-resident scenes): from the same fp32 (v0, e1, e2) the
+// Moeller-Trumbore record holds, in double:  n = e1 x e2 / |e1 x e2|, d0 = n . v0  (the supporting plane: t = (d0 - n.o) / (n.dir));
+// n1 = (e2 x n) / (e1 . (e2 x n)), d1 = -n1 . v0  (u = n1 . P + d1 = weight of vertex 1);  n2 = (n x e1) / (e2 . (n x e1)), d2 = -n2 . v0
+// (v = weight of vertex 2).  A degenerate triangle gets planes no ray passes (u = -1).  meta = (original index << 2) | (material id & 3):
+// rays carry mask 3 (primary) or 1 (secondary), so the two low bits of the material id are all the mask test ever sees.
+static void fill_plane_record(unsigned char *dst, uint16_t *meta, const F4 *rec48) {
+    const double v0[3] = { rec48[0].x, rec48[0].y, rec48[0].z }, e1[3] = { rec48[1].x, rec48[1].y, rec48[1].z }, e2[3] = { rec48[2].x, rec48[2].y, rec48[2].z };
+    auto cross = [](const double *a, const double *b, double *o) { o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; };
+    auto dot = [](const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+    double n[3], a1[3], a2[3];
+    cross(e1, e2, n);
+    const double len = std::sqrt(dot(n, n));
+    float o[12] = { 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, -1.f, 0.f, 0.f, 0.f, -1.f };   // never hit
+    if (len > 0.0 && std::isfinite(len)) {
+        for (int k = 0; k < 3; ++k) n[k] /= len;
+        cross(e2, n, a1); cross(n, e1, a2);
+        const double s1 = dot(e1, a1), s2 = dot(e2, a2);
+        if (s1 != 0.0 && s2 != 0.0) {
+            for (int k = 0; k < 3; ++k) { a1[k] /= s1; a2[k] /= s2; }
+            const double d0 = dot(n, v0), d1 = -dot(a1, v0), d2 = -dot(a2, v0);
+            const float r[12] = { (float)n[0], (float)n[1], (float)n[2], (float)d0, (float)a1[0], (float)a1[1], (float)a1[2], (float)d1,
+                                  (float)a2[0], (float)a2[1], (float)a2[2], (float)d2 };
+            bool ok = true;
+            for (float f : r) ok = ok && std::isfinite(f);
+            if (ok) memcpy(o, r, sizeof(o));
+        }
+    }
+    memcpy(dst, o, 48);
+    uint32_t prim, mask;
+    memcpy(&prim, &rec48[0].w, 4); memcpy(&mask, &rec48[1].w, 4);
+    *meta = (uint16_t)((prim << 2) | (mask & 3u));
 }
 
 constexpr uint32_t kStackLdsLevels = TRG_STACK_LDS_LEVELS;
@@ -244,6 +282,10 @@ static uint32_t choose_fsplit(const trg_ctx *c, uint32_t spp, uint32_t rows) {
 // XCD-aware order 8 x the largest of the xcd_cols x (8 / xcd_cols) regions (regions differ by a row or a column of tiles at most).
 static uint64_t tile_slots(uint32_t tiles_x, uint32_t tiles_y, uint32_t xcd_cols) {
     if (xcd_cols == 0u) return (uint64_t)tiles_x * tiles_y;
+    if (xcd_cols >= kXcdStripes) {
+        const uint32_t S = xcd_cols - kXcdStripes;
+        return (uint64_t)((tiles_y + kXcds * S - 1u) / (kXcds * S)) * S * kXcds * tiles_x;
+    }
     const uint32_t rc = xcd_cols, rq = kXcds / rc;
     uint64_t largest = 0;
     for (uint32_t ci = 0; ci < rc; ++ci)
@@ -330,6 +372,7 @@ static int load_scene_gpu_build(trg_ctx *c, const float *pos, const float *nrm, 
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->last_build_ms = ms;
     c->gpu_built = true;
+    for (int a = 0; a < 3; ++a) { c->scene_lo[a] = lo[a]; c->scene_hi[a] = hi[a]; }
 
     SceneDesc sc{};
     sc.n_nodes = 0; sc.n_tris = n_tris;
@@ -420,6 +463,7 @@ struct HostScene {
     SceneDesc sc{};                    // offsets; sc.blob is filled in per context
     uint32_t bvh_nodes = 0, bvh_depth = 0, bvh_leaves = 0, bvh_nodes4 = 0, bvh_depth4 = 0;
     double build_ms = 0.0;
+    float lo[3] = { 0.f, 0.f, 0.f }, hi[3] = { 1.f, 1.f, 1.f };   // bounds of the triangles
 };
 int ctx_gpu_build_option(const trg_ctx *c) { return c ? c->opt_gpu_build : 0; }
 void *ctx_current_stream(trg_ctx *c) { return c ? (void *)c->stream : nullptr; }
@@ -518,6 +562,13 @@ int host_scene_build(trg_ctx *c, const float *pos, const float *nrm, const float
     Bvh bvh;
     build_bvh(pos, idx, mat, n_tris, bvh);
     hs->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
+    if (n_tris) {
+        for (int a = 0; a < 3; ++a) { hs->lo[a] = INFINITY; hs->hi[a] = -INFINITY; }
+        for (size_t i = 0; i < (size_t)n_tris * 3; ++i) {
+            const float *v = pos + (size_t)idx[i] * 3;
+            for (int a = 0; a < 3; ++a) { hs->lo[a] = std::min(hs->lo[a], v[a]); hs->hi[a] = std::max(hs->hi[a], v[a]); }
+        }
+    }
 
     // Positions go through the index buffer (MPS vertexBuffer + indexBuffer, MetalRenderer.mm:274-275);
     // normals and colours are read as attributes[triangle*3 + j], NOT through the index buffer
@@ -530,10 +581,11 @@ int host_scene_build(trg_ctx *c, const float *pos, const float *nrm, const float
     // TRG_TRAV_LDS == 6: 2 entries of 64 bytes per BVH2 node, then 8 order tables of (entries + 1) words, counted in 64-byte units
     const uint32_t thr_entries = 2u * bvh.n_nodes, thr_units = thr_entries + (8u * (thr_entries + 1u) * 4u + 63u) / 64u;
     const uint32_t lds_nodes = kThreadedLds ? thr_units : (kWideLds ? bvh.n_nodes4 : bvh.n_nodes);
-    const uint64_t small_bytes = (uint64_t)lds_nodes * kLdsNodeBytes + (uint64_t)nt_rec * 48u + (uint64_t)attr_tris * 76u + 64u + kHtabBytes;
-    const bool lds_candidate = small_bytes <= kMaxLdsScene && (!kThreadedLds || thr_units * 64u < 65536u);
+    const uint64_t small_bytes = (uint64_t)lds_nodes * kLdsNodeBytes + (uint64_t)nt_rec * 50u + (uint64_t)attr_tris * 76u + 80u + kHtabBytes;
+    const bool lds_candidate = small_bytes <= kMaxLdsScene && (!kThreadedLds || thr_units * 64u < 65536u) && n_tris < (1u << 14);   // (u16 per record: index << 2 | mask)
     SceneDesc sc{};
     sc.n_nodes = lds_candidate ? lds_nodes : 0u; sc.n_tris = n_tris;
+    sc.n_tris_rec = lds_candidate ? nt_rec : 0u;
     sc.thr_entries = (kThreadedLds && lds_candidate) ? thr_entries : 0u;
     const uint32_t node_bytes = kLdsNodeBytes;
     sc.n_nodes4 = bvh.n_nodes4;
@@ -622,10 +674,8 @@ int host_scene_build(trg_ctx *c, const float *pos, const float *nrm, const float
             memcpy(ch, &n[3].x, 8);
             for (int k = 0; k < 2; ++k) {
                 if (ch[k] >= 0) ch[k] *= (int32_t)kLdsNodeBytes;   // inner child: byte offset of its node
-                else {   // leaf child: the record index counted in 16-byte units (x 3), so that the leaf step needs no multiply
-                    const uint32_t code = ~(uint32_t)ch[k];
-                    ch[k] = (int32_t)~((((code >> 3) * 3u) << 3) | (code & 7u));
-                }
+                // (a leaf child keeps its code ~((record << 3) | (count - 1)): the leaf step turns the record into an address with ONE
+                //  v_mad_u32_u24, and the same number indexes the u16 per record of the plane test)
             }
             // one 32-byte block [X copy | Y copy] per sign pair (sx + 2 sy) at 0 / 32 / 64 / 96 -- ONE address for both axes --, then
             // Z+ at 128 and Z- at 160, each followed by the child pair (+ 8 bytes of padding); 192 bytes + 16 of padding
@@ -649,6 +699,7 @@ int host_scene_build(trg_ctx *c, const float *pos, const float *nrm, const float
     }
     if (lds_candidate) {
         memcpy(&host[sc.off_tris], bvh.tris.data(), bvh.tris.size() * sizeof(F4));
+        for (uint32_t i = 0; i < nt_rec; ++i) fill_plane_record(&host[sc.off_tris_alt + (size_t)i * 48u], reinterpret_cast<uint16_t *>(&host[sc.off_meta]) + i, &bvh.tris[(size_t)i * 3]);
         if (n_tris) {
             memcpy(&host[sc.off_normals], nrm, (size_t)n_tris * 36);
             memcpy(&host[sc.off_colors], col, (size_t)n_tris * 36);
@@ -688,6 +739,7 @@ int host_scene_upload(trg_ctx *c, const HostScene *hs) {
     sc.blob = c->blob;
     c->sc = sc;
     c->last_build_ms = hs->build_ms;
+    for (int a = 0; a < 3; ++a) { c->scene_lo[a] = hs->lo[a]; c->scene_hi[a] = hs->hi[a]; }
     c->gpu_built = false;
     c->bvh_nodes = hs->bvh_nodes; c->bvh_depth = hs->bvh_depth; c->bvh_leaves = hs->bvh_leaves;
     c->bvh_nodes4 = hs->bvh_nodes4; c->bvh_depth4 = hs->bvh_depth4;
@@ -917,7 +969,8 @@ static int render_impl(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t 
         // compaction levels: K, K + 2, K + 4 ... while at least two bounces are left (each level halves the live lanes again)
         uint32_t levels[8]; int n_levels = 0;
         for (uint32_t k = tail_k; k < bounces && n_levels < 8; k += kTailLevelStep) { levels[n_levels++] = k; if (c->opt_tail_levels == 1) break; }
-        const bool two_queues = n_levels > 1;
+        const bool sorted = c->opt_tail_sort > 0 && cap * kWaves <= 4096u;   // the sort kernel holds a tile's keys in LDS
+        const bool two_queues = n_levels > 1 || sorted;
         const size_t need = q_bytes * (two_queues ? 2u : 1u) + cnt_bytes * 2u + rad_bytes;
         if (need > c->wf_bytes[slot]) {
             if (c->wf_mem[slot]) { (void)hipDeviceSynchronize(); (void)hipFree(c->wf_mem[slot]); c->wf_mem[slot] = nullptr; c->wf_bytes[slot] = 0; }
@@ -936,9 +989,21 @@ static int render_impl(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t 
             p.frame_begin = frame_begin + f0; p.spp = std::min(fc, spp - f0);
             p.tail_k = levels[0]; p.tail_k_end = levels[0]; p.tail_queue = q[0]; p.tail_count = qc[0];
             hipError_t te = c->opt_strict ? launch_render_head_strict(p, c->opt_counters, grid, plan.total, c->stream) : launch_render_head_fast(p, c->opt_counters, grid, plan.total, c->stream);
+            float inv3[3];
+            for (int a = 0; a < 3; ++a) inv3[a] = 1.0f / std::max(c->scene_hi[a] - c->scene_lo[a], 1e-20f);
             for (int l = 0; l < n_levels && te == hipSuccess; ++l) {
                 p.tail_k = levels[l]; p.tail_k_end = l + 1 < n_levels ? levels[l + 1] : bounces;
-                p.tail_queue = q[l & 1]; p.tail_count = qc[l & 1]; p.tail_queue_out = q[(l + 1) & 1]; p.tail_count_out = qc[(l + 1) & 1];
+                if (sorted) {
+                    // TRG_OPT_TAIL_SORT: the paths of a tile by direction octant (and origin cell) before a tail launch reads them -- q0 (written by
+                    // the head / the previous tail) -> q1 (read by this tail, which compacts into q0 again); the counts stay in qc[l & 1]
+                    p.tail_queue = q[0]; p.tail_count = qc[l & 1]; p.tail_queue_out = q[1];
+                    te = c->opt_strict ? launch_tail_sort_strict(p, grid, (uint32_t)c->opt_tail_sort, c->scene_lo, inv3, c->stream)
+                                       : launch_tail_sort_fast(p, grid, (uint32_t)c->opt_tail_sort, c->scene_lo, inv3, c->stream);
+                    if (te != hipSuccess) break;
+                    p.tail_queue = q[1]; p.tail_queue_out = q[0]; p.tail_count_out = qc[(l + 1) & 1];
+                } else {
+                    p.tail_queue = q[l & 1]; p.tail_count = qc[l & 1]; p.tail_queue_out = q[(l + 1) & 1]; p.tail_count_out = qc[(l + 1) & 1];
+                }
                 te = c->opt_strict ? launch_render_tail_strict(p, c->opt_counters, grid, plan.total, c->stream) : launch_render_tail_fast(p, c->opt_counters, grid, plan.total, c->stream);
             }
             if (te == hipSuccess) te = c->opt_strict ? launch_tail_accumulate_strict(p, c->stream) : launch_tail_accumulate_fast(p, c->stream);
@@ -1098,9 +1163,13 @@ int trg_set_option(trg_ctx *c, int option, int64_t value) {
         if (value < 2 || value > (int64_t)kStackLdsLevels) return fail(c, TRG_ERR_INVALID, "trg_set_option: 2..%u stack levels in LDS", kStackLdsLevels);
         c->opt_stack_levels = (int)value;
         break;
+    case TRG_OPT_TAIL_SORT:
+        if (value < 0 || value > 3) return fail(c, TRG_ERR_INVALID, "trg_set_option: tail sort must be 0 (off), 1 (octant), 2 or 3 (octant + origin cell)");
+        c->opt_tail_sort = (int)value;
+        break;
     case TRG_OPT_TILE_ORDER:
-        if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
-            return fail(c, TRG_ERR_INVALID, "trg_set_option: tile order must be -1 (auto), 0 (columns) or 1, 2, 4, 8 (XCD regions: column strips)");
+        if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 17 && value != 18 && value != 20 && value != 24)
+            return fail(c, TRG_ERR_INVALID, "trg_set_option: tile order must be -1 (auto), 0 (columns), 1, 2, 4, 8 (XCD regions: column strips) or 17, 18, 20, 24 (XCD stripes of 1, 2, 4, 8 tile rows)");
         c->opt_tile_order = (int)value;
         break;
     case TRG_OPT_LAUNCHES_IN_FLIGHT:
@@ -1243,8 +1312,25 @@ int trg_debug_leaf_records(const float *positions3, const float *normals3, const
     return TRG_OK;
 }
 
+int trg_debug_plane_records(const float *positions3, const uint32_t *indices, const uint32_t *material_ids, uint32_t n_verts, uint32_t n_tris,
+                            float *planes12_out, uint16_t *meta_out, uint32_t records_cap, uint32_t *n_records) {
+    if (!positions3 || !indices || !material_ids || n_tris == 0) return TRG_ERR_INVALID;
+    for (size_t i = 0; i < (size_t)n_tris * 3; ++i)
+        if (indices[i] >= n_verts) return TRG_ERR_INVALID;
+    Bvh bvh;
+    build_bvh(positions3, indices, material_ids, n_tris, bvh);
+    const uint32_t nrec = (uint32_t)(bvh.tris.size() / 3);
+    if (n_records) *n_records = nrec;
+    if (planes12_out || meta_out) {
+        if (records_cap < nrec || !planes12_out || !meta_out) return TRG_ERR_RANGE;
+        for (uint32_t i = 0; i < nrec; ++i)
+            fill_plane_record(reinterpret_cast<unsigned char *>(planes12_out) + (size_t)i * 48u, meta_out + i, &bvh.tris[(size_t)i * 3]);
+    }
+    return TRG_OK;
+}
+
 int trg_debug_tile_of_slot(uint32_t tiles_x, uint32_t tiles_y, uint32_t order, uint32_t slot, uint32_t *n_slots, uint32_t *bx, uint32_t *by) {
-    if (tiles_x == 0 || tiles_y == 0 || (order != 0 && order != 1 && order != 2 && order != 4 && order != 8)) return TRG_ERR_INVALID;
+    if (tiles_x == 0 || tiles_y == 0 || (order != 0 && order != 1 && order != 2 && order != 4 && order != 8 && order != 17 && order != 18 && order != 20 && order != 24)) return TRG_ERR_INVALID;
     const uint64_t slots = tile_slots(tiles_x, tiles_y, order);
     if (slots > 0x7FFFFFFFull) return TRG_ERR_RANGE;
     if (n_slots) *n_slots = (uint32_t)slots;

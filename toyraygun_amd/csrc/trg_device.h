@@ -515,6 +515,7 @@ struct SceneView {
     const uint32_t *mats;   // LDS scene: 1 per triangle, ORIGINAL order (reference triangleMasks buffer); HBM scene: nullptr
     const float *htab;      // Halton group tables in LDS (trg_kernels.h kHtab), or nullptr
     trg::TexDesc tex;       // albedo textures in global memory (tex.uv == nullptr: none)
+    const unsigned short *meta;   // LDS scene: per record (original index << 2) | (material id & 3) (the plane test of the shipped build)
     uint32_t thr_entries;   // TRG_TRAV_LDS == 6: entries of the octant-threaded tree behind `nodes`
     uint32_t rec_delta;     // HBM scene: byte distance from `nodes` to `tris` (the records follow the nodes in the blob)
 };
@@ -534,6 +535,22 @@ TRG_DEV bool tri_test(const v4f a, const v4f b, const v4f c, V3 o, V3 d, float t
     t = dot(e2, q) * inv;
     return (u >= 0.0f) && (v >= 0.0f) && ((u + v) <= 1.0f) && (t >= 0.0f) && (t <= tmax_ray);
 }
+
+// The same test on a triangle given as THREE PLANES (shipped build, LDS-resident scenes; trg_capi.cpp fill_plane_record): a = (n, d0) the
+// unit supporting plane, b = (n1, d1) and c = (n2, d2) the planes whose signed distances are the weights of vertex 1 and 2.
+// t = (d0 - n.o) / (n.d), P = o + t d, u = n1.P + d1, v = n2.P + d2: 17 arithmetic instructions against Moeller-Trumbore's 31, the same
+// (t, u, v) up to rounding.  A ray parallel to the plane gets t = +-inf or NaN and then u, v = NaN: no hit, like MT's det = 0.
+TRG_DEV bool tri_test_planes(const v4f a, const v4f b, const v4f c, V3 o, V3 d, float tmax_ray, float &t, float &u, float &v) {
+    const float den = a.x * d.x + a.y * d.y + a.z * d.z;
+    const float q = a.x * o.x + (a.y * o.y + (a.z * o.z - a.w));
+    t = -q * rcp_fast(den);
+    const V3 P = mk(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);
+    u = b.x * P.x + (b.y * P.y + (b.z * P.z + b.w));
+    v = c.x * P.x + (c.y * P.y + (c.z * P.z + c.w));
+    return (u >= 0.0f) && (v >= 0.0f) && ((u + v) <= 1.0f) && (t >= 0.0f) && (t <= tmax_ray);
+}
+// the build's triangle test on an LDS-resident scene: planes + the u16 per record (shipped), or the Moeller-Trumbore rows (strict)
+constexpr bool kTriPlanes = !TRG_STRICT && TRG_TRI_PLANES;
 
 // Per-lane traversal stack, laid out [level][thread] so lane i always hits LDS bank i%32 (no conflicts).
 // Scenes staged in LDS have shallow trees and keep the whole stack in LDS (klds = all levels).  Scenes in
@@ -667,7 +684,7 @@ TRG_DEV void trav_node_math(const v4f n0, const v4f n1, const v4f n2, const v4f 
 // (< 0; the record index in them is pre-multiplied by 3 = counted in 16-byte units); 208 = 52 banks, so random nodes
 // spread over 16 bank groups.
 constexpr int kSignedNodeBytes = 208;
-constexpr int kLeafMul = (TRG_TRAV_LDS == 4) ? 1 : 3;   // float4 rows per unit of a leaf code's record index in an LDS-resident scene
+// the 48-byte records of an LDS-resident scene from record `first` on: base + first * 48 as ONE v_mad_u32_u24 (a leaf code holds the record index)
 typedef __attribute__((address_space(3))) v4f lds_v4f_t;
 TRG_DEV float min_raw(float a, float b) {
     float r;
@@ -748,6 +765,29 @@ TRG_DEV bool trav_tri_math(const v4f a, const v4f b, const v4f c, Trav &tv, bool
     return any && ok;
 }
 
+// the plane form of the same fold (LDS-resident scenes, shipped build): `meta` = (original index << 2) | (material id & 3)
+template <bool COUNT>
+TRG_DEV bool trav_tri_planes(const v4f a, const v4f b, const v4f c, uint32_t meta, Trav &tv, bool any, Counters &cnt) {
+    const bool masked_in = (meta & tv.rmask) != 0u;
+    if (COUNT) { if (masked_in) cnt.tris++; if (mbcnt64(__ballot(1)) == 0) cnt.wtris++; }
+    float t, u, v;
+    const bool ok = tri_test_planes(a, b, c, tv.o, tv.d, tv.best, t, u, v) && masked_in;
+    const int prim = (int)(meta >> 2);
+    const bool take = ok && (any || !tv.found || t < tv.best || (t == tv.best && prim < tv.hit.prim));
+    tv.found = tv.found || ok;
+    tv.best = take ? t : tv.best;
+    tv.hit.prim = take ? prim : tv.hit.prim;
+    tv.hit.u = take ? u : tv.hit.u;
+    tv.hit.v = take ? v : tv.hit.v;
+    return any && ok;
+}
+// triangle `k` of the records starting at `tr` (LDS-resident scene): whichever test the build uses
+template <bool COUNT>
+TRG_DEV bool trav_tri_lds(const SceneView &sc, const v4f *tr, uint32_t rec, Trav &tv, bool any, Counters &cnt) {
+    if (kTriPlanes) return trav_tri_planes<COUNT>(tr[0], tr[1], tr[2], sc.meta[rec], tv, any, cnt);
+    return trav_tri_math<COUNT>(tr[0], tr[1], tr[2], tv, any, cnt);
+}
+
 // the hit record of a finished traversal
 TRG_DEV Hit trav_hit(const Trav &tv) {
     Hit h = tv.hit;
@@ -758,17 +798,17 @@ TRG_DEV Hit trav_hit(const Trav &tv) {
 // One leaf: test its 1..8 triangles.  ~node = (first << 3) | (count - 1).  Pops the next node (the sentinel kNodeDone when
 // nothing is pending) and returns true when an any-hit query is satisfied -- the caller then stops whatever was popped.
 // the triangles of one leaf, without touching the stack (the octant-threaded walk, TRG_TRAV_LDS == 6)
+TRG_DEV const v4f *lds_records(const SceneView &sc, uint32_t first) {
+    return reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(sc.tris) + __umul24(first, 48u));
+}
 template <bool COUNT>
 TRG_DEV bool trav_leaf_test(const SceneView &sc, Trav &tv, int leaf, bool any, Counters &cnt) {
     const uint32_t code = (uint32_t)~leaf;
     const uint32_t first = code >> 3, count = (code & 7u) + 1u;
-    const v4f *tr = sc.tris + first * kLeafMul;
-    bool stop = trav_tri_math<COUNT>(tr[0], tr[1], tr[2], tv, any, cnt);
-    if (!stop && count > 1u) stop = trav_tri_math<COUNT>(tr[3], tr[4], tr[5], tv, any, cnt);
-    for (uint32_t k = 2; k < count && !stop; ++k) {
-        const v4f *t2 = tr + k * 3;
-        stop = trav_tri_math<COUNT>(t2[0], t2[1], t2[2], tv, any, cnt);
-    }
+    const v4f *tr = lds_records(sc, first);
+    bool stop = trav_tri_lds<COUNT>(sc, tr, first, tv, any, cnt);
+    if (!stop && count > 1u) stop = trav_tri_lds<COUNT>(sc, tr + 3, first + 1u, tv, any, cnt);
+    for (uint32_t k = 2; k < count && !stop; ++k) stop = trav_tri_lds<COUNT>(sc, tr + k * 3, first + k, tv, any, cnt);
     return stop;
 }
 
@@ -778,13 +818,10 @@ TRG_DEV bool trav_leaf_step(const SceneView &sc, Trav &tv, bool any, STK stk, Co
     const uint32_t first = code >> 3, count = (code & 7u) + 1u;
     bool stop = false;
     {   // leaves of the host builder hold one or two triangles: those without a loop (-2 %); more only from other builders
-        const v4f *tr = sc.tris + first * kLeafMul;
-        stop = trav_tri_math<COUNT>(tr[0], tr[1], tr[2], tv, any, cnt);
-        if (!stop && count > 1u) stop = trav_tri_math<COUNT>(tr[3], tr[4], tr[5], tv, any, cnt);
-        for (uint32_t k = 2; k < count && !stop; ++k) {
-            const v4f *t2 = tr + k * 3;
-            stop = trav_tri_math<COUNT>(t2[0], t2[1], t2[2], tv, any, cnt);
-        }
+        const v4f *tr = lds_records(sc, first);
+        stop = trav_tri_lds<COUNT>(sc, tr, first, tv, any, cnt);
+        if (!stop && count > 1u) stop = trav_tri_lds<COUNT>(sc, tr + 3, first + 1u, tv, any, cnt);
+        for (uint32_t k = 2; k < count && !stop; ++k) stop = trav_tri_lds<COUNT>(sc, tr + k * 3, first + k, tv, any, cnt);
     }
     const int sp = tv.sp - STK::unit;
     tv.node = stk.pop(sp);

@@ -52,6 +52,10 @@ struct SceneDesc {
     uint32_t off_htab;              // Halton group tables (kHtabFloats floats), inside the staged region
     uint32_t off_fat, n_fat;        // leaf records of the HBM traversal: geometry + attributes, 128 bytes each, 128-byte aligned, leaf order
     uint32_t thr_entries;           // TRG_TRAV_LDS == 6 (experiment): entries of the octant-threaded tree in the LDS node section
+    // LDS-resident scenes, shipped build (TRG_TRI_PLANES, round 4): the triangle test on three precomputed PLANES per triangle -- 48 bytes in
+    // leaf order like the Moeller-Trumbore records (off_tris), kept outside the staged part and copied over them at staging time --
+    // and, inside the staged part, one u16 per record: (original index << 2) | (material id & 3), the test's mask and the hit's primitive
+    uint32_t off_tris_alt, off_meta, n_tris_rec;   // n_tris_rec = 48-byte records of the staged part (leaf order)
 };
 constexpr uint32_t kFatRecBytes = 128u;
 
@@ -102,6 +106,7 @@ struct RenderParams {
     uint32_t il_n, il_r;
 };
 constexpr uint32_t kMicroBandRows = 8;   // = the rows of a wavefront's 8x8 sub-tile: a wavefront never straddles two micro-bands
+constexpr uint32_t kXcdStripes = 16;   // tile orders 17, 18, 20, 24: stripes of 1, 2, 4, 8 tile rows dealt round robin over the XCDs
 constexpr uint32_t kXcds = 8;   // XCDs of an MI355X: workgroups are dealt round-robin over them (MI355X_MICROARCH.md, workgroup dispatch)
 
 // Workgroup slot -> tile of a launch over tiles_x x tiles_y tiles (any bijection onto the tiles is correct; this is about time only).
@@ -130,6 +135,20 @@ TRG_HD inline bool tile_of_slot(uint32_t tiles_x, uint32_t tiles_y, uint32_t xcd
         return crank < tiles_x;
     }
     const uint32_t x = slot % kXcds, j = slot / kXcds;
+    if (xcd_cols >= kXcdStripes) {
+        // STRIPES (round 4): XCD x owns the tile rows whose group of S rows has number x mod 8 -- S = xcd_cols - 16 in {1, 2, 4, 8} -- i.e.
+        // horizontal stripes of S tile rows dealt round robin over the XCDs: every XCD gets an eighth of every part of the picture (the
+        // regions above differ in cost and the dispatcher deals the XCDs their workgroups strictly in turn), and the workgroups an L2 serves
+        // at one time still sit side by side in a few stripes.  Columns from the centre outwards, the XCD's rows inner.
+        const uint32_t S = xcd_cols - kXcdStripes;
+        const uint32_t hmax = ((tiles_y + kXcds * S - 1u) / (kXcds * S)) * S;   // rows of the XCD with the most
+        const uint32_t c = j / hmax, k = j - c * hmax;
+        const uint32_t row = ((k / S) * kXcds + x) * S + k % S;
+        if (row >= tiles_y || c >= tiles_x) return false;
+        bx = (c & 1u) ? cleft + 1u + c / 2u : cleft - c / 2u;
+        by = row;
+        return true;
+    }
     const uint32_t rc = xcd_cols, rq = kXcds / rc;
     const uint32_t ci = x % rc, qi = x / rc;
     const uint32_t c0 = ci * tiles_x / rc, c1 = (ci + 1u) * tiles_x / rc;
@@ -179,6 +198,11 @@ struct TraceParams {
 // samples of bounce 0), staged in LDS with the scene: T_b[r] = radical inverse of r read as a K-digit base-b number.
 // The shipped megakernel on an LDS-resident scene takes K digits per lookup instead of one digit per five VALU
 // instructions (trg_device.h halton_c); everything else (strict build, HBM scenes, other dimensions) keeps the digits.
+// The shipped build's triangle test on an LDS-resident scene: 1 = three planes per triangle (17 arithmetic instructions), 0 = Moeller-Trumbore
+// on (v0, e1, e2) like the strict build (31).  trg_device.h tri_test_planes.
+#ifndef TRG_TRI_PLANES
+#define TRG_TRI_PLANES 1
+#endif
 #ifndef TRG_HALTON_TABLES
 #define TRG_HALTON_TABLES 1
 #endif
@@ -218,6 +242,7 @@ static_assert(!(kSignedLds || kWideLds || kThreadedLds) || kWideHbm, "the LDS no
     hipError_t launch_render_head_##SFX(const RenderParams &p, bool counters, uint32_t grid, size_t lds_bytes, hipStream_t s); \
     hipError_t launch_render_tail_##SFX(const RenderParams &p, bool counters, uint32_t grid, size_t lds_bytes, hipStream_t s); \
     hipError_t launch_tail_accumulate_##SFX(const RenderParams &p, hipStream_t s);                               \
+    hipError_t launch_tail_sort_##SFX(const RenderParams &p, uint32_t grid, uint32_t mode, const float *lo3, const float *inv3, hipStream_t s); \
     hipError_t launch_wf_raygen_##SFX(const WfParams &p, hipStream_t s);                                         \
     hipError_t launch_wf_trace_##SFX(const WfParams &p, bool lds_scene, bool counters, uint32_t grid, size_t lds_bytes, \
                                      hipStream_t s);                                                             \

@@ -34,17 +34,24 @@ TRG_DEV SceneView scene_view(const trg::SceneDesc &sc, unsigned char *smem) {
         const uint32_t n16 = sc.lds_stage_bytes >> 4;
         for (uint32_t i = threadIdx.x; i < n16; i += trg::kBlock) dst[i] = src[i];
         __syncthreads();
+        if (kTriPlanes) {   // the shipped build tests triangles in their PLANE form: those records over the Moeller-Trumbore ones
+            const uint4 *alt = reinterpret_cast<const uint4 *>(sc.blob + sc.off_tris_alt);
+            uint4 *tr = reinterpret_cast<uint4 *>(smem + sc.off_tris);
+            for (uint32_t i = threadIdx.x; i < sc.n_tris_rec * 3u; i += trg::kBlock) tr[i] = alt[i];
+            __syncthreads();
+        }
         v.nodes = reinterpret_cast<const v4f *>(smem + sc.off_nodes);
         v.tris = reinterpret_cast<const v4f *>(smem + sc.off_tris);
         v.normals = reinterpret_cast<const float *>(smem + sc.off_normals);
         v.colors = reinterpret_cast<const float *>(smem + sc.off_colors);
         v.mats = reinterpret_cast<const uint32_t *>(smem + sc.off_mats);
+        v.meta = reinterpret_cast<const unsigned short *>(smem + sc.off_meta);
         v.htab = reinterpret_cast<const float *>(smem + sc.off_htab);
     } else {
         // traversed from HBM: the quantised 4-wide nodes and the 128-byte leaf records (geometry + attributes, trg_device.h kRecV4)
         v.nodes = reinterpret_cast<const v4f *>(sc.blob + sc.off_nodes4);
         v.tris = reinterpret_cast<const v4f *>(sc.blob + sc.off_fat);
-        v.normals = nullptr; v.colors = nullptr; v.mats = nullptr;
+        v.normals = nullptr; v.colors = nullptr; v.mats = nullptr; v.meta = nullptr;
         v.htab = nullptr;
     }
     v.tex.uv = nullptr; v.tex.ids = nullptr; v.tex.table = nullptr; v.tex.texels = nullptr;
@@ -820,6 +827,10 @@ hipError_t SFX(launch_render_head)(const RenderParams &p, bool counters, uint32_
 hipError_t SFX(launch_render_tail)(const RenderParams &p, bool counters, uint32_t grid, size_t lds_bytes, hipStream_t s) {
     if (counters) hipLaunchKernelGGL((render_tail_kernel<true>), dim3(grid), dim3(kBlock), lds_bytes, s, p);
     else hipLaunchKernelGGL((render_tail_kernel<false>), dim3(grid), dim3(kBlock), lds_bytes, s, p);
+    return hipGetLastError();
+}
+hipError_t SFX(launch_tail_sort)(const RenderParams &p, uint32_t grid, uint32_t mode, const float *lo3, const float *inv3, hipStream_t s) {
+    hipLaunchKernelGGL(tail_sort_kernel, dim3(grid), dim3(256), 0, s, p, mode, lo3[0], lo3[1], lo3[2], inv3[0], inv3[1], inv3[2]);
     return hipGetLastError();
 }
 hipError_t SFX(launch_tail_accumulate)(const RenderParams &p, hipStream_t s) {

@@ -202,6 +202,81 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES) void render_tail_kernel
     flush_counters(p, smem, wave, lane_id_opaque(), pc, cnt, COUNT);
 }
 
+// ---- sort a tile's queued paths by a coherence key (TRG_OPT_TAIL_SORT; round 4, DESIGN section 6: the verdict's "direction-octant sub-queues") ----
+// A tail wavefront takes 64 CONSECUTIVE entries of its segment: paths of neighbouring pixels at bounce K, whose rays point anywhere.  This
+// kernel re-orders the entries of a workgroup's four segments (one tile's paths of the chunk) by key -- the octant of the direction
+// (3 bits) and, for mode >= 2, the cell of the origin in a 2^3 / 4^3 grid over the scene box -- so that the 64 lanes of a tail wavefront
+// start from the same part of the room in the same general direction: same sign-ordered node addresses, similar walks.  The four
+// segments keep their lengths (segment w takes the next count[w] entries of the sorted sequence), so the tail kernel is unchanged; order
+// inside a key is whatever the LDS atomics give -- every path's arithmetic is its own, the image does not depend on it.
+constexpr uint32_t kTailSortMaxKeys = 512u, kTailSortMaxEntries = 4u * 1024u;
+TRG_DEV uint32_t tail_sort_key(const v4f e0, const v4f e1, uint32_t mode, const float *lo, const float *inv) {
+    const uint32_t oct = (__float_as_uint(e1.x) >> 31) | ((__float_as_uint(e1.y) >> 31) << 1) | ((__float_as_uint(e1.z) >> 31) << 2);
+    if (mode <= 1u) return oct;
+    const uint32_t g = mode == 2u ? 2u : 4u;   // cells per axis
+    const float fg = (float)g;
+    const uint32_t cx = (uint32_t)fminf(fmaxf((e0.x - lo[0]) * inv[0] * fg, 0.0f), fg - 1.0f);
+    const uint32_t cy = (uint32_t)fminf(fmaxf((e0.y - lo[1]) * inv[1] * fg, 0.0f), fg - 1.0f);
+    const uint32_t cz = (uint32_t)fminf(fmaxf((e0.z - lo[2]) * inv[2] * fg, 0.0f), fg - 1.0f);
+    return (((cz * g + cy) * g + cx) << 3) | oct;
+}
+__global__ __launch_bounds__(256) void tail_sort_kernel(const trg::RenderParams p, uint32_t mode, float lox, float loy, float loz, float ivx, float ivy, float ivz) {
+    __shared__ unsigned short keys[kTailSortMaxEntries];
+    __shared__ uint32_t hist[kTailSortMaxKeys];
+    __shared__ uint32_t scan[kTailSortMaxKeys];
+    __shared__ uint32_t segb[5];
+    const uint32_t W0 = blockIdx.x * (uint32_t)trg::kWaves;
+    if (threadIdx.x == 0) {
+        uint32_t a = 0;
+        for (uint32_t w = 0; w < (uint32_t)trg::kWaves; ++w) { segb[w] = a; a += p.tail_count[W0 + w]; }
+        segb[trg::kWaves] = a;
+    }
+    for (uint32_t k = threadIdx.x; k < kTailSortMaxKeys; k += 256u) hist[k] = 0u;
+    __syncthreads();
+    const uint32_t T = segb[trg::kWaves];
+    if (T == 0u) return;
+    const float lo[3] = { lox, loy, loz }, inv[3] = { ivx, ivy, ivz };
+    const v4f *qin = reinterpret_cast<const v4f *>(p.tail_queue);
+    v4f *qout = reinterpret_cast<v4f *>(p.tail_queue_out);
+    // entry i of the tile's sequence -> (segment, index in it)
+    auto locate = [&](uint32_t i, uint32_t &w, uint32_t &k) {
+        w = (i >= segb[1]) + (i >= segb[2]) + (i >= segb[3]);
+        k = i - segb[w];
+    };
+    for (uint32_t i = threadIdx.x; i < T; i += 256u) {
+        uint32_t w, k;
+        locate(i, w, k);
+        const v4f *e = qin + ((size_t)(W0 + w) * p.tail_cap + k) * 3u;
+        const uint32_t key = tail_sort_key(e[0], e[1], mode, lo, inv);
+        keys[i] = (unsigned short)key;
+        atomicAdd(&hist[key], 1u);
+    }
+    __syncthreads();
+    // exclusive prefix over the keys (Hillis-Steele on 512 words, two per thread)
+    for (uint32_t k = threadIdx.x; k < kTailSortMaxKeys; k += 256u) scan[k] = hist[k];
+    __syncthreads();
+    for (uint32_t d = 1u; d < kTailSortMaxKeys; d <<= 1) {
+        uint32_t v[2];
+        for (uint32_t j = 0; j < 2u; ++j) { const uint32_t k = threadIdx.x + j * 256u; v[j] = k >= d ? scan[k - d] : 0u; }
+        __syncthreads();
+        for (uint32_t j = 0; j < 2u; ++j) scan[threadIdx.x + j * 256u] += v[j];
+        __syncthreads();
+    }
+    for (uint32_t k = threadIdx.x; k < kTailSortMaxKeys; k += 256u) hist[k] = scan[k] - hist[k];   // first position of key k
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < T; i += 256u) {
+        uint32_t w, k;
+        locate(i, w, k);
+        const v4f *e = qin + ((size_t)(W0 + w) * p.tail_cap + k) * 3u;
+        const v4f e0 = e[0], e1 = e[1], e2 = e[2];
+        const uint32_t pos = atomicAdd(&hist[keys[i]], 1u);
+        uint32_t w2, k2;
+        locate(pos, w2, k2);
+        v4f *o = qout + ((size_t)(W0 + w2) * p.tail_cap + k2) * 3u;
+        o[0] = e0; o[1] = e1; o[2] = e2;
+    }
+}
+
 // ---- fold the chunk's frames into the running average, in frame order (Accumulate.metal:19-39) ----
 __global__ __launch_bounds__(256) void tail_accumulate_kernel(const trg::RenderParams p) {
     const uint32_t pl = blockIdx.x * 256u + threadIdx.x;

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void wf_shade_kernel(const trg::WfParams p) {
     const WfView w = wf_view(p);
     const trg::SceneDesc &sd = p.sc;
     SceneView sc;
-    sc.nodes = nullptr; sc.htab = nullptr; sc.thr_entries = 0u;
+    sc.nodes = nullptr; sc.htab = nullptr; sc.thr_entries = 0u; sc.meta = nullptr;
     sc.tex = p.tex;
     sc.tris = FAT ? reinterpret_cast<const v4f *>(sd.blob + sd.off_fat) : nullptr;
     sc.normals = FAT ? nullptr : reinterpret_cast<const float *>(sd.blob + sd.off_normals);
