@@ -330,9 +330,11 @@ TRG_API int trg_debug_leaf_records(const float *positions3, const float *normals
 /* host-only: the PLANE form of the triangle records (round 4) -- what the shipped build's triangle test reads on an LDS-resident scene, exactly
  * as trg_load_scene lays it out: per record of trg_debug_build_bvh 12 floats (n.xyz d0 | n1.xyz d1 | n2.xyz d2: t = (d0 - n.o) / (n.dir),
  * P = o + t dir, u = n1.P + d1 = weight of vertex 1, v = n2.P + d2 = weight of vertex 2) and one u16 = (original index << 2) | (material id & 3).
- * A degenerate triangle gets planes no ray passes.  Pass NULL outputs to query the count. */
+ * The planes are relative to the centre of the scene's bounding box (center3_out; the ray origin is shifted by it when a traversal begins), so
+ * that n.o - d0 cancels numbers of the scene's size, not of its distance from the coordinate origin.  A degenerate triangle gets planes no
+ * ray passes.  Pass NULL outputs to query the count. */
 TRG_API int trg_debug_plane_records(const float *positions3, const uint32_t *indices, const uint32_t *material_ids, uint32_t n_verts, uint32_t n_tris,
-                                    float *planes12_out, uint16_t *meta_out, uint32_t records_cap, uint32_t *n_records);
+                                    float *planes12_out, uint16_t *meta_out, uint32_t records_cap, uint32_t *n_records, float *center3_out);
 
 /* host-only: the tile (bx, by) workgroup slot `slot` of a launch over tiles_x x tiles_y tiles renders under tile order `order` (0, 1, 2, 4, 8:
  * TRG_OPT_TILE_ORDER), exactly as the kernels compute it.  Returns 1, 0 for a padding slot of an XCD-aware order (or a slot beyond the

@@ -1,9 +1,12 @@
 """Where does path regeneration start to pay?  Lock-step vs regeneration on lattices of growing size (1920x1080, 16 spp, 3 bounces,
 one launch alone, ms): python scripts/regen_crossover.py"""
 import sys; sys.path.insert(0, ".")
+import os
 from toyraygun_amd import capi, host
+if os.environ.get("TRG_VARIANT"):
+    capi.HIP_SO = os.path.join("exp_build", os.environ["TRG_VARIANT"], "libtoyraygun_hip.so")
 W, H = 1920, 1080
-for n in (0, 4, 6, 9, 12, 16, 20, 28, 36):
+for n in [int(a) for a in sys.argv[1:]] or (0, 4, 6, 9, 12, 16, 20, 28, 36):
     sc = host.Scene.cornell_lattice(n) if n else host.Scene.cornell_box()
     b = sc.buffers()
     c = capi.Context(W, H)

@@ -39,10 +39,11 @@ def test_scene_blob_layout_is_64_bit_and_refuses_what_cannot_fit(built):
     o = list(off)
     # a scene this size has no LDS part: the quantised wide nodes lead the blob, the 128-byte leaf records follow on their own lines
     assert o[:6] == [0] * 6 and o[6] % 128 == 0 and o[6] >= 246_000 * 64
-    assert total.value >= o[6] + 1_022_244 * 128
-    # 25 M triangles fit (128 B per triangle + nodes = 3.6e9); 30 M (4.3e9) would not
-    assert L.trg_debug_scene_layout(25_000_000, 6_000_000, C.byref(total), None) == capi.OK
-    assert total.value > 25_000_000 * 128
+    assert total.value >= o[6] + 1_022_244 * 256       # two sets of leaf records since round 4: Moeller-Trumbore rows (strict build) and planes (shipped build)
+    # 14 M triangles fit (2 x 128 B per triangle + nodes = 3.8e9); 16 M (4.35e9) would not
+    assert L.trg_debug_scene_layout(14_000_000, 3_500_000, C.byref(total), None) == capi.OK
+    assert total.value > 14_000_000 * 256
+    assert L.trg_debug_scene_layout(16_000_000, 4_000_000, C.byref(total), None) == capi.ERR_RANGE
     assert L.trg_debug_scene_layout(30_000_000, 7_500_000, C.byref(total), None) == capi.ERR_RANGE
     # 50 M triangles: the old uint32 sums wrapped to ~2.9e9 and passed; now refused with the true size
     assert L.trg_debug_scene_layout(50_000_000, 12_000_000, C.byref(total), None) == capi.ERR_RANGE
@@ -754,12 +755,14 @@ def test_plane_records_are_the_triangles(built, O):
     for scene in (box, soup):
         b = scene.buffers()
         _, tris, _ = capi.debug_build_bvh(b["positions"], b["indices"], b["material_ids"])
-        planes, meta = capi.debug_plane_records(b["positions"], b["indices"], b["material_ids"])
+        planes, meta, ctr = capi.debug_plane_records(b["positions"], b["indices"], b["material_ids"])
+        pos_all = b["positions"].reshape(-1, 3)
+        assert np.allclose(ctr, 0.5 * (pos_all.min(0) + pos_all.max(0)), atol=1e-6)
         assert planes.shape == (tris.shape[0], 12) and meta.shape == (tris.shape[0],)
         prim, mask = tris[:, 3].view(np.uint32), tris[:, 7].view(np.uint32)
         assert np.array_equal(meta, ((prim << 2) | (mask & 3)).astype(np.uint16))
         assert sorted(prim.tolist()) == list(range(scene.ntris))
-        v0, e1, e2 = tris[:, 0:3].astype(np.float64), tris[:, 4:7].astype(np.float64), tris[:, 8:11].astype(np.float64)
+        v0, e1, e2 = tris[:, 0:3].astype(np.float64) - ctr.astype(np.float64), tris[:, 4:7].astype(np.float64), tris[:, 8:11].astype(np.float64)   # (the planes are relative to the centre)
         P = planes.astype(np.float64)
         area = np.linalg.norm(np.cross(e1, e2), axis=1)
         ok = area > 0

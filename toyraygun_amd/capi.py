@@ -106,7 +106,7 @@ _SYMBOLS = [
     ("trg_group_time_launches", C.c_int, [_P, C.c_int]),
     ("trg_group_launch_ms", C.c_int, [_P, C.c_int, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
     ("trg_group_exchange_note", C.c_char_p, [_P]),
-    ("trg_debug_plane_records", C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
+    ("trg_debug_plane_records", C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, _P, C.c_uint32, C.POINTER(C.c_uint32), _P]),
     ("trg_group_set_bands", C.c_int, [_P, C.c_int]),
     ("trg_group_bands", C.c_int, [_P]),
     ("trg_group_postprocess", C.c_int, [_P, C.c_int, _P, C.c_int]),
@@ -484,20 +484,22 @@ class Group:
 
 
 def debug_plane_records(positions, indices, material_ids):
-    """Host-only (no GPU): the plane form of the triangle records -- (planes[n,12] float32, meta[n] uint16) in the record order of debug_build_bvh."""
+    """Host-only (no GPU): the plane form of the triangle records -- (planes[n,12] float32, meta[n] uint16, center[3] float32) in the record
+    order of debug_build_bvh; the planes are relative to `center`."""
     L = load()
     pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
     idx = np.ascontiguousarray(indices, np.uint32).reshape(-1)
     mat = np.ascontiguousarray(material_ids, np.uint32).reshape(-1)
     n = C.c_uint32()
-    rc = L.trg_debug_plane_records(_ptr(pos), _ptr(idx), _ptr(mat), pos.shape[0], mat.shape[0], None, None, 0, C.byref(n))
+    ctr = np.zeros(3, np.float32)
+    rc = L.trg_debug_plane_records(_ptr(pos), _ptr(idx), _ptr(mat), pos.shape[0], mat.shape[0], None, None, 0, C.byref(n), None)
     if rc != OK:
         raise TrgError(rc, "trg_debug_plane_records")
     planes, meta = np.zeros((n.value, 12), np.float32), np.zeros(n.value, np.uint16)
-    rc = L.trg_debug_plane_records(_ptr(pos), _ptr(idx), _ptr(mat), pos.shape[0], mat.shape[0], _ptr(planes), _ptr(meta), n.value, C.byref(n))
+    rc = L.trg_debug_plane_records(_ptr(pos), _ptr(idx), _ptr(mat), pos.shape[0], mat.shape[0], _ptr(planes), _ptr(meta), n.value, C.byref(n), _ptr(ctr))
     if rc != OK:
         raise TrgError(rc, "trg_debug_plane_records")
-    return planes, meta
+    return planes, meta, ctr
 
 
 def debug_build_bvh(positions, indices, material_ids):

@@ -14,6 +14,8 @@ hipError_t gpu_quantize_nodes4(const float4 *d_nodes4, uint32_t n_nodes4, void *
 
 // 48-byte geometry records (leaf order) + normals / colours in original order (9 floats per triangle) -> 128-byte leaf records
 // (trg_device.h kRecV4) at d_out
-hipError_t gpu_fatten_records(const float4 *d_tris48, const float *d_normals, const float *d_colors, uint32_t ntris, void *d_out, hipStream_t s);
+// planes: the shipped build's form -- rows 0..2 the triangle's three planes (computed in double, as trg_capi.cpp fill_plane_record does on the
+// host), the original index and the material id in the last two words
+hipError_t gpu_fatten_records(const float4 *d_tris48, const float *d_normals, const float *d_colors, uint32_t ntris, void *d_out, bool planes, const float center[3], hipStream_t s);
 
 }  // namespace trg

@@ -736,7 +736,29 @@ hipError_t gpu_build_lbvh(const float *d_pos, const uint32_t *d_idx, const uint3
 // 48-byte geometry records in leaf order + the attribute arrays in original order -> the 128-byte leaf records the HBM kernels read
 // (trg_device.h kRecV4): rows 0..2 the geometry record, floats 12..20 the triangle's normals, 21..29 its colours.  Two threads per
 // record, 64 bytes each: coalesced stores, gathered 36-byte reads.
-__global__ void fatten_records_kernel(const float4 *tris48, const float *nrm, const float *col, uint32_t n, float4 *out) {
+// the three planes of a triangle given as (v0, e1, e2): the arithmetic of trg_capi.cpp fill_plane_record, in double
+__device__ void plane_rows(const float4 r0, const float4 r1, const float4 r2, float cx, float cy, float cz, float4 *o) {
+    const double v0[3] = { (double)r0.x - cx, (double)r0.y - cy, (double)r0.z - cz }, e1[3] = { r1.x, r1.y, r1.z }, e2[3] = { r2.x, r2.y, r2.z };
+    double n[3] = { e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0] };
+    const double len = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    o[0] = make_float4(0.f, 0.f, 0.f, 1.f); o[1] = make_float4(0.f, 0.f, 0.f, -1.f); o[2] = make_float4(0.f, 0.f, 0.f, -1.f);   // never hit
+    if (!(len > 0.0) || !isfinite(len)) return;
+    for (int k = 0; k < 3; ++k) n[k] /= len;
+    double a1[3] = { e2[1] * n[2] - e2[2] * n[1], e2[2] * n[0] - e2[0] * n[2], e2[0] * n[1] - e2[1] * n[0] };
+    double a2[3] = { n[1] * e1[2] - n[2] * e1[1], n[2] * e1[0] - n[0] * e1[2], n[0] * e1[1] - n[1] * e1[0] };
+    const double s1 = e1[0] * a1[0] + e1[1] * a1[1] + e1[2] * a1[2], s2 = e2[0] * a2[0] + e2[1] * a2[1] + e2[2] * a2[2];
+    if (s1 == 0.0 || s2 == 0.0) return;
+    for (int k = 0; k < 3; ++k) { a1[k] /= s1; a2[k] /= s2; }
+    const float4 p0 = make_float4((float)n[0], (float)n[1], (float)n[2], (float)(n[0] * v0[0] + n[1] * v0[1] + n[2] * v0[2]));
+    const float4 p1 = make_float4((float)a1[0], (float)a1[1], (float)a1[2], (float)-(a1[0] * v0[0] + a1[1] * v0[1] + a1[2] * v0[2]));
+    const float4 p2 = make_float4((float)a2[0], (float)a2[1], (float)a2[2], (float)-(a2[0] * v0[0] + a2[1] * v0[1] + a2[2] * v0[2]));
+    const float f[12] = { p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w };
+    bool ok = true;
+    for (int k = 0; k < 12; ++k) ok = ok && isfinite(f[k]);
+    if (ok) { o[0] = p0; o[1] = p1; o[2] = p2; }
+}
+
+__global__ void fatten_records_kernel(const float4 *tris48, const float *nrm, const float *col, uint32_t n, float4 *out, bool planes, float cx, float cy, float cz) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t i = t >> 1, half = t & 1u;
     if (i >= n) return;
@@ -745,20 +767,23 @@ __global__ void fatten_records_kernel(const float4 *tris48, const float *nrm, co
     const float *N = nrm + (size_t)prim * 9, *C = col + (size_t)prim * 9;
     float4 *o = out + (size_t)i * 8;
     if (half == 0u) {
-        o[0] = r0; o[1] = tris48[(size_t)i * 3 + 1]; o[2] = tris48[(size_t)i * 3 + 2];
+        const float4 r1 = tris48[(size_t)i * 3 + 1], r2 = tris48[(size_t)i * 3 + 2];
+        if (planes) plane_rows(r0, r1, r2, cx, cy, cz, o);
+        else { o[0] = r0; o[1] = r1; o[2] = r2; }
         o[3] = make_float4(N[0], N[1], N[2], N[3]);
     } else {
         o[4] = make_float4(N[4], N[5], N[6], N[7]);
         o[5] = make_float4(N[8], C[0], C[1], C[2]);
         o[6] = make_float4(C[3], C[4], C[5], C[6]);
-        o[7] = make_float4(C[7], C[8], 0.0f, 0.0f);
+        // the plane form has no room for them in rows 0..2: the original index and the material id close the record
+        o[7] = planes ? make_float4(C[7], C[8], r0.w, tris48[(size_t)i * 3 + 1].w) : make_float4(C[7], C[8], 0.0f, 0.0f);
     }
 }
 
-hipError_t gpu_fatten_records(const float4 *d_tris48, const float *d_normals, const float *d_colors, uint32_t ntris, void *d_out, hipStream_t s) {
+hipError_t gpu_fatten_records(const float4 *d_tris48, const float *d_normals, const float *d_colors, uint32_t ntris, void *d_out, bool planes, const float center[3], hipStream_t s) {
     if (ntris == 0) return hipSuccess;
     const uint64_t threads = 2ull * ntris;
-    hipLaunchKernelGGL(fatten_records_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, d_tris48, d_normals, d_colors, ntris, static_cast<float4 *>(d_out));
+    hipLaunchKernelGGL(fatten_records_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, d_tris48, d_normals, d_colors, ntris, static_cast<float4 *>(d_out), planes, center[0], center[1], center[2]);
     return hipGetLastError();
 }
 

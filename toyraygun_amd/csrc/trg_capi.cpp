@@ -113,14 +113,15 @@ static bool plan_scene_layout(uint64_t n_nodes, uint32_t node_bytes, uint64_t nt
     const uint64_t stage_end = align16_64(off_htab + (with_htab ? kHtabBytes : 0u));
     const uint64_t off_nodes4 = (stage_end + 127ull) & ~127ull;  // 64-byte nodes, two per 128-byte line
     const uint64_t off_fat = (off_nodes4 + n_nodes4 * kQ4NodeBytes + 127ull) & ~127ull;   // one record per 128-byte line
-    const uint64_t off_tris_alt = off_fat + n_fat * kFatRecBytes;                          // the plane records of an LDS-sized scene (16-byte aligned)
+    const uint64_t off_fat_planes = off_fat + n_fat * kFatRecBytes;                        // the shipped build's leaf records (planes), one per line as well
+    const uint64_t off_tris_alt = off_fat_planes + n_fat * kFatRecBytes;                   // the plane records of an LDS-sized scene (16-byte aligned)
     total = off_tris_alt + nt_rec * 48ull + 128ull;
     if (total > kBlobLimit) return false;
     sc.off_meta = (uint32_t)off_meta; sc.off_tris_alt = (uint32_t)off_tris_alt;
     sc.off_nodes = (uint32_t)off_nodes; sc.off_tris = (uint32_t)off_tris; sc.off_normals = (uint32_t)off_normals;
     sc.off_colors = (uint32_t)off_colors; sc.off_mats = (uint32_t)off_mats; sc.off_htab = (uint32_t)off_htab;
     sc.off_nodes4 = (uint32_t)off_nodes4;
-    sc.off_fat = (uint32_t)off_fat; sc.n_fat = (uint32_t)n_fat;
+    sc.off_fat = (uint32_t)off_fat; sc.n_fat = (uint32_t)n_fat; sc.off_fat_planes = (uint32_t)off_fat_planes;
     sc.lds_stage_bytes = with_htab ? (uint32_t)stage_end : 0u;
     sc.blob_bytes = (uint32_t)total;
     return true;
@@ -147,8 +148,9 @@ static void fill_fat_record(unsigned char *dst, const F4 *rec48, const float *nr
 // n1 = (e2 x n) / (e1 . (e2 x n)), d1 = -n1 . v0  (u = n1 . P + d1 = weight of vertex 1);  n2 = (n x e1) / (e2 . (n x e1)), d2 = -n2 . v0
 // (v = weight of vertex 2).  A degenerate triangle gets planes no ray passes (u = -1).  meta = (original index << 2) | (material id & 3):
 // rays carry mask 3 (primary) or 1 (secondary), so the two low bits of the material id are all the mask test ever sees.
-static void fill_plane_record(unsigned char *dst, uint16_t *meta, const F4 *rec48) {
-    const double v0[3] = { rec48[0].x, rec48[0].y, rec48[0].z }, e1[3] = { rec48[1].x, rec48[1].y, rec48[1].z }, e2[3] = { rec48[2].x, rec48[2].y, rec48[2].z };
+static void fill_plane_record(unsigned char *dst, uint16_t *meta, const F4 *rec48, const float *center) {
+    // (relative to `center`: SceneDesc::center -- the ray origin is shifted by it too, trg_device.h trav_begin)
+    const double v0[3] = { (double)rec48[0].x - center[0], (double)rec48[0].y - center[1], (double)rec48[0].z - center[2] }, e1[3] = { rec48[1].x, rec48[1].y, rec48[1].z }, e2[3] = { rec48[2].x, rec48[2].y, rec48[2].z };
     auto cross = [](const double *a, const double *b, double *o) { o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; };
     auto dot = [](const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
     double n[3], a1[3], a2[3];
@@ -173,6 +175,16 @@ static void fill_plane_record(unsigned char *dst, uint16_t *meta, const F4 *rec4
     uint32_t prim, mask;
     memcpy(&prim, &rec48[0].w, 4); memcpy(&mask, &rec48[1].w, 4);
     *meta = (uint16_t)((prim << 2) | (mask & 3u));
+}
+
+// The shipped build's 128-byte leaf record: rows 0..2 the three planes (fill_plane_record), the attributes where fill_fat_record puts them,
+// the original index and the material id in the last two words.
+static void fill_fat_record_planes(unsigned char *dst, const F4 *rec48, const float *nrm, const float *col, uint32_t n_tris, const float *center) {
+    fill_fat_record(dst, rec48, nrm, col, n_tris);
+    uint16_t meta;
+    fill_plane_record(dst, &meta, rec48, center);
+    memcpy(dst + 120, &rec48[0].w, 4);   // float 30: original index
+    memcpy(dst + 124, &rec48[1].w, 4);   // float 31: material id = mask
 }
 
 constexpr uint32_t kStackLdsLevels = TRG_STACK_LDS_LEVELS;
@@ -377,6 +389,7 @@ static int load_scene_gpu_build(trg_ctx *c, const float *pos, const float *nrm, 
     SceneDesc sc{};
     sc.n_nodes = 0; sc.n_tris = n_tris;
     sc.n_nodes4 = n4;
+    for (int a = 0; a < 3; ++a) sc.center[a] = 0.5f * (lo[a] + hi[a]);
     uint64_t total = 0;
     if (!plan_scene_layout(0, 64u, 0, 0, false, n4, n_tris, sc, total))
         return fail(c, TRG_ERR_RANGE, "trg_load_scene: scene needs %llu B on the device (limit 4 GiB)", (unsigned long long)total);
@@ -390,7 +403,8 @@ static int load_scene_gpu_build(trg_ctx *c, const float *pos, const float *nrm, 
         HIPCHK(c, hipMalloc(&d_nrm.p, (size_t)n_tris * 36)); HIPCHK(c, hipMalloc(&d_col.p, (size_t)n_tris * 36));
         HIPCHK(c, hipMemcpyAsync(d_nrm.p, nrm, (size_t)n_tris * 36, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(d_col.p, col, (size_t)n_tris * 36, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, gpu_fatten_records((const float4 *)d_tris.p, (const float *)d_nrm.p, (const float *)d_col.p, n_tris, c->blob + sc.off_fat, c->stream));
+        HIPCHK(c, gpu_fatten_records((const float4 *)d_tris.p, (const float *)d_nrm.p, (const float *)d_col.p, n_tris, c->blob + sc.off_fat, false, sc.center, c->stream));
+        HIPCHK(c, gpu_fatten_records((const float4 *)d_tris.p, (const float *)d_nrm.p, (const float *)d_col.p, n_tris, c->blob + sc.off_fat_planes, true, sc.center, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     HIPCHK(c, gpu_quantize_nodes4((const float4 *)d_nodes4.p, n4, c->blob + sc.off_nodes4, c->stream));
@@ -586,6 +600,7 @@ int host_scene_build(trg_ctx *c, const float *pos, const float *nrm, const float
     SceneDesc sc{};
     sc.n_nodes = lds_candidate ? lds_nodes : 0u; sc.n_tris = n_tris;
     sc.n_tris_rec = lds_candidate ? nt_rec : 0u;
+    for (int a = 0; a < 3; ++a) sc.center[a] = n_tris ? 0.5f * (hs->lo[a] + hs->hi[a]) : 0.0f;
     sc.thr_entries = (kThreadedLds && lds_candidate) ? thr_entries : 0u;
     const uint32_t node_bytes = kLdsNodeBytes;
     sc.n_nodes4 = bvh.n_nodes4;
@@ -699,14 +714,17 @@ int host_scene_build(trg_ctx *c, const float *pos, const float *nrm, const float
     }
     if (lds_candidate) {
         memcpy(&host[sc.off_tris], bvh.tris.data(), bvh.tris.size() * sizeof(F4));
-        for (uint32_t i = 0; i < nt_rec; ++i) fill_plane_record(&host[sc.off_tris_alt + (size_t)i * 48u], reinterpret_cast<uint16_t *>(&host[sc.off_meta]) + i, &bvh.tris[(size_t)i * 3]);
+        for (uint32_t i = 0; i < nt_rec; ++i) fill_plane_record(&host[sc.off_tris_alt + (size_t)i * 48u], reinterpret_cast<uint16_t *>(&host[sc.off_meta]) + i, &bvh.tris[(size_t)i * 3], sc.center);
         if (n_tris) {
             memcpy(&host[sc.off_normals], nrm, (size_t)n_tris * 36);
             memcpy(&host[sc.off_colors], col, (size_t)n_tris * 36);
             memcpy(&host[sc.off_mats], mat, (size_t)n_tris * 4);
         }
     }
-    for (uint32_t i = 0; i < nt_rec; ++i) fill_fat_record(&host[sc.off_fat + (size_t)i * kFatRecBytes], &bvh.tris[(size_t)i * 3], nrm, col, n_tris);
+    for (uint32_t i = 0; i < nt_rec; ++i) {
+        fill_fat_record(&host[sc.off_fat + (size_t)i * kFatRecBytes], &bvh.tris[(size_t)i * 3], nrm, col, n_tris);
+        fill_fat_record_planes(&host[sc.off_fat_planes + (size_t)i * kFatRecBytes], &bvh.tris[(size_t)i * 3], nrm, col, n_tris, sc.center);
+    }
     if (lds_candidate) {  // Halton group tables (trg_kernels.h kHtab)
         float *T = reinterpret_cast<float *>(&host[sc.off_htab]);
         for (const HtabSpec &h : kHtab)
@@ -1313,7 +1331,7 @@ int trg_debug_leaf_records(const float *positions3, const float *normals3, const
 }
 
 int trg_debug_plane_records(const float *positions3, const uint32_t *indices, const uint32_t *material_ids, uint32_t n_verts, uint32_t n_tris,
-                            float *planes12_out, uint16_t *meta_out, uint32_t records_cap, uint32_t *n_records) {
+                            float *planes12_out, uint16_t *meta_out, uint32_t records_cap, uint32_t *n_records, float *center3_out) {
     if (!positions3 || !indices || !material_ids || n_tris == 0) return TRG_ERR_INVALID;
     for (size_t i = 0; i < (size_t)n_tris * 3; ++i)
         if (indices[i] >= n_verts) return TRG_ERR_INVALID;
@@ -1321,10 +1339,15 @@ int trg_debug_plane_records(const float *positions3, const uint32_t *indices, co
     build_bvh(positions3, indices, material_ids, n_tris, bvh);
     const uint32_t nrec = (uint32_t)(bvh.tris.size() / 3);
     if (n_records) *n_records = nrec;
+    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY }, ctr[3];
+    for (size_t i = 0; i < (size_t)n_tris * 3; ++i)
+        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], positions3[(size_t)indices[i] * 3 + a]); hi[a] = std::max(hi[a], positions3[(size_t)indices[i] * 3 + a]); }
+    for (int a = 0; a < 3; ++a) ctr[a] = 0.5f * (lo[a] + hi[a]);
+    if (center3_out) memcpy(center3_out, ctr, 12);
     if (planes12_out || meta_out) {
         if (records_cap < nrec || !planes12_out || !meta_out) return TRG_ERR_RANGE;
         for (uint32_t i = 0; i < nrec; ++i)
-            fill_plane_record(reinterpret_cast<unsigned char *>(planes12_out) + (size_t)i * 48u, meta_out + i, &bvh.tris[(size_t)i * 3]);
+            fill_plane_record(reinterpret_cast<unsigned char *>(planes12_out) + (size_t)i * 48u, meta_out + i, &bvh.tris[(size_t)i * 3], ctr);
     }
     return TRG_OK;
 }

@@ -516,9 +516,14 @@ struct SceneView {
     const float *htab;      // Halton group tables in LDS (trg_kernels.h kHtab), or nullptr
     trg::TexDesc tex;       // albedo textures in global memory (tex.uv == nullptr: none)
     const unsigned short *meta;   // LDS scene: per record (original index << 2) | (material id & 3) (the plane test of the shipped build)
+    V3 center;              // shipped build: the point the plane records are relative to (SceneDesc::center); Trav::o is relative to it too
     uint32_t thr_entries;   // TRG_TRAV_LDS == 6: entries of the octant-threaded tree behind `nodes`
     uint32_t rec_delta;     // HBM scene: byte distance from `nodes` to `tris` (the records follow the nodes in the blob)
 };
+// original index / material id of leaf record r of an HBM-resident scene: the .w of rows 0 / 1 (Moeller-Trumbore records), or the last two
+// words of the record (plane records, whose rows 0..2 are full)
+TRG_DEV int fat_prim(const v4f *recs, uint32_t r);
+TRG_DEV uint32_t fat_mask(const v4f *recs, uint32_t r);
 struct Hit { float t; int prim; float u, v; };  // u, v = Moeller-Trumbore weights of vertex 1 and 2; prim = original index (LDS scene) or leaf record (HBM scene)
 struct Counters { uint32_t nodes, tris, wnodes, wtris; };  // per-lane work and wave-level iterations (first active lane counts)
 
@@ -551,6 +556,11 @@ TRG_DEV bool tri_test_planes(const v4f a, const v4f b, const v4f c, V3 o, V3 d, 
 }
 // the build's triangle test on an LDS-resident scene: planes + the u16 per record (shipped), or the Moeller-Trumbore rows (strict)
 constexpr bool kTriPlanes = !TRG_STRICT && TRG_TRI_PLANES;
+// ... and on a scene traversed from HBM: the leaf records of SceneDesc::off_fat_planes (rows 0..2 planes, words 30 / 31 index and mask)
+constexpr bool kRecPlanes = !TRG_STRICT && TRG_TRI_PLANES_HBM;
+
+TRG_DEV int fat_prim(const v4f *recs, uint32_t r) { return __float_as_int(kRecPlanes ? recs[(size_t)r * kRecV4 + 7].z : recs[(size_t)r * kRecV4].w); }
+TRG_DEV uint32_t fat_mask(const v4f *recs, uint32_t r) { return (uint32_t)__float_as_int(kRecPlanes ? recs[(size_t)r * kRecV4 + 7].w : recs[(size_t)r * kRecV4 + 1].w); }
 
 // Per-lane traversal stack, laid out [level][thread] so lane i always hits LDS bank i%32 (no conflicts).
 // Scenes staged in LDS have shallow trees and keep the whole stack in LDS (klds = all levels).  Scenes in
@@ -616,14 +626,17 @@ TRG_DEV float clamp_away_from_zero(float v) {
     const uint32_t mag = b & 0x7fffffffu, tiny = 0x0da24260u;  // 1e-30f
     return __uint_as_float((b & 0x80000000u) | (mag < tiny ? tiny : mag));
 }
-TRG_DEV void trav_begin(Trav &tv, V3 o, V3 d, float tmax, uint32_t rmask, int sp0, uint32_t node_base = 0u, bool wide_lds = false) {
+// The plane tests want the ray origin RELATIVE to the scene's centre (SceneView::center).  A traversal of an LDS-resident scene (`rel`) keeps
+// o - centre in Trav::o -- nothing but the triangle test reads it there, the kernels keep the path's own origin --; the HBM step subtracts per
+// test instead, because the regeneration kernel's Trav::o IS the path's origin (one copy, read back by the shading event).
+TRG_DEV void trav_begin(const SceneView &sc, Trav &tv, V3 o, V3 d, float tmax, uint32_t rmask, int sp0, uint32_t node_base = 0u, bool wide_lds = false, bool rel = false) {
     // Reciprocal direction with zero components pushed to +-1e-30: the slab products stay finite (no
     // inf - inf = NaN whose fmin/fmax would pick the wrong endpoint), and a ray that moves 1e-30 per
     // unit t along an axis is parallel to the slab for every practical purpose.
     // |d| < 1e-30 ? copysign(1e-30, d) : d, written on the bit patterns (the magnitudes of non-negative floats order like
     // unsigned integers) so that every constant is a VOP2 literal instead of a VGPR the inner loops would have to carry
     const float dx = clamp_away_from_zero(d.x), dy = clamp_away_from_zero(d.y), dz = clamp_away_from_zero(d.z);
-    tv.o = o; tv.d = d;
+    tv.o = (kTriPlanes && rel) ? o - sc.center : o; tv.d = d;
     tv.idx = rcp_fast(dx); tv.idy = rcp_fast(dy); tv.idz = rcp_fast(dz);
     tv.oix = o.x * tv.idx; tv.oiy = o.y * tv.idy; tv.oiz = o.z * tv.idz;
     tv.best = tmax; tv.rmask = rmask;
@@ -753,7 +766,7 @@ TRG_DEV bool trav_tri_math(const v4f a, const v4f b, const v4f c, Trav &tv, bool
     if (REC) {
         const bool closer = any || !tv.found || t < tv.best;
         take = ok && closer;
-        if (ok && !closer && t == tv.best) take = prim < __float_as_int(recs[(size_t)(uint32_t)tv.hit.prim * kRecV4].w);
+        if (ok && !closer && t == tv.best) take = prim < fat_prim(recs, (uint32_t)tv.hit.prim);
     } else {
         take = ok && (any || !tv.found || t < tv.best || (t == tv.best && prim < tv.hit.prim));
     }
@@ -777,6 +790,24 @@ TRG_DEV bool trav_tri_planes(const v4f a, const v4f b, const v4f c, uint32_t met
     tv.found = tv.found || ok;
     tv.best = take ? t : tv.best;
     tv.hit.prim = take ? prim : tv.hit.prim;
+    tv.hit.u = take ? u : tv.hit.u;
+    tv.hit.v = take ? v : tv.hit.v;
+    return any && ok;
+}
+// ... and on a leaf RECORD of an HBM-resident scene (the hit keeps the record index; ties go to the lower original index, read back from the
+// held record only then): mask and prim are the record's last two words
+template <bool COUNT>
+TRG_DEV bool trav_tri_planes_rec(const v4f a, const v4f b, const v4f c, uint32_t mask, int prim, Trav &tv, bool any, Counters &cnt, uint32_t rec, const v4f *recs, V3 center) {
+    const bool masked_in = (mask & tv.rmask) != 0u;
+    if (COUNT) { if (masked_in) cnt.tris++; if (mbcnt64(__ballot(1)) == 0) cnt.wtris++; }
+    float t, u, v;
+    const bool ok = tri_test_planes(a, b, c, tv.o - center, tv.d, tv.best, t, u, v) && masked_in;   // (Trav::o is the path's origin here: trav_begin)
+    const bool closer = any || !tv.found || t < tv.best;
+    bool take = ok && closer;
+    if (ok && !closer && t == tv.best) take = prim < fat_prim(recs, (uint32_t)tv.hit.prim);
+    tv.found = tv.found || ok;
+    tv.best = take ? t : tv.best;
+    tv.hit.prim = take ? (int)rec : tv.hit.prim;
     tv.hit.u = take ? u : tv.hit.u;
     tv.hit.v = take ? v : tv.hit.v;
     return any && ok;
@@ -949,11 +980,15 @@ TRG_DEV void trav_step_wide(const SceneView &sc, Trav &tv, bool any, STK stk, Co
     const uint32_t off = inner ? (uint32_t)tv.node * 64u : (code & ~7u) * (uint32_t)(kRecV4 * 16 / 8) + sc.rec_delta;
     const v4f *ptr = reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(sc.nodes) + off);
     const v4f q0 = ptr[0], q1 = ptr[1], q2 = ptr[2];
+    // the fourth load: the children of a node, or -- plane records -- the last row of the leaf record (its index and mask); one instruction for both kinds
+    v4f q3;
+    if (kRecPlanes) q3 = ptr[inner ? 3 : 7];
+    else if (inner) q3 = ptr[3];
     if (inner) {
-        const v4f q3 = ptr[3];
         trav_node4_math<COUNT, BLOCK>(q0, q1, q2, q3, tv, stk, cnt);
     } else {
-        const bool stop = trav_tri_math<COUNT, true>(q0, q1, q2, tv, any, cnt, first, sc.tris);
+        const bool stop = kRecPlanes ? trav_tri_planes_rec<COUNT>(q0, q1, q2, (uint32_t)__float_as_int(q3.w), __float_as_int(q3.z), tv, any, cnt, first, sc.tris, sc.center)
+                                     : trav_tri_math<COUNT, true>(q0, q1, q2, tv, any, cnt, first, sc.tris);
         const bool more = left != 0u;
         const bool do_pop = !stop && !more;
         const int sp = tv.sp - (do_pop ? STK::unit : 0);
@@ -991,7 +1026,7 @@ TRG_DEV bool traverse(const SceneView &sc, V3 o, V3 d, float tmax_ray, uint32_t 
     return !ANY;
 #endif
     Trav tv;
-    trav_begin(tv, o, d, tmax_ray, rmask, stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED && TRG_TRAV_LDS == 5);
+    trav_begin(sc, tv, o, d, tmax_ray, rmask, stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED && TRG_TRAV_LDS == 5, !UNIFIED);
     constexpr int mode = UNIFIED ? TRG_TRAV_HBM : TRG_TRAV_LDS;
     if (mode == 3) {
         while (tv.node != kNodeDone) trav_step_wide<COUNT, BLOCK>(sc, tv, ANY, stk, cnt);
@@ -1051,7 +1086,7 @@ TRG_DEV void traverse_pair(const SceneView &sc, V3 org, bool has_shadow, V3 sdir
     nhit.t = -1.0f; nhit.prim = -1; nhit.u = 0.0f; nhit.v = 0.0f;
     int phase = has_shadow ? 0 : (has_next ? 1 : 2);
     Trav tv;
-    trav_begin(tv, org, phase == 0 ? sdir : ndir, phase == 0 ? smax : INFINITY, phase == 0 ? 1u : nmask, stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED && TRG_TRAV_LDS == 5);
+    trav_begin(sc, tv, org, phase == 0 ? sdir : ndir, phase == 0 ? smax : INFINITY, phase == 0 ? 1u : nmask, stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED && TRG_TRAV_LDS == 5, !UNIFIED);
     if (phase == 2) tv.node = kNodeDone;
     constexpr int mode = UNIFIED ? TRG_TRAV_HBM : TRG_TRAV_LDS;
     while (phase < 2) {
@@ -1066,7 +1101,7 @@ TRG_DEV void traverse_pair(const SceneView &sc, V3 org, bool has_shadow, V3 sdir
             if (phase == 0) {
                 occluded = tv.found;
                 phase = has_next ? 1 : 2;
-                if (phase == 1) trav_begin(tv, org, ndir, INFINITY, nmask, stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED && TRG_TRAV_LDS == 5);
+                if (phase == 1) trav_begin(sc, tv, org, ndir, INFINITY, nmask, stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED && TRG_TRAV_LDS == 5, !UNIFIED);
             } else {
                 nhit = trav_hit(tv); nfound = tv.found;
                 phase = 2;
@@ -1109,7 +1144,7 @@ TRG_DEV void trace_queue(const SceneView &sc, const PoolView pv, const unsigned 
     bool busy = false, exhausted = false, any = false;
     uint32_t slot = 0;
     Trav tv;
-    trav_begin(tv, mk(0.0f, 0.0f, 0.0f), mk(0.0f, 0.0f, 1.0f), 0.0f, 0u, stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED && TRG_TRAV_LDS == 5);
+    trav_begin(sc, tv, mk(0.0f, 0.0f, 0.0f), mk(0.0f, 0.0f, 1.0f), 0.0f, 0u, stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED && TRG_TRAV_LDS == 5, !UNIFIED);
     tv.node = kNodeDone;
     for (;;) {
         // ---- refill: idle lanes take the next list entries ----
@@ -1128,8 +1163,8 @@ TRG_DEV void trace_queue(const SceneView &sc, const PoolView pv, const unsigned 
                 any = (e >> 15) != 0u;
                 const v4f r0 = pv.R0[slot];  // the shadow ray starts where the next ray starts
                 const v4f r1 = any ? pv.SH[slot] : pv.R1[slot];
-                trav_begin(tv, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), any ? r1.w : r0.w,
-                           any ? 1u : (uint32_t)__float_as_int(r1.w), stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED && TRG_TRAV_LDS == 5);
+                trav_begin(sc, tv, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), any ? r1.w : r0.w,
+                           any ? 1u : (uint32_t)__float_as_int(r1.w), stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED && TRG_TRAV_LDS == 5, !UNIFIED);
                 busy = true;
             }
         }
@@ -1214,7 +1249,7 @@ TRG_DEV Surf<FAT> surf_fetch(const SceneView &sc, int ref) {
     s.ref = ref;
     if (FAT) {
         const v4f *rec = sc.tris + (size_t)(uint32_t)ref * kRecV4;
-        s.mat = (uint32_t)__float_as_int(rec[1].w);
+        s.mat = (uint32_t)__float_as_int(kRecPlanes ? rec[7].w : rec[1].w);
         s.r3 = rec[3]; s.r4 = rec[4]; s.r5 = rec[5]; s.r6 = rec[6]; s.r7 = rec[7];
     } else {
         s.mat = sc.mats[ref];
@@ -1231,7 +1266,7 @@ TRG_DEV void surf_interp(const SceneView &sc, const Surf<FAT> &s, float cx, floa
         const V3 C0 = mk(s.r5.y, s.r5.z, s.r5.w), C1 = mk(s.r6.x, s.r6.y, s.r6.z), C2 = mk(s.r6.w, s.r7.x, s.r7.y);
         vcol = cx * C0 + cy * C1 + cz * C2;
         nraw = cx * N0 + cy * N1 + cz * N2;
-        if (sc.tex.uv) prim = __float_as_int(sc.tris[(size_t)(uint32_t)s.ref * kRecV4].w);   // textures are addressed by the original index
+        if (sc.tex.uv) prim = fat_prim(sc.tris, (uint32_t)s.ref);   // textures are addressed by the original index
     } else {
         vcol = interp_attr(sc.colors, prim, cx, cy);
         nraw = interp_attr(sc.normals, prim, cx, cy);

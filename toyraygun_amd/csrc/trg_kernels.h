@@ -56,6 +56,12 @@ struct SceneDesc {
     // leaf order like the Moeller-Trumbore records (off_tris), kept outside the staged part and copied over them at staging time --
     // and, inside the staged part, one u16 per record: (original index << 2) | (material id & 3), the test's mask and the hit's primitive
     uint32_t off_tris_alt, off_meta, n_tris_rec;   // n_tris_rec = 48-byte records of the staged part (leaf order)
+    // scenes traversed from HBM, shipped build (TRG_TRI_PLANES_HBM): a second set of 128-byte leaf records whose rows 0..2 are the triangle's
+    // three planes; its attributes sit where off_fat's do, the original index and the material id in the last two words (floats 30, 31)
+    uint32_t off_fat_planes;
+    // the planes are stored relative to this point (the centre of the scene's bounding box) and a ray's origin is shifted by it when its
+    // traversal begins: n . o - d0 then cancels numbers of the size of the scene instead of its distance from the coordinate origin
+    float center[3];
 };
 constexpr uint32_t kFatRecBytes = 128u;
 
@@ -202,6 +208,9 @@ struct TraceParams {
 // on (v0, e1, e2) like the strict build (31).  trg_device.h tri_test_planes.
 #ifndef TRG_TRI_PLANES
 #define TRG_TRI_PLANES 1
+#endif
+#ifndef TRG_TRI_PLANES_HBM
+#define TRG_TRI_PLANES_HBM 1   // the same for scenes traversed from HBM (their own set of leaf records, SceneDesc::off_fat_planes)
 #endif
 #ifndef TRG_HALTON_TABLES
 #define TRG_HALTON_TABLES 1

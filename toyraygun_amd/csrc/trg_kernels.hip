@@ -50,13 +50,14 @@ TRG_DEV SceneView scene_view(const trg::SceneDesc &sc, unsigned char *smem) {
     } else {
         // traversed from HBM: the quantised 4-wide nodes and the 128-byte leaf records (geometry + attributes, trg_device.h kRecV4)
         v.nodes = reinterpret_cast<const v4f *>(sc.blob + sc.off_nodes4);
-        v.tris = reinterpret_cast<const v4f *>(sc.blob + sc.off_fat);
+        v.tris = reinterpret_cast<const v4f *>(sc.blob + (kRecPlanes ? sc.off_fat_planes : sc.off_fat));
         v.normals = nullptr; v.colors = nullptr; v.mats = nullptr; v.meta = nullptr;
         v.htab = nullptr;
     }
+    v.center = mk(sc.center[0], sc.center[1], sc.center[2]);
     v.tex.uv = nullptr; v.tex.ids = nullptr; v.tex.table = nullptr; v.tex.texels = nullptr;
     v.thr_entries = sc.thr_entries;
-    v.rec_delta = LDS_SCENE ? 0u : sc.off_fat - sc.off_nodes4;
+    v.rec_delta = LDS_SCENE ? 0u : (kRecPlanes ? sc.off_fat_planes : sc.off_fat) - sc.off_nodes4;
     return v;
 }
 
@@ -672,7 +673,7 @@ __global__ __launch_bounds__(trg::kBlock) void trace_kernel(const trg::TracePara
         trg_isect is;
         is.distance = found ? h.t : -1.0f;
         // an HBM-resident scene names the leaf record of the hit: its first row carries the original index
-        is.primitiveIndex = found ? (LDS_SCENE ? h.prim : __float_as_int(sc.tris[(size_t)(uint32_t)h.prim * kRecV4].w)) : -1;
+        is.primitiveIndex = found ? (LDS_SCENE ? h.prim : fat_prim(sc.tris, (uint32_t)h.prim)) : -1;
         is.coordinates[0] = found ? (1.0f - h.u - h.v) : 0.0f;
         is.coordinates[1] = found ? h.u : 0.0f;
         reinterpret_cast<trg_isect *>(p.out)[i] = is;

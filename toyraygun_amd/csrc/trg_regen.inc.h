@@ -125,7 +125,7 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
     bool in_shadow = false, in_next = false;   // traversing the shadow ray / the nearest-hit ray (neither: waiting); lane masks, not a VGPR
     V3 dnext = mk(0.0f, 0.0f, 1.0f), scol = mk(0.0f, 0.0f, 0.0f);
     Trav tv;
-    trav_begin(tv, mk(0.0f, 0.0f, 0.0f), mk(0.0f, 0.0f, 1.0f), 0.0f, 0u, stk.first());
+    trav_begin(sc, tv, mk(0.0f, 0.0f, 0.0f), mk(0.0f, 0.0f, 1.0f), 0.0f, 0u, stk.first());
     tv.node = kNodeDone;
     uint32_t rot = 0, it = 0;
 #ifdef TRG_REGEN_GUARD
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
                                 park[6 * trg::kBlock] = 0.0f; park[7 * trg::kBlock] = 0.0f; park[8 * trg::kBlock] = 0.0f;   // the frame's texel
                                 primary_ray = true;   // (taking the job has reset the event count)
                                 active = p.bounces > 0u;   // with no bounce to trace the path is over as it starts
-                                if (active) { trav_begin(tv, o, d, INFINITY, 3u, stk.first()); in_next = true; pending_next = false; }
+                                if (active) { trav_begin(sc, tv, o, d, INFINITY, 3u, stk.first()); in_next = true; pending_next = false; }
                             }
                         } else {
                             running = false;
@@ -244,10 +244,10 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
                         park[6 * trg::kBlock] = rad.x; park[7 * trg::kBlock] = rad.y; park[8 * trg::kBlock] = rad.z;
                         has_shadow = so.want_shadow; scol = so.scol;
                         if (so.want_shadow) {
-                            trav_begin(tv, o, so.sdir, so.smax, 1u, stk.first());
+                            trav_begin(sc, tv, o, so.sdir, so.smax, 1u, stk.first());
                             in_shadow = true; pending_next = so.want_next; dnext = d;
                         } else if (so.want_next) {
-                            trav_begin(tv, o, d, INFINITY, rmask, stk.first());
+                            trav_begin(sc, tv, o, d, INFINITY, rmask, stk.first());
                             in_next = true; pending_next = false;
                         }
                         // neither: the path is over (last bounce, light, miss) and the lane waits for class 0
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
                 if (in_shadow) {
                     occluded = tv.found;
                     in_shadow = false;
-                    if (pending_next) { trav_begin(tv, tv.o, dnext, INFINITY, 1u, stk.first()); in_next = true; pending_next = false; }
+                    if (pending_next) { trav_begin(sc, tv, tv.o, dnext, INFINITY, 1u, stk.first()); in_next = true; pending_next = false; }
                 } else {
                     in_next = false;
                 }

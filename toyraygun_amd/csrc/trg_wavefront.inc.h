@@ -123,7 +123,7 @@ __global__ __launch_bounds__(trg::kBlock, 8) void wf_trace_kernel(const trg::WfP
     bool busy = false, exhausted = false, any = false;
     uint32_t pid = 0;
     Trav tv;
-    trav_begin(tv, mk(0.0f, 0.0f, 0.0f), mk(0.0f, 0.0f, 1.0f), 0.0f, 0u, stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED && TRG_TRAV_LDS == 5);
+    trav_begin(sc, tv, mk(0.0f, 0.0f, 0.0f), mk(0.0f, 0.0f, 1.0f), 0.0f, 0u, stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED && TRG_TRAV_LDS == 5, !UNIFIED);
     tv.node = kNodeDone;
     // This wavefront's reserved slice [cur, end) of the queue.  A slice is taken with ONE atomic on the queue head and then handed
     // out to idle lanes with a ballot / mbcnt prefix, no memory traffic: one word sustains only ~90 atomics per microsecond
@@ -157,8 +157,8 @@ __global__ __launch_bounds__(trg::kBlock, 8) void wf_trace_kernel(const trg::WfP
                 any = (e >> 31) != 0u;
                 const v4f r0 = wf_ld(&w.ray_o[pid]);
                 const v4f r1 = any ? wf_ld(&w.sh[pid]) : wf_ld(&w.ray_d[pid]);
-                trav_begin(tv, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), any ? r1.w : r0.w, any ? 1u : (uint32_t)__float_as_int(r1.w),
-                           stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED && TRG_TRAV_LDS == 5);
+                trav_begin(sc, tv, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), any ? r1.w : r0.w, any ? 1u : (uint32_t)__float_as_int(r1.w),
+                           stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED && TRG_TRAV_LDS == 5, !UNIFIED);
                 busy = true;
             }
             const uint32_t n_idle = (uint32_t)__popcll(idle);
@@ -230,9 +230,9 @@ __global__ __launch_bounds__(256) void wf_shade_kernel(const trg::WfParams p) {
     const WfView w = wf_view(p);
     const trg::SceneDesc &sd = p.sc;
     SceneView sc;
-    sc.nodes = nullptr; sc.htab = nullptr; sc.thr_entries = 0u; sc.meta = nullptr;
+    sc.nodes = nullptr; sc.htab = nullptr; sc.thr_entries = 0u; sc.meta = nullptr; sc.center = mk(sd.center[0], sd.center[1], sd.center[2]);
     sc.tex = p.tex;
-    sc.tris = FAT ? reinterpret_cast<const v4f *>(sd.blob + sd.off_fat) : nullptr;
+    sc.tris = FAT ? reinterpret_cast<const v4f *>(sd.blob + (kRecPlanes ? sd.off_fat_planes : sd.off_fat)) : nullptr;
     sc.normals = FAT ? nullptr : reinterpret_cast<const float *>(sd.blob + sd.off_normals);
     sc.colors = FAT ? nullptr : reinterpret_cast<const float *>(sd.blob + sd.off_colors);
     sc.mats = FAT ? nullptr : reinterpret_cast<const uint32_t *>(sd.blob + sd.off_mats);
