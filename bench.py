@@ -74,21 +74,31 @@ def scene_buffers(cfg):
 from toyraygun_amd.roofline import algorithmic_bytes_per_ray  # SURVEY 8(d) figure from the kernel's counters
 
 
-def _oracle_leg(O, scene, name, w, h, spp, bounces, full_spp, threads):
+def _oracle_leg(O, scene, name, w, h, spp, bounces, full_spp, threads, tuned=False):
     t0 = time.perf_counter()
-    _, st = O.render(scene, w, h, spp, bounces, nthreads=threads)
+    _, st = O.render(scene, w, h, spp, bounces, nthreads=threads, tuned=tuned)
     dt = time.perf_counter() - t0
-    return {"config": name, "value": st.rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "rays": int(st.rays), "seconds": round(dt, 3),
+    return {"config": name, "build": "tuned" if tuned else "checker", "value": st.rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "rays": int(st.rays), "seconds": round(dt, 3),
             "sample": "%dx%d, %d of %d spp, %d bounces" % (w, h, spp, full_spp, bounces),
             "extrapolation": "x%g in spp to the full configuration (cost is linear in spp: frames are independent)" % (full_spp / spp),
             "full_config_seconds_estimate": round(dt * full_spp / spp, 2)}
 
 
+CPU_BUILDS = {
+    "checker": "oracle/liboracle.so: gcc -O2 -ffp-contract=off (no -march), brute force over the 36 triangles of the Cornell box, its own median-split BVH on the lattice "
+               "-- the bit-exact checker of the parity tests, timed as it is",
+    "tuned": "oracle/liboracle_tuned.so: the same source at gcc -O3 -march=x86-64-v3 -ffp-contract=fast (contraction allowed), Halton with compile-time bases, walking "
+             "THE PRODUCT'S BVH2 (trg_debug_build_bvh, host-only) on every scene -- BASELINE.md section 3's baseline; validated against the checker in tests/test_oracle.py",
+}
+
+
 def cpu_baseline(config_name):
-    """The CPU oracle (project restatement of the Metal semantics; OpenMP over row bands; brute force over the 36
-    triangles of the Cornell box, its own BVH on the lattice) on the GPU box's host cores.  Headline leg = the benched
-    configuration on all cores; the other legs are the bounded samples SURVEY 8(d) / BASELINE.md ask for."""
+    """The CPU oracle (project restatement of the Metal semantics; OpenMP over row bands) on the GPU box's host cores, in two builds of
+    the same source (CPU_BUILDS): the bit-exact CHECKER as it is, and the TUNED build BASELINE.md section 3 plans (-O3, the same BVH as
+    the HIP path).  Headline = the tuned build on the benched configuration on all cores; the other legs are the bounded samples
+    SURVEY 8(d) / BASELINE.md ask for, with the extrapolation factor stated."""
     from oracle import pyoracle as O
+    from toyraygun_amd import capi
     box = O.OracleScene.cornell_box()
     # the GPU box gives one GPU a CPU share of 16 cores even though it shows more hardware threads
     threads = max(1, min(O.num_threads(), len(os.sched_getaffinity(0)), 16))
@@ -97,17 +107,35 @@ def cpu_baseline(config_name):
     if config_name == "c4" or not os.environ.get("TRG_BENCH_FEW_CPU_LEGS"):
         lattice = O.OracleScene.cornell_lattice(44)
         O.render(lattice, 16, 16, 1, 1, nthreads=threads)   # builds the oracle's BVH (not part of the timed sample)
-    legs.append(_oracle_leg(O, box, "C1", 256, 256, 1, 1, 1, 1))
-    legs.append(_oracle_leg(O, box, "C2", 1920, 1080, 16, 3, 16, threads))
-    legs.append(_oracle_leg(O, box, "C2", 1920, 1080, 1, 3, 16, 1))
-    legs.append(_oracle_leg(O, box, "C3", 1920, 1080, 2, 8, 256, threads))
-    if lattice is not None:
-        legs.append(_oracle_leg(O, lattice, "C4", 1920, 1080, 1, 3, 16, threads))
-    legs.append(_oracle_leg(O, box, "C5", 3840, 2160, 1, 3, 64, threads))
+
+    def run_legs(tuned):
+        legs.append(_oracle_leg(O, box, "C1", 256, 256, 1, 1, 1, 1, tuned))
+        legs.append(_oracle_leg(O, box, "C2", 1920, 1080, 16, 3, 16, threads, tuned))
+        legs.append(_oracle_leg(O, box, "C2", 1920, 1080, 1, 3, 16, 1, tuned))
+        legs.append(_oracle_leg(O, box, "C3", 1920, 1080, 2, 8, 256, threads, tuned))
+        if lattice is not None:
+            legs.append(_oracle_leg(O, lattice, "C4", 1920, 1080, 1, 3, 16, threads, tuned))
+        legs.append(_oracle_leg(O, box, "C5", 3840, 2160, 1, 3, 64, threads, tuned))
+    run_legs(False)
+    # the tuned build walks the product's BVH (host build, no GPU involved); handed to the oracle's scenes for these legs only
+    for sc in (box, lattice):
+        if sc is not None:
+            b = sc.buffers()
+            nodes, tris, _ = capi.debug_build_bvh(b["positions"], b["indices"], b["material_ids"])
+            O.set_bvh(sc, nodes, tris)
+    try:
+        run_legs(True)
+    finally:
+        for sc in (box, lattice):
+            if sc is not None:
+                O.set_bvh(sc)
     want = config_name.upper()
-    head = next(l for l in legs if l["config"] == want and l["cores"] == threads)
-    return {"value": head["value"], "unit": "Mrays/s", "cores": threads, "kind": "port",
+    head = next(l for l in legs if l["config"] == want and l["cores"] == threads and l["build"] == "tuned")
+    chk = next(l for l in legs if l["config"] == want and l["cores"] == threads and l["build"] == "checker")
+    return {"value": head["value"], "unit": "Mrays/s", "cores": threads, "kind": "port", "build": "tuned",
             "sample": "%s: %s, %d rays in %.1f s; %s" % (head["config"], head["sample"], head["rays"], head["seconds"], head["extrapolation"]),
+            "checker_value": chk["value"],
+            "builds": CPU_BUILDS,
             "note": "project CPU restatement of ToyRaygun's Metal semantics (oracle/trg_oracle.c), never a reference CPU path: the reference has none",
             "legs": legs}
 

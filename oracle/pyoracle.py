@@ -40,6 +40,7 @@ class Scene(C.Structure):
         ("accel", C.c_void_p),
         ("uvs", C.POINTER(C.c_float)), ("tex_ids", C.POINTER(C.c_uint32)), ("tex_table", C.POINTER(C.c_uint32)),
         ("texels", C.POINTER(C.c_uint32)), ("ntextures", C.c_uint32),
+        ("xnodes", C.POINTER(C.c_float)), ("xtris", C.POINTER(C.c_float)), ("xn_nodes", C.c_uint32), ("xn_recs", C.c_uint32),
     ]
 
 
@@ -62,12 +63,47 @@ EYE = (0.0, 1.0, 3.38)   # src/main.cpp:85
 AT = (0.0, 1.0, -1.0)    # src/main.cpp:86
 
 
-def build(force=False):
-    so = os.path.join(_HERE, "liboracle.so")
+def build(force=False, tuned=False):
+    """liboracle.so (the checker: -O2, no contraction) or, tuned=True, liboracle_tuned.so -- the same source at -O3 -march=x86-64-v3 with
+    contraction, what bench.py's `tuned` CPU-baseline leg times (oracle/Makefile)."""
+    name = "liboracle_tuned.so" if tuned else "liboracle.so"
+    so = os.path.join(_HERE, name)
     src = [os.path.join(_HERE, f) for f in ("trg_oracle.c", "trg_oracle.h", "Makefile")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, "-B", name], stdout=subprocess.DEVNULL)
     return so
+
+
+_LIB_TUNED = None
+
+
+def tuned_lib():
+    """The tuned build, bound for what the CPU-baseline leg needs: orc_render on a scene of the default library (same source, same
+    structures) and orc_scene_set_bvh."""
+    global _LIB_TUNED
+    if _LIB_TUNED is None:
+        lib()
+        L = C.CDLL(build(tuned=True))
+        L.orc_render.argtypes = [C.POINTER(Scene), C.POINTER(Uniforms), C.c_void_p, C.c_uint32, C.c_uint32,
+                                 C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(Stats), C.c_int]
+        L.orc_render.restype = C.c_int
+        L.orc_intersect_nearest.argtypes = [C.POINTER(Scene), C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(Stats)]
+        L.orc_intersect_any.argtypes = [C.POINTER(Scene), C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(Stats)]
+        L.orc_num_threads.restype = C.c_int
+        _LIB_TUNED = L
+    return _LIB_TUNED
+
+
+def set_bvh(scene, nodes=None, tris=None):
+    """orc_scene_set_bvh: walk this BVH2 (toyraygun_amd.capi.debug_build_bvh's arrays: nodes [n,16], records [m,12]) instead of brute force /
+    the oracle's own tree; None removes it."""
+    L = lib()
+    if nodes is None:
+        L.orc_scene_set_bvh(scene.p, None, 0, None, 0)
+        return
+    nodes = np.ascontiguousarray(nodes, np.float32).reshape(-1, 16)
+    tris = np.ascontiguousarray(tris, np.float32).reshape(-1, 12)
+    L.orc_scene_set_bvh(scene.p, _fp(nodes), nodes.shape[0], _fp(tris), tris.shape[0])
 
 
 def lib():
@@ -112,6 +148,7 @@ def lib():
         L.orc_render.restype = C.c_int
         L.orc_postprocess.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int]
         L.orc_set_trig_mode.argtypes = [C.c_int]
+        L.orc_scene_set_bvh.argtypes = [C.POINTER(Scene), fp, C.c_uint32, fp, C.c_uint32]
         L.orc_num_threads.restype = C.c_int
         _LIB = L
     return _LIB
@@ -229,9 +266,9 @@ def halton(i, d):
 
 
 def render(scene, w, h, spp, bounces, frame_begin=0, row0=0, rows=None, accum=None, offsets=None,
-           uniforms=None, nthreads=0, want_stats=True):
-    """Render frames [frame_begin, frame_begin+spp) -> (accum[h,w,4] float32, Stats)."""
-    L = lib()
+           uniforms=None, nthreads=0, want_stats=True, tuned=False):
+    """Render frames [frame_begin, frame_begin+spp) -> (accum[h,w,4] float32, Stats).  tuned=True: the -O3 build (CPU baseline only)."""
+    L = tuned_lib() if tuned else lib()
     rows = h - row0 if rows is None else rows
     u = uniforms if uniforms is not None else make_uniforms(w, h)
     off = offsets if offsets is not None else pixel_offsets(w, h)

@@ -198,6 +198,7 @@ void orc_scene_free(orc_scene *s)
     free(s->positions); free(s->normals); free(s->colors); free(s->indices); free(s->material_ids);
     free(s->uvs); free(s->tex_ids); free(s->tex_table); free(s->texels);
     accel_free(s->accel);
+    free(s->xnodes); free(s->xtris);
     free(s);
 }
 /* Albedo textures: the project's definition (the reference has none).  Copies everything; ntextures = 0 removes them. */
@@ -437,8 +438,87 @@ static const uint32_t k_primes[ORC_HALTON_DIMS] = {
     227, 229, 233, 239, 241, 251, 257, 263, 269, 271, 277, 281, 283, 293, 307, 311,
 };
 uint32_t orc_halton_prime(uint32_t d) { return k_primes[d % ORC_HALTON_DIMS]; }
+#ifdef ORC_TUNED
+/* the tuned build (bench.py's CPU-baseline leg only): the SAME recurrence with the base as a compile-time constant per dimension, so that
+ * i % b and i / b become a multiply and a shift -- identical integers, identical floats, about five times faster */
+static inline __attribute__((always_inline)) float halton_const_base(uint32_t i, const uint32_t b)
+{
+    float f = 1.0f, invB = 1.0f / b, r = 0;
+    while (i > 0) { f = f * invB; r = r + f * (i % b); i = i / b; }
+    return r;
+}
+#endif
 float orc_halton(uint32_t i, uint32_t d)
 {
+#ifdef ORC_TUNED
+    switch (d) {
+    case 0: return halton_const_base(i, 2u);
+    case 1: return halton_const_base(i, 3u);
+    case 2: return halton_const_base(i, 5u);
+    case 3: return halton_const_base(i, 7u);
+    case 4: return halton_const_base(i, 11u);
+    case 5: return halton_const_base(i, 13u);
+    case 6: return halton_const_base(i, 17u);
+    case 7: return halton_const_base(i, 19u);
+    case 8: return halton_const_base(i, 23u);
+    case 9: return halton_const_base(i, 29u);
+    case 10: return halton_const_base(i, 31u);
+    case 11: return halton_const_base(i, 37u);
+    case 12: return halton_const_base(i, 41u);
+    case 13: return halton_const_base(i, 43u);
+    case 14: return halton_const_base(i, 47u);
+    case 15: return halton_const_base(i, 53u);
+    case 16: return halton_const_base(i, 59u);
+    case 17: return halton_const_base(i, 61u);
+    case 18: return halton_const_base(i, 67u);
+    case 19: return halton_const_base(i, 71u);
+    case 20: return halton_const_base(i, 73u);
+    case 21: return halton_const_base(i, 79u);
+    case 22: return halton_const_base(i, 83u);
+    case 23: return halton_const_base(i, 89u);
+    case 24: return halton_const_base(i, 97u);
+    case 25: return halton_const_base(i, 101u);
+    case 26: return halton_const_base(i, 103u);
+    case 27: return halton_const_base(i, 107u);
+    case 28: return halton_const_base(i, 109u);
+    case 29: return halton_const_base(i, 113u);
+    case 30: return halton_const_base(i, 127u);
+    case 31: return halton_const_base(i, 131u);
+    case 32: return halton_const_base(i, 137u);
+    case 33: return halton_const_base(i, 139u);
+    case 34: return halton_const_base(i, 149u);
+    case 35: return halton_const_base(i, 151u);
+    case 36: return halton_const_base(i, 157u);
+    case 37: return halton_const_base(i, 163u);
+    case 38: return halton_const_base(i, 167u);
+    case 39: return halton_const_base(i, 173u);
+    case 40: return halton_const_base(i, 179u);
+    case 41: return halton_const_base(i, 181u);
+    case 42: return halton_const_base(i, 191u);
+    case 43: return halton_const_base(i, 193u);
+    case 44: return halton_const_base(i, 197u);
+    case 45: return halton_const_base(i, 199u);
+    case 46: return halton_const_base(i, 211u);
+    case 47: return halton_const_base(i, 223u);
+    case 48: return halton_const_base(i, 227u);
+    case 49: return halton_const_base(i, 229u);
+    case 50: return halton_const_base(i, 233u);
+    case 51: return halton_const_base(i, 239u);
+    case 52: return halton_const_base(i, 241u);
+    case 53: return halton_const_base(i, 251u);
+    case 54: return halton_const_base(i, 257u);
+    case 55: return halton_const_base(i, 263u);
+    case 56: return halton_const_base(i, 269u);
+    case 57: return halton_const_base(i, 271u);
+    case 58: return halton_const_base(i, 277u);
+    case 59: return halton_const_base(i, 281u);
+    case 60: return halton_const_base(i, 283u);
+    case 61: return halton_const_base(i, 293u);
+    case 62: return halton_const_base(i, 307u);
+    case 63: return halton_const_base(i, 311u);
+    default: break;
+    }
+#endif
     /* common.h:51-75 */
     uint32_t b = k_primes[d];
     float f = 1.0f;
@@ -895,15 +975,100 @@ static float any_bvh_one(const orc_scene *s, const oaccel *A, const orc_ray *r, 
     }
     return -1.0f;
 }
+/* ---- an acceleration structure from outside (orc_scene_set_bvh): the product's BVH2, near child first, the far one on a stack ---- */
+void orc_scene_set_bvh(orc_scene *s, const float *nodes16, uint32_t n_nodes, const float *tris12, uint32_t n_recs)
+{
+    free(s->xnodes); free(s->xtris);
+    s->xnodes = NULL; s->xtris = NULL; s->xn_nodes = 0; s->xn_recs = 0;
+    if (!n_nodes || !nodes16 || !tris12) return;
+    s->xnodes = (float *)malloc(sizeof(float) * 16 * (size_t)n_nodes);
+    s->xtris = (float *)malloc(sizeof(float) * 12 * (size_t)n_recs);
+    memcpy(s->xnodes, nodes16, sizeof(float) * 16 * (size_t)n_nodes);
+    memcpy(s->xtris, tris12, sizeof(float) * 12 * (size_t)n_recs);
+    s->xn_nodes = n_nodes; s->xn_recs = n_recs;
+}
+static inline float slab_entry(const float *n, int child, const float o[3], const float inv[3], float tmax, int *hit)
+{
+    /* child 0: x (n0,n1) y (n2,n3) z (n8,n9); child 1: x (n4,n5) y (n6,n7) z (n10,n11) */
+    const float lo[3] = { n[child * 4 + 0], n[child * 4 + 2], n[8 + child * 2] }, hi[3] = { n[child * 4 + 1], n[child * 4 + 3], n[9 + child * 2] };
+    float t0 = 0.0f, t1 = tmax;
+    for (int a = 0; a < 3; ++a) {   /* (comparisons instead of fminf / fmaxf calls: the reciprocals are finite -- clamped away from zero -- so no NaN arises) */
+        const float ta = (lo[a] - o[a]) * inv[a], tb = (hi[a] - o[a]) * inv[a];
+        const float tn = ta < tb ? ta : tb, tf = ta < tb ? tb : ta;
+        t0 = tn > t0 ? tn : t0; t1 = tf < t1 ? tf : t1;
+    }
+    *hit = t0 <= t1 * 1.00001f + 1e-6f;   /* the product pads its boxes; the slack keeps this walk conservative whatever the contraction */
+    return t0;
+}
+/* any != 0: first hit ends the walk.  Returns 1 when something was hit (out filled for the nearest query). */
+static int ext_walk_one(const orc_scene *s, const orc_ray *r, int any, orc_isect *out, orc_stats *st)
+{
+    if (out) { out->distance = -1.0f; out->primitiveIndex = -1; out->coordinates[0] = 0.0f; out->coordinates[1] = 0.0f; }
+    if (r->maxDistance < 0.0f) return 0;
+    float inv[3];
+    for (int a = 0; a < 3; ++a) {
+        float d = r->direction[a];
+        if (fabsf(d) < 1e-30f) d = copysignf(1e-30f, d);
+        inv[a] = 1.0f / d;
+    }
+    float best = r->maxDistance; int found = 0; int32_t best_k = -1;
+    int32_t stack[128]; int sp = 0;
+    int32_t node = 0;
+    for (;;) {
+        if (node >= 0) {
+            const float *n = &s->xnodes[(size_t)node * 16];
+            if (st) st->node_visits++;
+            int h0, h1;
+            const float t0 = slab_entry(n, 0, r->origin, inv, best, &h0), t1 = slab_entry(n, 1, r->origin, inv, best, &h1);
+            int32_t c0, c1; memcpy(&c0, &n[12], 4); memcpy(&c1, &n[13], 4);
+            if (h0 && h1) {
+                const int first1 = t1 < t0;
+                stack[sp++] = first1 ? c0 : c1;
+                node = first1 ? c1 : c0;
+                continue;
+            }
+            if (h0) { node = c0; continue; }
+            if (h1) { node = c1; continue; }
+        } else {
+            const uint32_t code = ~(uint32_t)node, first = code >> 3, count = (code & 7u) + 1u;
+            for (uint32_t i = 0; i < count; ++i) {
+                const float *rec = &s->xtris[(size_t)(first + i) * 12];
+                uint32_t k, mask; memcpy(&k, &rec[3], 4); memcpy(&mask, &rec[7], 4);
+                if ((r->mask & mask) == 0) continue;
+                float t, u, v;
+                if (st) st->tri_tests++;
+                if (!tri_test(r->origin, r->direction, &rec[0], &rec[4], &rec[8], &t, &u, &v)) continue;
+                if (!(t >= 0.0f && t <= r->maxDistance)) continue;
+                if (any) return 1;
+                if (!found || t < best || (t == best && (int32_t)k < best_k)) {
+                    found = 1; best = t; best_k = (int32_t)k;
+                    out->distance = t; out->primitiveIndex = (int32_t)k;
+                    out->coordinates[0] = 1.0f - u - v; out->coordinates[1] = u;
+                }
+            }
+        }
+        if (!sp) break;
+        node = stack[--sp];
+    }
+    return found;
+}
+
+#ifndef ORC_BRUTE_MAX_TRIS
 #define ORC_BRUTE_MAX_TRIS 256u
+#endif
 void orc_intersect_nearest(orc_scene *s, const orc_ray *rays, size_t n, orc_isect *out, orc_stats *st)
 {
+    if (s->xn_nodes) { for (size_t i = 0; i < n; ++i) ext_walk_one(s, &rays[i], 0, &out[i], st); return; }
     if (s->ntris <= ORC_BRUTE_MAX_TRIS) { for (size_t i = 0; i < n; ++i) nearest_brute_one(s, &rays[i], &out[i], st); return; }
     const oaccel *A = accel_get(s);
     for (size_t i = 0; i < n; ++i) nearest_bvh_one(s, A, &rays[i], &out[i], st);
 }
 void orc_intersect_any(orc_scene *s, const orc_ray *rays, size_t n, float *out, orc_stats *st)
 {
+    if (s->xn_nodes) {   /* (the distance of an any-hit query is never read: -1 = unoccluded, anything else = occluded) */
+        for (size_t i = 0; i < n; ++i) out[i] = ext_walk_one(s, &rays[i], 1, NULL, st) ? 0.0f : -1.0f;
+        return;
+    }
     if (s->ntris <= ORC_BRUTE_MAX_TRIS) { for (size_t i = 0; i < n; ++i) out[i] = any_brute_one(s, &rays[i], st); return; }
     const oaccel *A = accel_get(s);
     for (size_t i = 0; i < n; ++i) out[i] = any_bvh_one(s, A, &rays[i], st);
@@ -1016,7 +1181,7 @@ int orc_render(orc_scene *s, const orc_uniforms *u_base, const uint32_t *offsets
                uint32_t frame_begin, uint32_t spp, uint32_t bounces,
                uint32_t row0, uint32_t rows, float *accum, orc_stats *st, int nthreads)
 {
-    if (s->ntris > ORC_BRUTE_MAX_TRIS) accel_get(s); /* build outside the parallel region */
+    if (!s->xn_nodes && s->ntris > ORC_BRUTE_MAX_TRIS) accel_get(s); /* build outside the parallel region */
     const uint32_t band = 8;
     const uint32_t nb = (rows + band - 1) / band;
     orc_stats total; memset(&total, 0, sizeof(total));

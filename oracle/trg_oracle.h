@@ -74,7 +74,16 @@ typedef struct orc_scene {
     uint32_t *tex_table;  /* per texture: first texel, width, height, 0 */
     uint32_t *texels;     /* RGBA8, all textures back to back */
     uint32_t ntextures;
+    /* an acceleration structure handed in from outside (orc_scene_set_bvh: bench.py's tuned CPU-baseline leg walks THE PRODUCT'S BVH2, as
+     * BASELINE.md section 3 plans -- "the same BVH"): nodes of 16 floats (ax0 ax1 ay0 ay1 | bx0 bx1 by0 by1 | az0 az1 bz0 bz1 | child0
+     * child1 - -; a child < 0 is the leaf code ~((first << 3) | (count - 1))), records of 12 floats (v0 | original index, e1 | mask, e2 | 0) */
+    float *xnodes, *xtris;
+    uint32_t xn_nodes, xn_recs;
 } orc_scene;
+/* copies the arrays (what toyraygun_amd.capi.debug_build_bvh returns); n_nodes = 0 removes them.  While set, orc_intersect_* and orc_render
+ * walk this tree instead of brute force / the oracle's own median-split tree: same hits (the triangle arithmetic is tri_test's on the
+ * same fp32 v0 / e1 / e2, ties to the lower original index). */
+void orc_scene_set_bvh(orc_scene *s, const float *nodes16, uint32_t n_nodes, const float *tris12, uint32_t n_recs);
 
 typedef struct orc_stats {
     uint64_t primary_rays;   /* raygen rays (one per pixel-sample)              */

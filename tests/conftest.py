@@ -11,6 +11,17 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950); run with -m gpu on the GPU box")
+    config.addinivalue_line("markers", "slow: minutes of oracle time (whole-frame parity of the full-size configurations); opt in with -m \"gpu and slow\" or TRG_RUN_SLOW=1")
+
+
+def pytest_collection_modifyitems(config, items):
+    # slow tests run only when asked for by name: `-m "gpu and slow"` (or TRG_RUN_SLOW=1) -- a plain `-m gpu` stays a one-minute suite
+    if "slow" in (config.getoption("-m") or "") or os.environ.get("TRG_RUN_SLOW"):
+        return
+    skip = pytest.mark.skip(reason="slow: run with -m \"gpu and slow\" or TRG_RUN_SLOW=1")
+    for item in items:
+        if "slow" in item.keywords:
+            item.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

@@ -292,3 +292,46 @@ def test_postprocess(O):
     assert [int(v) for v in out[0, 0, :3]] == [ref(0), ref(0.18), ref(1.0)] and out[0, 0, 3] == 255
     assert [int(v) for v in out[1, 2, :3]] == [ref(10.0), ref(0.001), ref(0.5)]
     assert np.array_equal(O.postprocess(acc, flip_y=True), out[::-1])
+
+
+def test_tuned_cpu_baseline_build_agrees_with_the_checker(O, cornell, built):
+    """bench.py's `tuned` CPU-baseline leg is a second build of the SAME source (oracle/Makefile liboracle_tuned.so: -O3
+    -march=x86-64-v3, contraction allowed, constant-base Halton) that walks THE PRODUCT'S BVH2 (trg_debug_build_bvh, host-only) on every
+    scene.  It is never the checker -- it is checked: (1) the checker build walking the product's tree gives the checker's own frame BIT
+    FOR BIT with the same ray counts (the tree changes which triangles are tested, not what a test returns; ties go to the lower index
+    either way), Cornell box and a 2,628-triangle lattice; (2) the tuned build stays within the shipped build's tolerance of it and
+    counts the same rays within 1e-4; (3) its constant-base Halton is the reference recurrence up to the contraction of r + f * digit."""
+    from toyraygun_amd import capi
+    from tests.util import TOL_FRAC, TOL_RMSE, image_metrics
+    for scene, (w, h, spp, bnc) in ((cornell, (160, 120, 3, 3)), (O.OracleScene.cornell_lattice(6), (96, 64, 2, 3))):
+        ref, rst = O.render(scene, w, h, spp, bnc)
+        b = scene.buffers()
+        nodes, tris, _ = capi.debug_build_bvh(b["positions"], b["indices"], b["material_ids"])
+        O.set_bvh(scene, nodes, tris)
+        try:
+            got, st = O.render(scene, w, h, spp, bnc)
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)) and st.rays == rst.rays and st.shaded_hits == rst.shaded_hits
+            assert st.node_visits > 0 and st.tri_tests < rst.tri_tests      # it really walked the tree
+            rays = np.zeros(4000, O.RAY_DTYPE)
+            rng = np.random.default_rng(9)
+            rays["origin"] = rng.uniform((-0.9, 0.1, -0.9), (0.9, 1.9, 2.5), (4000, 3)).astype(np.float32)
+            d = rng.normal(size=(4000, 3)); rays["direction"] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+            rays["mask"] = rng.choice([1, 2, 3], 4000).astype(np.uint32); rays["maxDistance"] = np.inf
+            walked, walked_any = O.intersect_nearest(scene, rays), O.intersect_any(scene, rays)
+            O.set_bvh(scene)
+            assert np.array_equal(walked.view(np.uint8), O.intersect_nearest(scene, rays, brute=True).view(np.uint8))
+            assert np.array_equal(walked_any >= 0, O.intersect_any(scene, rays, brute=True) >= 0)
+            O.set_bvh(scene, nodes, tris)
+            tun, tst = O.render(scene, w, h, spp, bnc, tuned=True)
+            rmse, frac_ok, worst = image_metrics(tun, ref)
+            assert rmse <= TOL_RMSE and frac_ok >= TOL_FRAC, (rmse, frac_ok, worst)
+            assert tst.primary_rays == rst.primary_rays and abs(tst.rays - rst.rays) <= 1e-4 * rst.rays
+        finally:
+            O.set_bvh(scene)
+    T = O.tuned_lib()
+    import ctypes as C
+    T.orc_halton.argtypes = [C.c_uint32, C.c_uint32]; T.orc_halton.restype = C.c_float
+    for d in range(64):
+        for i in (0, 1, 2, 17, 12345, 2 ** 24 - 1, 2 ** 24 + 1, 2 ** 31 + 7, 2 ** 32 - 1):
+            a, b = float(T.orc_halton(i, d)), float(O.halton(i, d))      # (contraction: r + f * digit is one fma in the tuned build)
+            assert abs(a - b) <= 2.5e-7 * max(b, 1e-3), (i, d, a, b)
