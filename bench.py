@@ -49,7 +49,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 LDS_PEAK_GBS = 150000.0     # aggregate ds_read_b64/b128 rate with every CU streaming (MI355X_MICROARCH.md, LDS)
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0  # wave-level VALU instructions per ns: 1024 SIMDs, 2 cycles per wave64 instruction, 2.4 GHz
-PROFILE_ROUNDS = ("r03", "r02")   # newest first: the first counters file whose kernel-source hash matches this tree is used
+PROFILE_ROUNDS = ("r04", "r03", "r02")   # newest first: the first counters file whose kernel-source hash matches this tree is used
 
 CONFIGS = {
     "c2": dict(w=1920, h=1080, spp=16, bounces=3, scene="cornell",
@@ -58,6 +58,9 @@ CONFIGS = {
                workload="Cornell box (36 triangles) 1920x1080, 256 spp, 8 bounces (BASELINE configs[2], deep-bounce divergence stress)"),
     "c4": dict(w=1920, h=1080, spp=16, bounces=3, scene="lattice44",
                workload="Cornell box + 44x44x44 replicated cubes = 1,022,244 triangles, 1920x1080, 16 spp, 3 bounces (BASELINE configs[3], BVH/HBM stress)"),
+    "c4xl": dict(w=1920, h=1080, spp=16, bounces=3, scene="lattice96",
+                 workload="Cornell box + 96x96x96 replicated cubes = 10,616,868 triangles (2.9 GB on the device: beyond the 256 MiB Infinity Cache), 1920x1080, 16 spp, 3 bounces "
+                          "(not a BASELINE configuration: the leg where memory-side traffic is DRAM traffic)"),
     "c5": dict(w=3840, h=2160, spp=64, bounces=3, scene="cornell",
                workload="Cornell box (36 triangles) 3840x2160, 64 spp, 3 bounces (BASELINE configs[4]; row bands over the GPUs)"),
 }
@@ -67,7 +70,7 @@ SECONDARY = (("c4", 5, 1), ("c3", 3, 1))   # (config, steps, warmup) timed after
 def scene_buffers(cfg):
     """Scene + uniforms from the PRODUCT's host library (libtoyraygun.so), not from the oracle."""
     from toyraygun_amd import host
-    sc = host.Scene.cornell_lattice(44) if cfg["scene"] == "lattice44" else host.Scene.cornell_box()
+    sc = host.Scene.cornell_lattice(int(cfg["scene"][7:])) if cfg["scene"].startswith("lattice") else host.Scene.cornell_box()
     return sc.buffers(), host.uniforms(cfg["w"], cfg["h"])[0]
 
 
@@ -104,7 +107,7 @@ def cpu_baseline(config_name):
     threads = max(1, min(O.num_threads(), len(os.sched_getaffinity(0)), 16))
     legs = []
     lattice = None
-    if config_name == "c4" or not os.environ.get("TRG_BENCH_FEW_CPU_LEGS"):
+    if config_name in ("c4", "c4xl") or not os.environ.get("TRG_BENCH_FEW_CPU_LEGS"):
         lattice = O.OracleScene.cornell_lattice(44)
         O.render(lattice, 16, 16, 1, 1, nthreads=threads)   # builds the oracle's BVH (not part of the timed sample)
 
@@ -129,7 +132,7 @@ def cpu_baseline(config_name):
         for sc in (box, lattice):
             if sc is not None:
                 O.set_bvh(sc)
-    want = config_name.upper()
+    want = "C4" if config_name == "c4xl" else config_name.upper()   # (c4xl has no CPU leg of its own: the C4 sample stands beside it)
     head = next(l for l in legs if l["config"] == want and l["cores"] == threads and l["build"] == "tuned")
     chk = next(l for l in legs if l["config"] == want and l["cores"] == threads and l["build"] == "checker")
     return {"value": head["value"], "unit": "Mrays/s", "cores": threads, "kind": "port", "build": "tuned",
@@ -245,7 +248,11 @@ def run_torch(config_name, steps, warmup, env, use_imported=True):
     # images, so the next steps fill the CUs that the tail of step k leaves idle (or that a small row band never fills),
     # and the gather of k overlaps the renders that follow
     r = DistributedRenderer(W, H, local_rank, pipelined=not os.environ.get("TRG_BENCH_SERIAL"))
+    if os.environ.get("TRG_BENCH_GPU_BUILD"):   # 1 = device binned SAH, 2 = LBVH, 3 = PLOC (default: the host SAH builder)
+        r.ctx.set_option(capi.OPT_GPU_BUILD, int(os.environ["TRG_BENCH_GPU_BUILD"]))
+    t_load = time.perf_counter()
     r.load_scene(buffers)
+    load_s = time.perf_counter() - t_load
     r.ctx.set_uniforms(uniforms)
     r.ctx.set_pixel_offsets_seed()
     dev = r.device
@@ -331,7 +338,9 @@ def run_torch(config_name, steps, warmup, env, use_imported=True):
                        "pipeline": ("%d frames in flight on alternating streams: later steps fill the CUs the tail of step k leaves idle "
                                     "(roofline.kernel_ms = average launch duration while they overlap; kernel_alone_ms = one launch by itself)" % len(r.render_streams)) if getattr(r, "_overlap", False) else "serial launches",
                        "kernel": kernel_name(st, in_lds),
-                       "triangles": int(len(buffers["material_ids"])), "scene_bytes": int(cst.scene_bytes)},
+                       "triangles": int(len(buffers["material_ids"])), "scene_bytes": int(cst.scene_bytes),
+                       "scene_build": {"builder": {0: "host SAH", 1: "device binned SAH", 2: "device LBVH", 3: "device PLOC"}[int(os.environ.get("TRG_BENCH_GPU_BUILD", "0"))],
+                                       "build_ms": cst.last_build_ms, "load_scene_s": load_s, "bvh_depth4": int(cst.bvh_depth4), "nodes4": int(cst.bvh_nodes4)}},
             "roofline": rf,
         }
     r.close()

@@ -113,7 +113,13 @@ enum trg_option {
                                  over the 8 XCDs, each with a private 4 MiB L2) own one of n column strips x 8/n row bands of the screen and walk
                                  it away from the image centre, so that an L2 serves the rays of one screen region (C4: 37 % less memory-side
                                  traffic, L2 hit rate 81 -> 86 %, but 14 % MORE time: the regions differ in cost and the dispatcher deals the
-                                 XCDs their workgroups strictly in turn); -1 (default): image columns */
+                                 XCDs their workgroups strictly in turn); 17, 18, 20, 24: stripes of 1, 2, 4, 8 tile rows dealt round robin over the
+                                 XCDs and 32: 8 x 8-tile super-blocks with one 2 x 4-tile sub-block per XCD (round 4: balanced by construction, 4-12 %
+                                 less traffic, no faster); 65, 66, 68, 72 = 64 + n: the n x (8 / n) regions dealt through ONE JOB QUEUE PER XCD --
+                                 about as many persistent workgroups as the chip holds, each popping from the queue of the XCD it runs on
+                                 (HW_REG_XCC_ID) and stealing from the others when it is empty (path-regeneration kernel; elsewhere = n): the
+                                 traffic cut of the regions (C4: 50.9 -> 33.8 GB per launch, L2 hit rate 69 -> 77 %) without their imbalance, at
+                                 +1.6 % time on C4 and -1.4 % on the 10.6 M-triangle scene; -1 (default): image columns */
     TRG_OPT_STACK_LDS_LEVELS = 13, /* scenes in HBM: levels of a thread's traversal stack kept in LDS (2..12, default 12; level 0 is the
                                  sentinel); deeper levels live in a per-launch scratch in memory.  Never changes the image: a knob for
                                  testing the scratch path and for trading LDS against it */

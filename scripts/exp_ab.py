@@ -3,7 +3,7 @@ python scripts/exp_ab.py <config: c2|c3|c4|c2b8> <variant|shipped> ...  -> launc
 step with four frames in flight, rays from the in-kernel counters."""
 import os, sys, time, subprocess
 sys.path.insert(0, ".")
-CFG = {"c2": (1920, 1080, 16, 3, "box"), "c3": (1920, 1080, 64, 8, "box"), "c4": (1920, 1080, 16, 3, "lattice"), "c2b8": (1920, 1080, 16, 8, "box"),
+CFG = {"c4xl": (1920, 1080, 16, 3, "lattice96"), "c2": (1920, 1080, 16, 3, "box"), "c3": (1920, 1080, 64, 8, "box"), "c4": (1920, 1080, 16, 3, "lattice"), "c2b8": (1920, 1080, 16, 8, "box"),
        "c2b4": (1920, 1080, 16, 4, "box"), "c2b5": (1920, 1080, 16, 5, "box"), "c2b6": (1920, 1080, 16, 6, "box")}
 if sys.argv[1].startswith("--one="):
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
@@ -14,8 +14,10 @@ if sys.argv[1].startswith("--one="):
     from toyraygun_amd import host
     from toyraygun_amd.dist import DistributedRenderer
     W, H, spp, bn, sc = CFG[cfg]
-    b = (host.Scene.cornell_lattice(44) if sc == "lattice" else host.Scene.cornell_box()).buffers()
+    b = (host.Scene.cornell_lattice(int(sc[7:] or 44)) if sc.startswith("lattice") else host.Scene.cornell_box()).buffers()
     r = DistributedRenderer(W, H, 0, pipelined=True)
+    for k, v in [kv.split("=") for kv in os.environ.get("TRG_EXP_OPTS", "").split(",") if kv]:
+        r.ctx.set_option(int(k), int(v))      # (before the scene too: option 6 picks the builder)
     r.load_scene(b); r.ctx.set_uniforms(host.uniforms(W, H)[0]); r.ctx.set_pixel_offsets_seed()
     for k, v in [kv.split("=") for kv in os.environ.get("TRG_EXP_OPTS", "").split(",") if kv]:
         r.ctx.set_option(int(k), int(v))

@@ -3,6 +3,7 @@
 per-launch counters of the benched megakernel that bench.py imports into its roofline object."""
 import collections
 import csv
+import re
 import glob
 import json
 import subprocess
@@ -26,7 +27,7 @@ for cfg in cfgs:
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if "render" in k and "_kernel<" in k:
+            if "trgk_" in k:
                 agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
         for (k, c), v in agg.items():
             vs = sorted(v)
@@ -53,54 +54,62 @@ for cfg in cfgs:
                                     "overlapped_mean_ms": sum(shared) / max(len(shared), 1), "alone_mean_ms": sum(alone) / max(len(alone), 1),
                                     "pipeline_ms_per_launch": (launches[-1][1] - launches[len(alone)][0]) / 1e6 / max(len(shared), 1) if shared else None}
         print(cfg, "launches alone:", [round(x, 3) for x in alone], "overlapped:", [round(x, 3) for x in shared])
-    # the kernel bench.py times = the one with the most launches
+    # ---- the counters file bench.py imports: EVERY field per bench STEP (one trg_render of the whole configuration), summed over every
+    #      kernel launch the step consists of -- the megakernel alone (C2, C5), regeneration + its fold per 16-frame chunk (C4), head +
+    #      tail levels + fold per chunk (C3).  The counted (`true>`) instantiations of the untimed counters pass and one-off helper kernels
+    #      (offsets, probes) are left out; which kernels went in, and how often per step, is part of the record.
     if counters:
-        kname = max(counters, key=lambda k: max(v["launches"] for v in counters[k].values()))
-        # medians: a launch that overlaps another stream's fill / copy occasionally reports that traffic too (one C2 launch in 15
-        # showed 208 MB of writes beside fourteen at 32.7 MB)
-        c = {n: v["median"] for n, v in counters[kname].items()}
+        import bench   # CONFIGS: spp of the profiled configuration -> chunks per step
+        spp = bench.CONFIGS.get(cfg, {}).get("spp", 16)
+
+        def timed(k):
+            base = k.split("(")[0]
+            if "trgk_" not in base or re.search(r"true>\s*$", base) or re.search(r"(offsets|xcc_probe|halton|raygen|sample|trace|postprocess|unpack_bands)_kernel", base):
+                return False
+            return True
+        tk = {k: v for k, v in counters.items() if timed(k)}
+        launches = lambda k: max(v["launches"] for v in tk[k].values())
+        lead = [k for k in tk if "render_head_kernel" in k] or [k for k in tk if "render_regen_kernel" in k]
+        if lead:
+            chunks_per_step = -(-spp // 16)            # head / regeneration launches run one 16-frame chunk each (trg_capi.cpp kTailChunkFrames)
+            steps = launches(lead[0]) / chunks_per_step
+        else:
+            lead = [max((k for k in tk if "render_" in k), key=launches)]
+            chunks_per_step = 1
+            steps = float(launches(lead[0]))
+        tot = collections.defaultdict(float)
+        for k, cs in tk.items():
+            for n, v in cs.items():
+                tot[n] += v["mean"] * v["launches"]
+        per_step = {n: v / steps for n, v in tot.items()}
+        c = per_step
         # FETCH_SIZE: rocprofv3 reports KiB and, on gfx950, tallies every 128-byte memory-side read request at 64 bytes
         # (TCC_BUBBLE reads 0): profiles/r02/fetch_calibration.md -- x2 for every access shape.  WRITE_SIZE is exact.
         fetch_raw = c.get("FETCH_SIZE", 0.0) * 1024.0
         fetch = 2.0 * fetch_raw
         write = c.get("WRITE_SIZE", 0.0) * 1024.0
         dram32 = c.get("TCC_EA0_RDREQ_DRAM_32B_sum")
-        rec = {"kernel": kname, "commit": commit, "kernel_source_hash": kernel_source_hash(),
+        rec = {"unit": "EVERY counter below is per bench step (one trg_render of the whole configuration): the sum over the kernels listed in `kernels`",
+               "kernel": " + ".join(sorted(k.split("(")[0].replace("void ", "").replace("trgk_fast::", "") for k in tk)),
+               "kernels": {k.split("(")[0].replace("void ", "").replace("trgk_fast::", ""): {"launches_per_step": launches(k) / steps, "launches_profiled": launches(k),
+                           "valu_insts_per_launch": tk[k].get("SQ_INSTS_VALU", {}).get("median"),
+                           "lanes_active_per_valu_inst": (tk[k]["SQ_THREAD_CYCLES_VALU"]["median"] / tk[k]["SQ_INSTS_VALU"]["median"]) if "SQ_THREAD_CYCLES_VALU" in tk[k] and tk[k].get("SQ_INSTS_VALU", {}).get("median") else None}
+                           for k in tk},
+               "steps_profiled": steps, "chunks_per_step": chunks_per_step,
+               "commit": commit, "kernel_source_hash": kernel_source_hash(),
                "valu_insts_per_launch": c.get("SQ_INSTS_VALU"), "salu_insts_per_launch": c.get("SQ_INSTS_SALU"), "lds_insts_per_launch": c.get("SQ_INSTS_LDS"),
                "lanes_active_per_valu_inst": (c["SQ_THREAD_CYCLES_VALU"] / c["SQ_INSTS_VALU"]) if c.get("SQ_THREAD_CYCLES_VALU") and c.get("SQ_INSTS_VALU") else None,
                "fetch_bytes": fetch, "fetch_size_raw_bytes": fetch_raw, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
                "rdreq_dram_32b_bytes": (dram32 * 32.0) if dram32 else None,
-               "wave_cycles": c.get("SQ_WAVE_CYCLES"), "wait_any_cycles": c.get("SQ_WAIT_ANY"), "busy_cycles": c.get("SQ_BUSY_CYCLES"),
+               "wave_cycles": c.get("SQ_WAVE_CYCLES"), "wait_any_cycles": c.get("SQ_WAIT_ANY"), "wait_inst_any_cycles": c.get("SQ_WAIT_INST_ANY"), "busy_cycles": c.get("SQ_BUSY_CYCLES"),
                "lds_idx_active": c.get("SQ_LDS_IDX_ACTIVE"), "lds_bank_conflict": c.get("SQ_LDS_BANK_CONFLICT"),
                "tcc_hit": c.get("TCC_HIT_sum"), "tcc_miss": c.get("TCC_MISS_sum"), "ta_busy_avr": c.get("TA_BUSY_avr"), "gui_active": c.get("GRBM_GUI_ACTIVE"),
                "alone_mean_ms": summary[cfg].get("launches", {}).get("alone_mean_ms"),
-               "source": "scripts/profile_round.sh at commit %s: one rocprofv3 --pmc pass per counter group of `python3 bench.py%s`, per-launch means; "
+               "note": "`*_per_launch` keeps its name for bench.py: a launch IS a step here (for C2 / C5 literally one kernel launch)",
+               "source": "scripts/profile_round.sh at commit %s: one rocprofv3 --pmc pass per counter group of `python3 bench.py%s`, mean per launch x launches / steps profiled, summed over the step's kernels; "
                          "fetch_bytes = 2 x FETCH_SIZE x 1024 (gfx950 counts each 128-byte request as 64: profiles/%s/fetch_calibration.md), write_bytes = WRITE_SIZE x 1024" % (commit, " --no-secondary" if cfg == "c2" else " --config " + cfg, "r02")}
-        # a step of a tail-compacted configuration (C3) is many launches -- per 16-frame chunk one head, the tail levels, one fold: the
-        # per-STEP instruction counts are the sums over the <false> instantiations divided by the steps profiled (head launches / chunks per step)
-        heads = [k for k in counters if "render_head_kernel<false>" in k]
-        if heads:
-            chunks_per_step = int(os.environ.get("TRG_CHUNKS_PER_STEP", "16"))   # C3: 256 spp in chunks of 16 frames
-            steps = counters[heads[0]]["SQ_INSTS_VALU"]["launches"] / chunks_per_step
-            tot = collections.defaultdict(float)
-            for k, cs in counters.items():
-                if "<false>" in k or "accumulate" in k:
-                    for n, v in cs.items():
-                        tot[n] += v["mean"] * v["launches"]
-            rec["kernel"] = "render_head_kernel<false> + render_tail_kernel<false> (all launches of a step)"
-            rec["per_kernel_launch"] = {k: {"valu_insts": cs.get("SQ_INSTS_VALU", {}).get("median"), "launches_profiled": cs.get("SQ_INSTS_VALU", {}).get("launches"),
-                                            "lanes_active_per_valu_inst": (cs["SQ_THREAD_CYCLES_VALU"]["median"] / cs["SQ_INSTS_VALU"]["median"]) if "SQ_THREAD_CYCLES_VALU" in cs and "SQ_INSTS_VALU" in cs else None}
-                                        for k, cs in counters.items() if "<false>" in k}
-            rec["steps_profiled"] = steps
-            rec["valu_insts_per_launch"] = tot["SQ_INSTS_VALU"] / steps
-            rec["salu_insts_per_launch"] = tot["SQ_INSTS_SALU"] / steps
-            rec["lanes_active_per_valu_inst"] = tot["SQ_THREAD_CYCLES_VALU"] / tot["SQ_INSTS_VALU"] if tot["SQ_INSTS_VALU"] else None
-            rec["fetch_bytes"] = 2.0 * tot["FETCH_SIZE"] * 1024.0 / steps
-            rec["write_bytes"] = tot["WRITE_SIZE"] * 1024.0 / steps
-            rec["hbm_bytes_per_launch"] = rec["fetch_bytes"] + rec["write_bytes"]
-            rec["note"] = "`per launch` here = per bench step (one trg_render of the whole configuration): sums over every kernel launch of the step"
         json.dump(rec, open(f"{out}/{cfg}_counters.json", "w"), indent=1)
-        print(cfg, json.dumps({k: (round(v) if isinstance(v, float) and v > 100 else v) for k, v in rec.items() if k not in ("source",)}))
+        print(cfg, json.dumps({k: (round(v) if isinstance(v, float) and v > 100 else v) for k, v in rec.items() if k not in ("source", "kernels", "unit", "note")}))
     for r in stats[:2]:
         print(cfg, r["Name"][:70], "calls", r["Calls"], "avg ns", r["AverageNs"])
 json.dump(summary, open(f"{out}/summary.json", "w"), indent=1)

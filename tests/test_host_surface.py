@@ -703,7 +703,7 @@ def test_every_tile_order_is_a_bijection(built):
     L = capi.load()
     n, bx, by = C.c_uint32(), C.c_uint32(), C.c_uint32()
     for tx, ty in ((120, 68), (1, 1), (7, 3), (13, 1), (2, 9), (240, 135), (5, 5), (64, 2)):
-        for order in (0, 1, 2, 4, 8, 17, 18, 20, 24):
+        for order in (0, 1, 2, 4, 8, 17, 18, 20, 24, 32):
             assert L.trg_debug_tile_of_slot(tx, ty, order, 0, C.byref(n), None, None) >= 0
             slots = n.value
             seen, per_xcd = set(), {}
@@ -718,6 +718,19 @@ def test_every_tile_order_is_a_bijection(built):
             assert L.trg_debug_tile_of_slot(tx, ty, order, slots, None, None, None) == 0
             if order == 0:
                 assert slots == tx * ty
+            elif order == 32:
+                # 8 x 8-tile super-blocks, one 2 x 4-tile sub-block per XCD: the 8 tiles an XCD gets from a super-block form one 2 x 4 rectangle
+                assert slots == ((tx + 7) // 8) * ((ty + 7) // 8) * 64
+                for x, tiles in per_xcd.items():
+                    groups = {}
+                    for (a, b_) in tiles:
+                        groups.setdefault((a // 8, b_ // 8), []).append((a, b_))
+                    for g_ in groups.values():
+                        xs, ys = [t[0] for t in g_], [t[1] for t in g_]
+                        assert max(xs) - min(xs) <= 1 and max(ys) - min(ys) <= 3
+                if tx % 8 == 0 and ty >= 16:
+                    counts = [len(v) for v in per_xcd.values()]
+                    assert max(counts) - min(counts) <= tx // 8 * 8 // 2 + 8           # the partial bottom row of super-blocks is shared out by the rotation
             elif order >= 16:
                 # stripes of S tile rows dealt round robin: XCD x owns exactly the rows whose group number is x mod 8, all columns of them
                 S = order - 16

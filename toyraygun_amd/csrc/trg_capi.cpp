@@ -45,6 +45,7 @@ struct trg_ctx {
     unsigned char *wf_mem[kScratchSlots] = {};
     size_t wf_bytes[kScratchSlots] = {};
     int cu_count = 256;
+    uint32_t *xq = nullptr;   // kScratchSlots x 8 job-queue heads of the persistent regeneration launches (TRG_OPT_TILE_ORDER 64 + n), one set per stream
     uint32_t bvh_depth4 = 0, bvh_nodes4 = 0;
     SceneDesc sc{};
     bool scene_loaded = false, have_uniforms = false, have_offsets = false;
@@ -294,6 +295,7 @@ static uint32_t choose_fsplit(const trg_ctx *c, uint32_t spp, uint32_t rows) {
 // XCD-aware order 8 x the largest of the xcd_cols x (8 / xcd_cols) regions (regions differ by a row or a column of tiles at most).
 static uint64_t tile_slots(uint32_t tiles_x, uint32_t tiles_y, uint32_t xcd_cols) {
     if (xcd_cols == 0u) return (uint64_t)tiles_x * tiles_y;
+    if (xcd_cols == kXcdBlocks) return (uint64_t)((tiles_x + 7u) / 8u) * ((tiles_y + 7u) / 8u) * 64ull;
     if (xcd_cols >= kXcdStripes) {
         const uint32_t S = xcd_cols - kXcdStripes;
         return (uint64_t)((tiles_y + kXcds * S - 1u) / (kXcds * S)) * S * kXcds * tiles_x;
@@ -315,6 +317,7 @@ static uint64_t tile_slots(uint32_t tiles_x, uint32_t tiles_y, uint32_t xcd_cols
 // strictly in turn, so the cheap regions' XCDs idle (1 x 8: 23.8 ms, 4 x 2: 37.5, 8 x 1: 35.9 -- the 16:9 side bars).  TRG_XCD_AUTO_COLS
 // (a build flag) would make an XCD-aware layout the automatic choice for scenes traversed from HBM.
 static uint32_t choose_xcd_cols(const trg_ctx *c, bool lds_scene, uint32_t tiles_x, uint32_t tiles_y) {
+    if (c->opt_tile_order >= (int)kXcdPersist) return (uint32_t)c->opt_tile_order - kXcdPersist;   // 64 + n: the n x (8 / n) regions, dealt through per-XCD queues where the kernel can (regeneration)
     if (c->opt_tile_order >= 0) return (uint32_t)c->opt_tile_order;
     if (lds_scene || TRG_XCD_AUTO_COLS == 0) return 0u;
     uint32_t rc = TRG_XCD_AUTO_COLS;
@@ -513,6 +516,7 @@ int trg_create(trg_ctx **out, int device, uint32_t width, uint32_t height) {
     if (e == hipSuccess) e = hipMalloc((void **)&c->accum_own, npix * 16);
     if (e == hipSuccess) e = hipMalloc((void **)&c->offsets, npix * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&c->counters, sizeof(unsigned long long) * kCounterSlots * kCounterWords);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->xq, sizeof(uint32_t) * kXcds * trg_ctx::kScratchSlots);
     if (e == hipSuccess) e = hipMemset(c->accum_own, 0, npix * 16);
     if (e == hipSuccess) e = hipMemset(c->counters, 0, sizeof(unsigned long long) * kCounterSlots * kCounterWords);
     if (e != hipSuccess) {
@@ -537,6 +541,7 @@ void trg_destroy(trg_ctx *c) {
         if (c->wf_mem[k]) (void)hipFree(c->wf_mem[k]);
     }
     if (c->counters) (void)hipFree(c->counters);
+    if (c->xq) (void)hipFree(c->xq);
     if (c->offsets) (void)hipFree(c->offsets);
     if (c->accum_own) (void)hipFree(c->accum_own);
     for (int k = 0; k < 8; ++k)
@@ -1059,11 +1064,17 @@ static int render_impl(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t 
             c->wf_bytes[slot] = rad_bytes;
         }
         p.tail_radbuf = c->wf_mem[slot];
+        // TRG_OPT_TILE_ORDER 64 + n: about as many PERSISTENT workgroups as the chip holds (7 per CU) pop the jobs of the n x (8 / n) screen regions
+        // from one queue per XCD (trg_regen.inc.h): the heads are zeroed in front of every launch, on its stream
+        const bool persist = c->opt_tile_order >= (int)kXcdPersist && p.xcd_cols != 0u;
+        const uint32_t launch_grid = persist ? std::min<uint32_t>(rgrid, (uint32_t)c->cu_count * 7u) : rgrid;
+        if (persist) { p.xq = c->xq + (size_t)slot * kXcds; p.xq_jobs = rgrid / kXcds; c->last_xcd_cols = p.xcd_cols + kXcdPersist; }
         if (c->opt_timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
         for (uint32_t f0 = 0; f0 < spp; f0 += fc) {
             p.frame_begin = frame_begin + f0; p.spp = std::min(fc, spp - f0);
-            hipError_t te = c->opt_strict ? launch_render_regen_strict(p, c->opt_counters, rgrid, plan.total, c->stream)
-                                          : launch_render_regen_fast(p, c->opt_counters, rgrid, plan.total, c->stream);
+            if (persist) HIPCHK(c, hipMemsetAsync(p.xq, 0, sizeof(uint32_t) * kXcds, c->stream));
+            hipError_t te = c->opt_strict ? launch_render_regen_strict(p, c->opt_counters, launch_grid, plan.total, c->stream)
+                                          : launch_render_regen_fast(p, c->opt_counters, launch_grid, plan.total, c->stream);
             if (te == hipSuccess) te = c->opt_strict ? launch_regen_accumulate_strict(p, grid, c->stream) : launch_regen_accumulate_fast(p, grid, c->stream);
             if (te != hipSuccess) return fail(c, TRG_ERR_DEVICE, "trg_render: regeneration launch failed: %s", hipGetErrorString(te));
         }
@@ -1186,8 +1197,8 @@ int trg_set_option(trg_ctx *c, int option, int64_t value) {
         c->opt_tail_sort = (int)value;
         break;
     case TRG_OPT_TILE_ORDER:
-        if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 17 && value != 18 && value != 20 && value != 24)
-            return fail(c, TRG_ERR_INVALID, "trg_set_option: tile order must be -1 (auto), 0 (columns), 1, 2, 4, 8 (XCD regions: column strips) or 17, 18, 20, 24 (XCD stripes of 1, 2, 4, 8 tile rows)");
+        if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 17 && value != 18 && value != 20 && value != 24 && value != 32 && value != 65 && value != 66 && value != 68 && value != 72)
+            return fail(c, TRG_ERR_INVALID, "trg_set_option: tile order must be -1 (auto), 0 (columns), 1, 2, 4, 8 (XCD regions: column strips), 17, 18, 20, 24 (XCD stripes of 1, 2, 4, 8 tile rows), 32 (XCD sub-blocks of 8 x 8-tile super-blocks) or 65, 66, 68, 72 (the XCD regions through per-XCD job queues)");
         c->opt_tile_order = (int)value;
         break;
     case TRG_OPT_LAUNCHES_IN_FLIGHT:
@@ -1353,7 +1364,7 @@ int trg_debug_plane_records(const float *positions3, const uint32_t *indices, co
 }
 
 int trg_debug_tile_of_slot(uint32_t tiles_x, uint32_t tiles_y, uint32_t order, uint32_t slot, uint32_t *n_slots, uint32_t *bx, uint32_t *by) {
-    if (tiles_x == 0 || tiles_y == 0 || (order != 0 && order != 1 && order != 2 && order != 4 && order != 8 && order != 17 && order != 18 && order != 20 && order != 24)) return TRG_ERR_INVALID;
+    if (tiles_x == 0 || tiles_y == 0 || (order != 0 && order != 1 && order != 2 && order != 4 && order != 8 && order != 17 && order != 18 && order != 20 && order != 24 && order != 32)) return TRG_ERR_INVALID;
     const uint64_t slots = tile_slots(tiles_x, tiles_y, order);
     if (slots > 0x7FFFFFFFull) return TRG_ERR_RANGE;
     if (n_slots) *n_slots = (uint32_t)slots;

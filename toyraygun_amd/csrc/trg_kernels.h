@@ -110,8 +110,17 @@ struct RenderParams {
     // row ((l / 8) * il_n + il_r) * 8 + l % 8 for the camera ray and the pixel's Halton offset, and row row0 + l of the accumulation
     // buffer.  il_n <= 1: rows [row0, row0 + rows) of the image, stored where they are.
     uint32_t il_n, il_r;
+    // PERSISTENT workgroups with one job queue per XCD (TRG_OPT_TILE_ORDER 66; render_regen_kernel only, round 4): xq != nullptr = the launch
+    // has about as many workgroups as the chip holds; each one reads the XCD it runs on (HW_REG_XCC_ID) and pops jobs -- (tile, frame lane)
+    // pairs, xq_jobs per queue -- from THAT XCD's queue, whose tiles are one of the 2 x 4 screen regions of the XCD-aware order (xcd_cols), and
+    // steals from the next queues when its own is empty.  An L2 then serves one screen region, whichever XCD the dispatcher's round robin
+    // hands a workgroup to, and no XCD idles behind a slower one.  xq: 8 counters, zeroed before the launch.
+    uint32_t *xq;
+    uint32_t xq_jobs;
 };
 constexpr uint32_t kMicroBandRows = 8;   // = the rows of a wavefront's 8x8 sub-tile: a wavefront never straddles two micro-bands
+constexpr uint32_t kXcdPersist = 64;   // tile order 64 + n: persistent workgroups popping from per-XCD queues over the n x (8 / n) regions (regeneration kernel)
+constexpr uint32_t kXcdBlocks = 32;    // tile order 32: 8 x 8-tile super-blocks, one 2 x 4-tile sub-block per XCD
 constexpr uint32_t kXcdStripes = 16;   // tile orders 17, 18, 20, 24: stripes of 1, 2, 4, 8 tile rows dealt round robin over the XCDs
 constexpr uint32_t kXcds = 8;   // XCDs of an MI355X: workgroups are dealt round-robin over them (MI355X_MICROARCH.md, workgroup dispatch)
 
@@ -141,6 +150,22 @@ TRG_HD inline bool tile_of_slot(uint32_t tiles_x, uint32_t tiles_y, uint32_t xcd
         return crank < tiles_x;
     }
     const uint32_t x = slot % kXcds, j = slot / kXcds;
+    if (xcd_cols == kXcdBlocks) {
+        // BLOCKS (round 4): the picture in super-blocks of 8 x 8 tiles, walked in columns from the centre outwards; the 8 XCDs work on ONE
+        // super-block at a time, each on a compact 2 x 4-tile sub-block of it (which XCD takes which sub-block rotates from super-block to
+        // super-block, so that the partial super-blocks at the picture's edge cost every XCD the same).  Neighbouring regions cost alike
+        // and the dispatcher's strict round robin never waits long, while an L2 serves 8 adjacent tiles instead of 8 scattered ones.
+        const uint32_t nsy = (tiles_y + 7u) / 8u, nsx = (tiles_x + 7u) / 8u;
+        const uint32_t sb = j / 8u, t = j % 8u;
+        const uint32_t sbc = sb / nsy, sby = sb - sbc * nsy;
+        if (sbc >= nsx) return false;
+        const uint32_t scl = (nsx - 1u) / 2u;
+        const uint32_t sbx = (sbc & 1u) ? scl + 1u + sbc / 2u : scl - sbc / 2u;
+        const uint32_t pos = (x + sb) % kXcds;                                      // this XCD's sub-block of the super-block: 4 across, 2 down
+        bx = sbx * 8u + (pos % 4u) * 2u + t % 2u;
+        by = sby * 8u + (pos / 4u) * 4u + t / 2u;
+        return bx < tiles_x && by < tiles_y;
+    }
     if (xcd_cols >= kXcdStripes) {
         // STRIPES (round 4): XCD x owns the tile rows whose group of S rows has number x mod 8 -- S = xcd_cols - 16 in {1, 2, 4, 8} -- i.e.
         // horizontal stripes of S tile rows dealt round robin over the XCDs: every XCD gets an eighth of every part of the picture (the

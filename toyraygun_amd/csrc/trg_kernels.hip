@@ -780,6 +780,11 @@ hipError_t SFX(launch_render)(const RenderParams &p, bool lds_scene, bool counte
 }
 
 hipError_t SFX(launch_render_regen)(const RenderParams &p, bool counters, uint32_t grid, size_t lds_bytes, hipStream_t s) {
+    if (p.xq) {   // persistent workgroups popping from per-XCD job queues (TRG_OPT_TILE_ORDER 64 + n)
+        if (counters) hipLaunchKernelGGL((render_regen_kernel<true, true>), dim3(grid), dim3(kBlock), lds_bytes, s, p);
+        else hipLaunchKernelGGL((render_regen_kernel<false, true>), dim3(grid), dim3(kBlock), lds_bytes, s, p);
+        return hipGetLastError();
+    }
     if (counters) hipLaunchKernelGGL((render_regen_kernel<true>), dim3(grid), dim3(kBlock), lds_bytes, s, p);
     else hipLaunchKernelGGL((render_regen_kernel<false>), dim3(grid), dim3(kBlock), lds_bytes, s, p);
     return hipGetLastError();

@@ -65,7 +65,7 @@ TRG_DEV void regen_count(lds_int_t *wred, int k, bool pred) {
 
 static_assert(TRG_PARK_PATH && TRG_PARK_OFFSET, "render_regen_kernel uses all ten words per thread of the LDS render_kernel parks its path and its Halton offset in "
                                                "(plan_lds_as: 40 bytes per thread): nine of path state, and waves 2 and 3 stage their log records in word [9]");
-template <bool COUNT>
+template <bool COUNT, bool PERSIST = false>
 __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_kernel(const trg::RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     SceneView sc = scene_view<false>(p.sc, smem);
@@ -78,14 +78,41 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
     // that a launch of few tiles (a row band, a small window) still fills the chip
     // (XCD-aware order: the F workgroups of a tile are F consecutive slots of ONE XCD, so that they share its L2)
     const uint32_t F = p.fsplit;   // wave-uniform
-    const uint32_t kx = blockIdx.x / trg::kXcds;
-    const uint32_t tile_id = p.xcd_cols ? (kx / F) * trg::kXcds + blockIdx.x % trg::kXcds : blockIdx.x / F;
-    const uint32_t fl = p.xcd_cols ? kx % F : blockIdx.x % F;
+    // A JOB = one (tile, frame lane): job number = the workgroup slot of the plain launch.  Plain launch: this workgroup's own number,
+    // once.  Persistent launch (p.xq): jobs popped from the queue of the XCD this workgroup runs on, until all eight queues are empty.
+    lds_int_t *job_word = (lds_int_t *)(reinterpret_cast<int *>(smem + p.red_off) + 7);   // (word 7 of wavefront 0's counter row: free while the kernel runs)
+    lds_int_t *wred = (lds_int_t *)(reinterpret_cast<int *>(smem + p.red_off) + wave * 8u);
+    if (lane_id() < 7u) wred[lane_id()] = 0;   // (the ray counters of the whole workgroup lifetime; word 7 is the job hand-off)
+    Counters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.wnodes = 0; cnt.wtris = 0;
+  for (uint32_t round = 0; PERSIST || round == 0u; ++round) {   // (PERSIST = false: exactly one trip, the straight-line kernel)
+    uint32_t job = blockIdx.x;
+    if (PERSIST) {
+        __syncthreads();   // everybody is done with the previous job (its LDS state, its log)
+        if (threadIdx.x == 0) {
+            uint32_t xcc;   // (read here, not kept: a workgroup stays on its XCD)
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            xcc &= 7u;
+            int got = -1;
+            for (uint32_t a = 0; a < trg::kXcds && got < 0; ++a) {   // own queue first, then the others in turn: at most eight atomics, then the workgroup ends
+                const uint32_t q = (xcc + a) % trg::kXcds;
+                const uint32_t k = atomicAdd(&p.xq[q], 1u);
+                if (k < p.xq_jobs) got = (int)(q + trg::kXcds * k);
+            }
+            *job_word = got;
+        }
+        __syncthreads();
+        const int got = *job_word;
+        if (got < 0) break;
+        job = (uint32_t)__builtin_amdgcn_readfirstlane(got);
+    }
+    const uint32_t kx = job / trg::kXcds;
+    const uint32_t tile_id = p.xcd_cols ? (kx / F) * trg::kXcds + job % trg::kXcds : job / F;
+    const uint32_t fl = p.xcd_cols ? kx % F : job % F;
     uint32_t bx, by;
-    if (!block_tile(p, tile_id, bx, by)) return;
+    if (!block_tile(p, tile_id, bx, by)) { if (PERSIST) continue; else break; }   // (a padding slot of the XCD-aware order)
     const uint32_t x0 = bx * trg::kTileW, y0 = p.row0 + by * trg::kTileH;   // the workgroup's 16x16 tile
     const uint32_t frames_wg = p.spp > fl ? (p.spp - fl + F - 1u) / F : 0u, frames_max = (p.spp + F - 1u) / F;
-    v4f *rlog = reinterpret_cast<v4f *>(p.tail_radbuf) + (size_t)blockIdx.x * trg::kBlock * frames_max;   // this workgroup's log: 256 x frames records
+    v4f *rlog = reinterpret_cast<v4f *>(p.tail_radbuf) + (size_t)job * trg::kBlock * frames_max;   // this job's log: 256 x frames records
     // per thread in LDS ([word][thread]): the Halton offset of the current job's pixel (1), throughput (3..5), radiance (6..8)
     lds_float_t *park = (lds_float_t *)(reinterpret_cast<float *>(smem + p.acc_off) + threadIdx.x);
     // the pool counter of the workgroup: the spare word [2] of thread 0
@@ -104,9 +131,7 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
 
     // the ray counters (primary, bounce, shadow, shaded) are kept in the wavefront's row of the LDS reduction scratch, not in registers:
     // the blocks below run under conditions the compiler does not see as wave-uniform, where a loop-carried sum becomes a VGPR
-    lds_int_t *wred = (lds_int_t *)(reinterpret_cast<int *>(smem + p.red_off) + wave * 8u);
-    if (lane_id() < 8u) wred[lane_id()] = 0;
-    Counters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.wnodes = 0; cnt.wtris = 0;
+    // (wred / cnt: set up once, before the job loop)
     const V3 light_color = mk(p.u.light_color[0], p.u.light_color[1], p.u.light_color[2]);
     // the number of the last bounce, as an SGPR the optimiser cannot see through (it rewrites `b + 1 == bounces` into `b == bounces - 1` and
     // kept that difference in a VGPR of its own across the main loop); with no bounces at all it matches no shading event, and there is none
@@ -273,6 +298,7 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
         }
     }
     regen_flush(stage, stage_cnt, rlog, pool_done);
+  }   // next job (persistent launch)
 #undef TRG_RG_HIDX
 #undef TRG_RG_FRAME
 #undef TRG_RG_JOB

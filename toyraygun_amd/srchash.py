@@ -1,27 +1,52 @@
-"""Hash of the kernel sources: ties imported profiler counters to the build they were measured on.
+"""Hash of what a render kernel's instruction counts depend on: ties imported profiler counters to the build they were measured on.
 
 scripts/pmc_summary.py stores it in profiles/<round>/<config>_counters.json; bench.py recomputes it and refuses counters whose
 hash differs from the tree it runs in (the instruction counts of a different kernel say nothing about this one)."""
 import hashlib
 import os
+import re
+import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
+ROOT = os.path.dirname(_HERE)
 
 
 def kernel_source_files():
-    """What the render kernels are compiled from: trg_kernels.hip and everything it includes from this directory (the host-side
-    sources -- C ABI, builders, device groups -- can change without making a kernel's instruction counts stale)."""
-    names = ["trg_kernels.hip", "trg_kernels.h", "trg_device.h"] + sorted(f for f in os.listdir(CSRC) if f.endswith(".inc.h"))
-    return [os.path.join(CSRC, f) for f in names]
+    """The kernels' own sources (trg_kernels.hip and everything it includes from csrc/), the ABI header they include
+    (include/trg.h: the uniforms block, material and mask constants), and -- ADVICE r03 -- the host side that decides WHICH kernel
+    runs with which parameters (trg_capi.cpp: kernel choice, frame split, regeneration lanes, tile order, LDS plan, scene layout):
+    a changed schedule changes the per-launch instruction counts as surely as a changed kernel."""
+    names = ["trg_kernels.hip", "trg_kernels.h", "trg_device.h", "q4node.h"] + sorted(f for f in os.listdir(CSRC) if f.endswith(".inc.h")) + ["trg_capi.cpp"]
+    return [os.path.join(CSRC, f) for f in names if os.path.exists(os.path.join(CSRC, f))] + [os.path.join(ROOT, "include", "trg.h")]
+
+
+def _compile_flags():
+    """The kernel compile flags of build.py (the `kern` / `common` lists and the -DTRG_* of the two kernel units), as source text."""
+    src = open(os.path.join(_HERE, "build.py")).read()
+    keep = [l.strip() for l in src.splitlines() if re.search(r"^\s*(common|hidden|dev|kern)\s*=|trg_kernels_(fast|strict)\.o", l)]
+    return "\n".join(keep)
+
+
+def _compiler_version():
+    try:
+        from .build import _hipcc
+        out = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True, timeout=60).stdout
+        m = re.search(r"HIP version: *(\S+)", out)
+        c = re.search(r"clang version *(\S+)", out)
+        return "hip %s clang %s" % (m.group(1) if m else "?", c.group(1) if c else "?")
+    except Exception:
+        return "hipcc unavailable"
 
 
 def kernel_source_hash():
-    """sha256 over the names and contents of the files above, first 16 hex digits."""
+    """sha256 over the names and contents of the files above, the kernel compile flags and the compiler version; first 16 hex digits."""
     h = hashlib.sha256()
     for path in kernel_source_files():
         h.update(os.path.basename(path).encode() + b"\0")
         with open(path, "rb") as f:
             h.update(f.read())
         h.update(b"\0")
+    h.update(_compile_flags().encode() + b"\0")
+    h.update(_compiler_version().encode() + b"\0")
     return h.hexdigest()[:16]
