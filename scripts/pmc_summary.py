@@ -64,7 +64,13 @@ for cfg in cfgs:
 
         def timed(k):
             base = k.split("(")[0]
-            if "trgk_" not in base or re.search(r"true>\s*$", base) or re.search(r"(offsets|xcc_probe|halton|raygen|sample|trace|postprocess|unpack_bands)_kernel", base):
+            if "trgk_" not in base or re.search(r"(offsets|xcc_probe|halton|raygen|sample|trace|postprocess|unpack_bands)_kernel", base):
+                return False
+            # the COUNT instantiations (the untimed counters pass): COUNT is the second template argument of render_kernel / render_fp_kernel /
+            # render_pool_kernel / wf_trace_kernel, the first (or only) one of render_regen_kernel / render_head_kernel / render_tail_kernel
+            if re.search(r"render_(kernel|fp_kernel|pool_kernel)<\w+, true", base) or re.search(r"wf_trace_kernel<\w+, true", base):
+                return False
+            if re.search(r"render_(regen|head|tail)_kernel<true", base):
                 return False
             return True
         tk = {k: v for k, v in counters.items() if timed(k)}
