@@ -32,7 +32,8 @@ for case in range(cases):
     spp, bnc = int(rng.integers(1, 41)) if rng.random() < 0.25 else int(rng.integers(1, 9)), int(rng.integers(0, 7))
     opts = dict(force_global=int(rng.integers(0, 2)), fsplit=int(rng.choice([0, 1, 2, 4])), gpu_build=int(rng.integers(0, 4)) if s.ntris >= 2 else 0,
                 kernel=int(rng.choice([0, 0, 0, 1, 2])), in_flight=int(rng.choice([1, 4])), counters=int(rng.integers(0, 2)),
-                regen=int(rng.choice([-1, 0, 1])), tail=int(rng.choice([-1, 0, 1, 2])), tile_order=int(rng.choice([-1, 0, 1, 2, 4, 8])), stack_levels=int(rng.choice([12, 12, 2, 3, 6])))
+                regen=int(rng.choice([-1, 0, 1])), tail=int(rng.choice([-1, 0, 1, 2])), tile_order=int(rng.choice([-1, 0, 1, 2, 4, 8, 17, 18, 20, 24, 32, 65, 66, 68, 72])), stack_levels=int(rng.choice([12, 12, 2, 3, 6])),
+                tail_sort=int(rng.choice([0, 0, 1, 2, 3])), bands=int(rng.integers(0, 2)), depth=int(rng.choice([1, 1, 2, 3])))   # (round 4: the stripe / sub-block / job-queue tile orders, the tail sort, interleaved bands and pipelined groups)
     oseed = int(rng.integers(1, 2 ** 31))
     off = O.pixel_offsets(w, h, seed=oseed)
     opts["group"] = int(rng.choice([0, 0, 0, 2, 3, 5]))   # 0: a plain context; n: a device group of n contexts on device 0 (row bands, possibly empty ones)
@@ -59,13 +60,28 @@ for case in range(cases):
         c.set_option(capi.OPT_TAIL_BOUNCE, opts["tail"])
         c.set_option(capi.OPT_TILE_ORDER, opts["tile_order"])
         c.set_option(capi.OPT_STACK_LDS_LEVELS, opts["stack_levels"])
+        c.set_option(capi.OPT_TAIL_SORT, opts["tail_sort"])
+        interleave_ok = opts["kernel"] == 0     # (interleaved bands are rendered by the direct megakernel only)
+        if opts["group"]:
+            c.set_bands(capi.BANDS_INTERLEAVED if opts["bands"] and interleave_ok else capi.BANDS_CONTIGUOUS)
         split = int(rng.integers(0, spp + 1))
-        if split:
-            c.render(0, split, bnc)
-        if spp - split:
-            c.render(split, spp - split, bnc)
+        if opts["group"] and opts["depth"] > 1:
+            # a pipelined group: independent frames in flight -- some other pictures first (their slots are re-used), the wanted one last, in one launch
+            c.set_option(capi.OPT_TIMING, 0)
+            c.set_pipeline(opts["depth"])
+            for k in range(int(rng.integers(0, 4))):
+                c.render(0, 1 + k % 2, max(bnc - 1, 0))
+            split = 0
+            c.render(0, spp, bnc)
+        else:
+            if split:
+                c.render(0, split, bnc)
+            if spp - split:
+                c.render(split, spp - split, bnc)
         if opts["group"]:
             c.sync()
+        if opts["group"] and opts["depth"] > 1:
+            c.reset_stats(); c.render(0, spp, bnc); c.sync()     # (the counters of the earlier pictures are not the wanted frame's)
         img, st = (c.read_accum(int(rng.integers(0, opts["group"]))) if opts["group"] else c.read_accum()), c.stats()
         if FAST:
             d = np.linalg.norm(img[..., :3].astype(np.float64) - ref[..., :3], axis=-1)

@@ -1,0 +1,8 @@
+O=gpurun_out/r4final2; mkdir -p $O
+python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "default rc $?"
+python bench.py --config c5 --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_c5.json 2> $O/c5.err; echo "c5 rc $?"
+python bench.py --config c4xl --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_c4xl.json 2> $O/c4xl.err; echo "c4xl rc $?"
+TRG_BENCH_GPU_BUILD=1 python bench.py --config c4xl --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_c4xl_device_build.json 2> $O/c4xl_dev.err; echo "c4xl dev rc $?"
+TRG_BENCH_GROUP=1 python bench.py --no-cpu-baseline > $O/bench_n1_through_group_path.json 2> $O/n1g.err; echo "n1 group rc $?"
+TRG_GROUP_EXCHANGE=copy TRG_BENCH_DEVICES=0,0,0,0,0,0,0,0 python bench.py --gpus 8 > $O/bench_g8_rehearsal_one_device.json 2> $O/g8.err; echo "g8 rc $?"
+TRG_RUN_SLOW=1 timeout -k 10 900 python -m pytest tests/test_gpu_fullframe.py -q -m "gpu and slow" > $O/fullframe.log 2>&1; tail -3 $O/fullframe.log

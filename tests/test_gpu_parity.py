@@ -744,6 +744,23 @@ def test_full_size_c3_and_c5_properties(capi, O, cornell):
         assert np.array_equal(_bits(c.read_accum()), _bits(full)) and c.stats().rays == st.rays
         # two rows across every boundary between the eight bands, and two more near the bottom and the top
         _rows_against_oracle(capi, O, c, cornell, w, h, spp, bnc, full, [(100, 2)] + [(270 * k - 1, 2) for k in range(1, 8)] + [(2050, 2)])
+        # the same eight ranks with INTERLEAVED bands (round 4: the default of the 8-GPU job -- 8-row micro-bands dealt round robin, rendered
+        # compactly, unpacked after the exchange): the union is the unsharded frame bit for bit, and the ranks' ray counts differ by under 1.5 %
+        import torch
+        rows0, stride = capi.microband_rows(h, 8, 0)
+        compact = torch.zeros((8 * stride, w, 4), dtype=torch.float32, device="cuda")
+        image = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+        c.bind_accum(compact.data_ptr())
+        per_rank = []
+        for r in range(8):
+            c.reset_stats()
+            c.render_bands(0, spp, bnc, 8, r, r * stride)
+            per_rank.append(c.stats().rays)
+        c.unpack_bands(compact.data_ptr(), image.data_ptr(), 8)
+        c.sync()
+        c.bind_accum(None)
+        assert np.array_equal(_bits(image.cpu().numpy()), _bits(full)) and sum(per_rank) == st.rays
+        assert max(per_rank) <= 1.015 * (sum(per_rank) / 8), per_rank
     finally:
         c.close()
 
