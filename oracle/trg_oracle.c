@@ -1030,7 +1030,7 @@ static int ext_walk_one(const orc_scene *s, const orc_ray *r, int any, orc_isect
             if (h0) { node = c0; continue; }
             if (h1) { node = c1; continue; }
         } else {
-            const uint32_t code = ~(uint32_t)node, first = code >> 3, count = (code & 7u) + 1u;
+            const uint32_t code = ~(uint32_t)node, first = code >> 3, count = (code & 7u) == 7u ? 2u : (code & 7u) + 1u;   /* 7: a quad leaf = two triangles (the product's bvh_build.h) */
             for (uint32_t i = 0; i < count; ++i) {
                 const float *rec = &s->xtris[(size_t)(first + i) * 12];
                 uint32_t k, mask; memcpy(&k, &rec[3], 4); memcpy(&mask, &rec[7], 4);

@@ -76,7 +76,7 @@ typedef struct orc_scene {
     uint32_t ntextures;
     /* an acceleration structure handed in from outside (orc_scene_set_bvh: bench.py's tuned CPU-baseline leg walks THE PRODUCT'S BVH2, as
      * BASELINE.md section 3 plans -- "the same BVH"): nodes of 16 floats (ax0 ax1 ay0 ay1 | bx0 bx1 by0 by1 | az0 az1 bz0 bz1 | child0
-     * child1 - -; a child < 0 is the leaf code ~((first << 3) | (count - 1))), records of 12 floats (v0 | original index, e1 | mask, e2 | 0) */
+     * child1 - -; a child < 0 is the leaf code ~((first << 3) | (count - 1)), count field 7 = a quad leaf of two triangles), records of 12 floats (v0 | original index, e1 | mask, e2 | 0) */
     float *xnodes, *xtris;
     uint32_t xn_nodes, xn_recs;
 } orc_scene;

@@ -8,6 +8,7 @@ Bars (north_star / SURVEY 8d):
     faithful libm mode.
 Nothing here reads /root/reference.
 """
+import os
 import numpy as np
 import pytest
 
@@ -1275,16 +1276,27 @@ def test_path_regeneration_is_bit_exact(capi, O):
 
 def test_plugin_device_build(capi, O):
     """HipRenderer::setDeviceBuild: the acceleration structure of the next loadScene is built on the device (the reference rebuilds
-    its MPS structure on the GPU, MetalRenderer.mm:272-279).  The image does not depend on the builder -- host SAH, device SAH,
-    LBVH and PLOC give the same accumulation buffer bit for bit (shipped build) -- and a scene that fits LDS ignores the option."""
+    its MPS structure on the GPU, MetalRenderer.mm:272-279).  The image does not depend on the tree -- host SAH, device SAH,
+    LBVH and PLOC give the same accumulation buffer bit for bit (shipped build) -- and a scene that fits LDS ignores the option.
+    (Round 4: the host builder pairs the triangles of a parallelogram into QUAD leaves, which the shipped build decides with one
+    plane test -- a different rounding of the same hit: bit-equal to the device builders with TRG_BVH_QUADS=0, within the shipped
+    build's tolerance with quads.)"""
     from toyraygun_amd import host
     w, h = 160, 120
     scene = host.Scene.cornell_lattice(12)     # 20,772 triangles: lives in HBM
-    ref, ms_host = host.render_scene(scene, w, h, 4, 3, device_build=0)
+    os.environ["TRG_BVH_QUADS"] = "0"
+    try:
+        ref, ms_host = host.render_scene(scene, w, h, 4, 3, device_build=0)
+    finally:
+        del os.environ["TRG_BVH_QUADS"]
     assert np.isfinite(ref).all() and ref[..., :3].max() > 0
     for builder in (1, 2, 3):
         got, ms_dev = host.render_scene(scene, w, h, 4, 3, device_build=builder)
         assert np.array_equal(_bits(got), _bits(ref)), builder
+    quads, _ = host.render_scene(scene, w, h, 4, 3, device_build=0)
+    d = np.linalg.norm(quads[..., :3].astype(np.float64) - ref[..., :3], axis=-1)
+    inl = d <= 1e-4 * np.maximum(1.0, np.linalg.norm(ref[..., :3].astype(np.float64), axis=-1))
+    assert inl.mean() >= 0.999 and np.sqrt(np.mean((d * d)[inl])) <= 1e-3, (inl.mean(), d.max())
     box = host.Scene.cornell_box()
     a, _ = host.render_scene(box, w, h, 4, 3, device_build=0)
     b, _ = host.render_scene(box, w, h, 4, 3, device_build=1)

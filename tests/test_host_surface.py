@@ -219,7 +219,7 @@ def _walk(nodes, tris, ntris):
                 stack.append((ref, d + 1, lo, hi))
             else:
                 code = ~ref
-                first, count = code >> 3, (code & 7) + 1
+                first, count = code >> 3, (2 if (code & 7) == 7 else (code & 7) + 1)     # (7: a quad leaf -- two triangles of a parallelogram, bvh_build.h)
                 depth_max = max(depth_max, d + 1)
                 for k in range(first, first + count):
                     rec = tris[k]
@@ -286,7 +286,7 @@ def test_wide_bvh_is_sound(built, O):
                     stack.append((ref, d + 1, lo - 1e-4, hi + 1e-4))
                 else:
                     code = ~ref
-                    first, count = code >> 3, (code & 7) + 1
+                    first, count = code >> 3, (2 if (code & 7) == 7 else (code & 7) + 1)
                     for r in range(first, first + count):
                         rec = tris[r]
                         v0, e1, e2 = rec[0:3], rec[4:7], rec[8:11]
@@ -767,8 +767,13 @@ def test_plane_records_are_the_triangles(built, O):
     soup.add_geometry(np.array([[0, 0, 0], [1, 1, 1], [2, 2, 2]], np.float32), [0, 1, 2], eye, (0.5, 0.5, 0.5), 1)   # zero area
     for scene in (box, soup):
         b = scene.buffers()
-        _, tris, _ = capi.debug_build_bvh(b["positions"], b["indices"], b["material_ids"])
+        nodes, tris, _ = capi.debug_build_bvh(b["positions"], b["indices"], b["material_ids"])
         planes, meta, ctr = capi.debug_plane_records(b["positions"], b["indices"], b["material_ids"])
+        # QUAD leaves (bvh_build.h, count field 7): record X carries the planes of the parallelogram X.e1 x Y.e2, Y (the next record) its own
+        refs = nodes[:, 12:14].copy().view(np.int32).reshape(-1)
+        quad_x = np.zeros(tris.shape[0], bool)
+        quad_x[[(~int(r)) >> 3 for r in refs if r < 0 and ((~int(r)) & 7) == 7]] = True
+        assert quad_x.sum() == (scene.ntris // 2 if scene is box else 0)       # the box is quads throughout (Scene.cpp:24-92), the soup has none
         pos_all = b["positions"].reshape(-1, 3)
         assert np.allclose(ctr, 0.5 * (pos_all.min(0) + pos_all.max(0)), atol=1e-6)
         assert planes.shape == (tris.shape[0], 12) and meta.shape == (tris.shape[0],)
@@ -776,6 +781,11 @@ def test_plane_records_are_the_triangles(built, O):
         assert np.array_equal(meta, ((prim << 2) | (mask & 3)).astype(np.uint16))
         assert sorted(prim.tolist()) == list(range(scene.ntris))
         v0, e1, e2 = tris[:, 0:3].astype(np.float64) - ctr.astype(np.float64), tris[:, 4:7].astype(np.float64), tris[:, 8:11].astype(np.float64)   # (the planes are relative to the centre)
+        mt_e2 = e2.copy()                                        # (the triangles themselves, for the Moeller-Trumbore side)
+        qx = np.nonzero(quad_x)[0]
+        assert np.allclose(v0[qx], v0[qx + 1]) and np.allclose(e2[qx], e1[qx + 1], atol=1e-6)      # X = (p0, p1, diagonal), Y = (p0, diagonal, p3)
+        assert np.allclose(e1[qx] + e2[qx + 1], e2[qx], atol=1e-5) and np.array_equal(mask[qx], mask[qx + 1])   # a parallelogram of one material
+        e2[qx] = e2[qx + 1]                                      # the axes of a quad's planes: X.e1 and Y.e2
         P = planes.astype(np.float64)
         area = np.linalg.norm(np.cross(e1, e2), axis=1)
         ok = area > 0
@@ -798,11 +808,24 @@ def test_plane_records_are_the_triangles(built, O):
                 t = -((P[k, 0:3] @ o.T) - P[k, 3]) / den
                 X = o + t[:, None] * d
                 u, v = X @ P[k, 4:7] + P[k, 7], X @ P[k, 8:11] + P[k, 11]
-                hit = (u >= 0) & (v >= 0) & (u + v <= 1) & (t >= 0)
-                pv = np.cross(d, e2[k]); det = pv @ e1[k]; tv = o - v0[k]
-                mu = (tv * pv).sum(1) / det; q = np.cross(tv, e1[k]); mv = (d * q).sum(1) / det; mt = (q @ e2[k]) / det
-                mhit = (mu >= 0) & (mv >= 0) & (mu + mv <= 1) & (mt >= 0)
-                edge = np.minimum.reduce([np.abs(mu), np.abs(mv), np.abs(1 - mu - mv), np.abs(mt)]) < 1e-4   # fp32 planes: undecided this close to an edge
+                def moller(j):
+                    pv = np.cross(d, mt_e2[j]); det = pv @ e1[j]; tv = o - v0[j]
+                    mu = (tv * pv).sum(1) / det; q = np.cross(tv, e1[j]); mv = (d * q).sum(1) / det; mt = (q @ mt_e2[j]) / det
+                    return mu, mv, mt, (mu >= 0) & (mv >= 0) & (mu + mv <= 1) & (mt >= 0), np.minimum.reduce([np.abs(mu), np.abs(mv), np.abs(1 - mu - mv), np.abs(mt)]) < 1e-4
+                if quad_x[k]:
+                    # ONE test for the two triangles: inside the unit square of (s, t); s >= t is X with weights (s - t, t), t > s is Y with (s, t - s)
+                    second = u < v
+                    hit = (u >= 0) & (v >= 0) & (u <= 1) & (v <= 1) & (t >= 0)
+                    u, v = np.where(second, u, u - v), np.where(second, v - u, v)
+                    mx, my = moller(k), moller(k + 1)
+                    mu, mv, mt = (np.where(second, my[i], mx[i]) for i in range(3))
+                    mhit = np.where(second, my[3], mx[3])
+                    edge = mx[4] | my[4]      # fp32 planes: undecided this close to an edge (the diagonal included: either triangle may claim it)
+                    assert not (mx[3] & my[3] & ~edge).any()
+                    assert np.array_equal((mx[3] | my[3])[~edge], hit[~edge]), k
+                else:
+                    hit = (u >= 0) & (v >= 0) & (u + v <= 1) & (t >= 0)
+                    mu, mv, mt, mhit, edge = moller(k)
             assert np.array_equal(hit[~edge], mhit[~edge]), k
             both = hit & mhit & ~edge
             assert np.allclose(t[both], mt[both], rtol=1e-4, atol=1e-5) and np.allclose(u[both], mu[both], atol=1e-4) and np.allclose(v[both], mv[both], atol=1e-4)

@@ -15,7 +15,8 @@ namespace trg {
 namespace {
 
 constexpr int kBins = 16;
-uint32_t kMaxLeaf = 2;               // leaf encoding allows 8 (tunable: TRG_BVH_MAXLEAF)
+uint32_t kMaxLeaf = 2;               // leaf encoding allows 7 (tunable: TRG_BVH_MAXLEAF)
+bool kQuads = true;                  // pair the two triangles of a parallelogram into one primitive with a leaf of its own (TRG_BVH_QUADS=0: off)
 float kTravCost = 1.2f;               // SAH cost of one node visit relative to one triangle test (TRG_BVH_TRAVCOST)
 constexpr uint32_t kSahDepthCap = 24; // below this depth switch to balanced median splits
 constexpr float kInf = std::numeric_limits<float>::infinity();
@@ -31,7 +32,7 @@ struct Box {
     }
 };
 
-struct Prim { Box b; float c[3]; uint32_t id; };
+struct Prim { Box b; float c[3]; uint32_t id; uint32_t id2; };   // id2 != ~0u: a quad -- triangle id is its X, id2 its Y (bvh_build.h)
 
 struct BuildNode {
     Box box;
@@ -61,6 +62,9 @@ struct Builder {
         Box box, cbox;
         for (uint32_t i = 0; i < count; ++i) { box.grow(prims[first + i].b); cbox.grow(prims[first + i].c); }
         if (count <= 1) return make_leaf(box, first, count, d);
+        // a quad is a leaf of its own: a range that holds one is split until it is alone
+        bool has_quad = false;
+        for (uint32_t i = 0; i < count && !has_quad; ++i) has_quad = prims[first + i].id2 != ~0u;
 
         int axis = 0;
         float ext[3] = { cbox.hi[0] - cbox.lo[0], cbox.hi[1] - cbox.lo[1], cbox.hi[2] - cbox.lo[2] };
@@ -96,7 +100,7 @@ struct Builder {
                 const float leaf_cost = box.half_area() * (float)count;
                 // node traversal cost 1 box-pair test ~ 1.2 triangle tests
                 const float split_cost = kTravCost * box.half_area() + best_cost;
-                if (count <= kMaxLeaf && leaf_cost <= split_cost) return make_leaf(box, first, count, d);
+                if (!has_quad && count <= kMaxLeaf && leaf_cost <= split_cost) return make_leaf(box, first, count, d);
                 const float scale = (float)kBins / ext[best_axis];
                 const float lo = cbox.lo[best_axis];
                 auto it = std::partition(prims + first, prims + first + count, [&](const Prim &p) {
@@ -108,7 +112,7 @@ struct Builder {
             }
         }
         if (!have_split) {
-            if (count <= kMaxLeaf && (ext[axis] <= 0.f || d >= kSahDepthCap)) return make_leaf(box, first, count, d);
+            if (!has_quad && count <= kMaxLeaf && (ext[axis] <= 0.f || d >= kSahDepthCap)) return make_leaf(box, first, count, d);
             // balanced median split (also the fallback for coincident centroids)
             mid = count / 2;
             std::nth_element(prims + first, prims + first + mid, prims + first + count,
@@ -138,20 +142,48 @@ inline float bits_f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 }  // namespace
 
 void build_bvh(const float *pos, const uint32_t *idx, const uint32_t *masks, uint32_t ntris, Bvh &out) {
-    if (const char *e = getenv("TRG_BVH_MAXLEAF")) kMaxLeaf = (uint32_t)std::min(8, std::max(1, atoi(e)));
+    if (const char *e = getenv("TRG_BVH_MAXLEAF")) kMaxLeaf = (uint32_t)std::min(7, std::max(1, atoi(e)));
     if (const char *e = getenv("TRG_BVH_TRAVCOST")) kTravCost = (float)atof(e);
+    if (const char *e = getenv("TRG_BVH_QUADS")) kQuads = atoi(e) != 0;
     Builder B;
     std::vector<Prim> prim_store(ntris);
     B.prims = prim_store.data();
     Box scene;
+    // Quads: triangles k and k + 1 with the same first vertex, one more shared vertex, equal material, and the fourth corner where a
+    // parallelogram has it.  Pattern 1 (cube faces, Scene.cpp:37-55): (a, b, c) (a, c, d) -- X = k, Y = k + 1.  Pattern 2 (planes and the
+    // light, Scene.cpp:60-92): (a, b, c) (a, d, b) -- X = k + 1, Y = k.  In both, X = (a, p1, diag), Y = (a, diag', p3) with diag = p1 + p3 - a.
+    auto vtx = [&](uint32_t k, int j) { return &pos[(size_t)idx[k * 3 + j] * 3]; };
+    auto same = [](const float *p, const float *q) { return p[0] == q[0] && p[1] == q[1] && p[2] == q[2]; };
+    auto quad_of = [&](uint32_t k, uint32_t &x, uint32_t &y) {
+        if (!kQuads || k + 1 >= ntris || masks[k] != masks[k + 1] || !same(vtx(k, 0), vtx(k + 1, 0))) return false;
+        const float *a = vtx(k, 0), *p1, *dg, *p3;
+        if (same(vtx(k, 2), vtx(k + 1, 1))) { x = k; y = k + 1; p1 = vtx(k, 1); dg = vtx(k, 2); p3 = vtx(k + 1, 2); }
+        else if (same(vtx(k, 1), vtx(k + 1, 2))) { x = k + 1; y = k; p1 = vtx(k + 1, 1); dg = vtx(k, 1); p3 = vtx(k, 2); }
+        else return false;
+        float big = 0.f, area2 = 0.f;
+        for (int c = 0; c < 3; ++c) big = std::max({ big, std::fabs(a[c]), std::fabs(p1[c]), std::fabs(p3[c]), std::fabs(dg[c]) });
+        for (int c = 0; c < 3; ++c)
+            if (!(std::fabs((p1[c] - a[c]) + (p3[c] - a[c]) - (dg[c] - a[c])) <= 4e-6f * big)) return false;   // (also false for NaN)
+        const float e1[3] = { p1[0] - a[0], p1[1] - a[1], p1[2] - a[2] }, e2[3] = { p3[0] - a[0], p3[1] - a[1], p3[2] - a[2] };
+        const float n[3] = { e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0] };
+        area2 = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+        return area2 > 0.f && std::isfinite(area2);
+    };
+    uint32_t n_prims = 0;
     for (uint32_t k = 0; k < ntris; ++k) {
-        Prim &p = B.prims[k];
-        p.id = k;
-        for (int j = 0; j < 3; ++j) p.b.grow(&pos[(size_t)idx[k * 3 + j] * 3]);
+        Prim &p = B.prims[n_prims++];
+        p = Prim();
+        p.id = k; p.id2 = ~0u;
+        uint32_t x = 0, y = 0;
+        const bool q = quad_of(k, x, y);
+        if (q) { p.id = x; p.id2 = y; }
+        for (uint32_t t = k; t <= k + (q ? 1u : 0u); ++t)
+            for (int j = 0; j < 3; ++j) p.b.grow(vtx(t, j));
         for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * (p.b.lo[a] + p.b.hi[a]);
         scene.grow(p.b);
+        if (q) ++k;
     }
-    B.nodes.reserve((size_t)ntris * 2 + 2);
+    B.nodes.reserve((size_t)n_prims * 2 + 2);
     // Large scenes: the top of the tree is built here, subtrees of at most `cutoff` triangles by worker threads (each sorts
     // its own range of the shared array and fills its own node vector), then spliced in.  Every split decision depends on
     // the triangles of its range only, so the tree -- and, after the depth-first flatten below, the device layout -- is the
@@ -159,11 +191,11 @@ void build_bvh(const float *pos, const uint32_t *idx, const uint32_t *masks, uin
     unsigned n_threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     if (const char *e = getenv("TRG_BVH_THREADS")) n_threads = (unsigned)std::min(64, std::max(1, atoi(e)));
     std::vector<Task> tasks;
-    if (ntris >= 65536u && n_threads > 1) {
-        B.cutoff = std::max(4096u, ntris / (n_threads * 8u));
+    if (n_prims >= 65536u && n_threads > 1) {
+        B.cutoff = std::max(4096u, n_prims / (n_threads * 8u));
         B.tasks = &tasks;
     }
-    int32_t root = ntris ? B.build(0, ntris, 0) : -1;
+    int32_t root = n_prims ? B.build(0, n_prims, 0) : -1;
     if (!tasks.empty()) {
         B.tasks = nullptr;
         std::vector<Builder> sub(tasks.size());
@@ -222,17 +254,29 @@ void build_bvh(const float *pos, const uint32_t *idx, const uint32_t *masks, uin
     out.tris.resize((size_t)ntris * 3);
     out.n_leaves = B.leaves; out.depth = B.depth + (synth_root ? 1 : 0); out.max_leaf = B.max_leaf;
 
-    // triangle records in leaf (prims[]) order
-    for (uint32_t i = 0; i < ntris; ++i) {
-        const uint32_t k = B.prims[i].id;
+    // triangle records in leaf (prims[]) order; a quad contributes its X record, then its Y record
+    std::vector<uint32_t> rec_first((size_t)n_prims + 1, 0u);   // first record of prim i
+    for (uint32_t i = 0; i < n_prims; ++i) rec_first[i + 1] = rec_first[i] + (B.prims[i].id2 != ~0u ? 2u : 1u);
+    out.quad.assign(ntris, 0);
+    out.n_quads = 0;
+    auto put_rec = [&](uint32_t r, uint32_t k) {
         const float *a = &pos[(size_t)idx[k * 3 + 0] * 3], *b = &pos[(size_t)idx[k * 3 + 1] * 3], *c = &pos[(size_t)idx[k * 3 + 2] * 3];
-        out.tris[(size_t)i * 3 + 0] = F4{ a[0], a[1], a[2], bits_f(k) };
-        out.tris[(size_t)i * 3 + 1] = F4{ b[0] - a[0], b[1] - a[1], b[2] - a[2], bits_f(masks[k]) };
-        out.tris[(size_t)i * 3 + 2] = F4{ c[0] - a[0], c[1] - a[1], c[2] - a[2], 0.f };
+        out.tris[(size_t)r * 3 + 0] = F4{ a[0], a[1], a[2], bits_f(k) };
+        out.tris[(size_t)r * 3 + 1] = F4{ b[0] - a[0], b[1] - a[1], b[2] - a[2], bits_f(masks[k]) };
+        out.tris[(size_t)r * 3 + 2] = F4{ c[0] - a[0], c[1] - a[1], c[2] - a[2], 0.f };
+    };
+    for (uint32_t i = 0; i < n_prims; ++i) {
+        put_rec(rec_first[i], B.prims[i].id);
+        if (B.prims[i].id2 != ~0u) { put_rec(rec_first[i] + 1u, B.prims[i].id2); out.quad[rec_first[i]] = 1; ++out.n_quads; }
     }
 
     auto padded = [&](Box b) { for (int a = 0; a < 3; ++a) { b.lo[a] -= pad; b.hi[a] += pad; } return b; };
-    auto leaf_ref = [](uint32_t first, uint32_t count) { return ~(int32_t)((first << 3) | (count - 1)); };
+    // leaf over the prims [first, first + count): a quad leaf (one quad prim) or 1..7 single triangles
+    auto leaf_ref = [&](uint32_t first, uint32_t count) {
+        const uint32_t r0 = rec_first[first], nrec = rec_first[first + count] - r0;
+        const bool q = count == 1u && B.prims[first].id2 != ~0u;
+        return ~(int32_t)((r0 << 3) | (q ? kLeafQuad : nrec - 1u));
+    };
     auto put = [&](uint32_t di, const Box &b0, int32_t r0, const Box &b1, int32_t r1) {
         F4 *n = &out.nodes[(size_t)di * 4];
         n[0] = F4{ b0.lo[0], b0.hi[0], b0.lo[1], b0.hi[1] };
@@ -252,10 +296,10 @@ void build_bvh(const float *pos, const uint32_t *idx, const uint32_t *masks, uin
         if (ntris == 0) {
             out.tris.assign(3, F4{ 0, 0, 0, 0 });
             Box z; const float o[3] = { 0, 0, 0 }; z.grow(o);
-            put(0, z, leaf_ref(0, 1), z, leaf_ref(0, 1));
+            put(0, z, ~(int32_t)0, z, ~(int32_t)0);   // (record 0, one triangle)
         } else {
             const Box b = padded(B.nodes[root].box);
-            const uint32_t n0 = (ntris + 1) / 2, n1 = ntris - n0;
+            const uint32_t n0 = (n_prims + 1) / 2, n1 = n_prims - n0;
             put(0, b, leaf_ref(0, n0), b, n1 ? leaf_ref(n0, n1) : leaf_ref(0, n0));
         }
     } else {

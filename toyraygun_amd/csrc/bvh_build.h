@@ -17,14 +17,28 @@ struct F4 { float x, y, z, w; };
 //    n[1] = (c1.lo.x, c1.hi.x, c1.lo.y, c1.hi.y)
 //    n[2] = (c0.lo.z, c0.hi.z, c1.lo.z, c1.hi.z)
 //    n[3] = (bits child0, bits child1, 0, 0)   child >= 0: inner node index
-//                                               child <  0: leaf, ~child = (firstTri << 3) | (count-1)
+//                                               child <  0: leaf, ~child = (firstTri << 3) | (count-1), count <= 7;
+//                                               (firstTri << 3) | 7 = a QUAD leaf (round 4): records firstTri and firstTri + 1 are the two
+//                                               triangles of a parallelogram (leaf_count / kLeafQuad below)
 //  every node has two children; the root is always an inner node (bvh_build.cpp synthesises one).
 //  triangle record k (leaf order) = 3 x float4 (48 B):
 //    t[0] = (v0.xyz, bits primitiveIndex)  t[1] = (e1.xyz, bits mask)  t[2] = (e2.xyz, 0)
 //  wide node i (scenes kept in HBM) = 8 x float4 (128 B, one cache line), four children, SoA:
 //    w[0..5] = lo.x[4], hi.x[4], lo.y[4], hi.y[4], lo.z[4], hi.z[4]   w[6] = (bits child0..3)   w[7] = padding
 //    child encoding as above; an unused slot holds 0x80000000 and is never entered.
+// QUAD leaves (round 4).  The reference's shapes are made of quads -- addPlane / addAreaLight / every cube face are two triangles that share an
+// edge and span a parallelogram (Scene.cpp:24-92) -- and the shipped build's plane form tests a parallelogram as cheaply as a triangle.  The
+// builder pairs such triangles (consecutive in the index buffer, sharing their first vertex and one more, fourth corner = the sum of the
+// other two to a few ulps, equal material), treats a pair as ONE primitive and gives it a leaf of its own, marked by the count field 7.
+// Its two records are stored X first, Y second such that in the coordinates  P = p0 + s * X.e1 + t * Y.e2  triangle X is the half s >= t with
+// weights (u, v) = (s - t, t) and triangle Y the half t > s with (u, v) = (s, t - s).  The strict build (and anything that walks the tree
+// without knowing) tests the two triangles one after the other: kLeafQuad = a count of 2.
+constexpr uint32_t kLeafQuad = 7u;
+inline uint32_t leaf_count(uint32_t code) { return (code & 7u) == kLeafQuad ? 2u : (code & 7u) + 1u; }
+
 struct Bvh {
+    std::vector<uint8_t> quad;   // per triangle record: 1 = record X of a quad leaf (the next record is its Y)
+    uint32_t n_quads = 0;
     std::vector<F4> nodes;   // 4 per node (BVH2)
     std::vector<F4> nodes4;  // 8 per node (BVH4 collapse of the same tree), float boxes: what the quantiser and the tests see
     std::vector<uint32_t> nodes4q;  // 16 dwords per node: the quantised 64-byte form the HBM kernels traverse (q4node.h)

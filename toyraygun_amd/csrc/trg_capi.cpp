@@ -149,9 +149,12 @@ static void fill_fat_record(unsigned char *dst, const F4 *rec48, const float *nr
 // n1 = (e2 x n) / (e1 . (e2 x n)), d1 = -n1 . v0  (u = n1 . P + d1 = weight of vertex 1);  n2 = (n x e1) / (e2 . (n x e1)), d2 = -n2 . v0
 // (v = weight of vertex 2).  A degenerate triangle gets planes no ray passes (u = -1).  meta = (original index << 2) | (material id & 3):
 // rays carry mask 3 (primary) or 1 (secondary), so the two low bits of the material id are all the mask test ever sees.
-static void fill_plane_record(unsigned char *dst, uint16_t *meta, const F4 *rec48, const float *center) {
+static void fill_plane_record(unsigned char *dst, uint16_t *meta, const F4 *rec48, const float *center, const F4 *quad_y = nullptr) {
     // (relative to `center`: SceneDesc::center -- the ray origin is shifted by it too, trg_device.h trav_begin)
-    const double v0[3] = { (double)rec48[0].x - center[0], (double)rec48[0].y - center[1], (double)rec48[0].z - center[2] }, e1[3] = { rec48[1].x, rec48[1].y, rec48[1].z }, e2[3] = { rec48[2].x, rec48[2].y, rec48[2].z };
+    // quad_y: this record is the X of a QUAD leaf (bvh_build.h) and quad_y its Y record: the planes are the parallelogram's --
+    // P = p0 + s X.e1 + t Y.e2 -- so that ONE test decides both triangles (s >= t: X with weights (s - t, t); t > s: Y with (s, t - s))
+    const F4 &second = quad_y ? quad_y[2] : rec48[2];
+    const double v0[3] = { (double)rec48[0].x - center[0], (double)rec48[0].y - center[1], (double)rec48[0].z - center[2] }, e1[3] = { rec48[1].x, rec48[1].y, rec48[1].z }, e2[3] = { second.x, second.y, second.z };
     auto cross = [](const double *a, const double *b, double *o) { o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; };
     auto dot = [](const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
     double n[3], a1[3], a2[3];
@@ -180,10 +183,10 @@ static void fill_plane_record(unsigned char *dst, uint16_t *meta, const F4 *rec4
 
 // The shipped build's 128-byte leaf record: rows 0..2 the three planes (fill_plane_record), the attributes where fill_fat_record puts them,
 // the original index and the material id in the last two words.
-static void fill_fat_record_planes(unsigned char *dst, const F4 *rec48, const float *nrm, const float *col, uint32_t n_tris, const float *center) {
+static void fill_fat_record_planes(unsigned char *dst, const F4 *rec48, const float *nrm, const float *col, uint32_t n_tris, const float *center, const F4 *quad_y) {
     fill_fat_record(dst, rec48, nrm, col, n_tris);
     uint16_t meta;
-    fill_plane_record(dst, &meta, rec48, center);
+    fill_plane_record(dst, &meta, rec48, center, quad_y);
     memcpy(dst + 120, &rec48[0].w, 4);   // float 30: original index
     memcpy(dst + 124, &rec48[1].w, 4);   // float 31: material id = mask
 }
@@ -719,7 +722,9 @@ int host_scene_build(trg_ctx *c, const float *pos, const float *nrm, const float
     }
     if (lds_candidate) {
         memcpy(&host[sc.off_tris], bvh.tris.data(), bvh.tris.size() * sizeof(F4));
-        for (uint32_t i = 0; i < nt_rec; ++i) fill_plane_record(&host[sc.off_tris_alt + (size_t)i * 48u], reinterpret_cast<uint16_t *>(&host[sc.off_meta]) + i, &bvh.tris[(size_t)i * 3], sc.center);
+        for (uint32_t i = 0; i < nt_rec; ++i)
+            fill_plane_record(&host[sc.off_tris_alt + (size_t)i * 48u], reinterpret_cast<uint16_t *>(&host[sc.off_meta]) + i, &bvh.tris[(size_t)i * 3], sc.center,
+                              (i < bvh.quad.size() && bvh.quad[i]) ? &bvh.tris[(size_t)(i + 1) * 3] : nullptr);
         if (n_tris) {
             memcpy(&host[sc.off_normals], nrm, (size_t)n_tris * 36);
             memcpy(&host[sc.off_colors], col, (size_t)n_tris * 36);
@@ -728,7 +733,8 @@ int host_scene_build(trg_ctx *c, const float *pos, const float *nrm, const float
     }
     for (uint32_t i = 0; i < nt_rec; ++i) {
         fill_fat_record(&host[sc.off_fat + (size_t)i * kFatRecBytes], &bvh.tris[(size_t)i * 3], nrm, col, n_tris);
-        fill_fat_record_planes(&host[sc.off_fat_planes + (size_t)i * kFatRecBytes], &bvh.tris[(size_t)i * 3], nrm, col, n_tris, sc.center);
+        fill_fat_record_planes(&host[sc.off_fat_planes + (size_t)i * kFatRecBytes], &bvh.tris[(size_t)i * 3], nrm, col, n_tris, sc.center,
+                               (i < bvh.quad.size() && bvh.quad[i]) ? &bvh.tris[(size_t)(i + 1) * 3] : nullptr);
     }
     if (lds_candidate) {  // Halton group tables (trg_kernels.h kHtab)
         float *T = reinterpret_cast<float *>(&host[sc.off_htab]);
@@ -1358,7 +1364,8 @@ int trg_debug_plane_records(const float *positions3, const uint32_t *indices, co
     if (planes12_out || meta_out) {
         if (records_cap < nrec || !planes12_out || !meta_out) return TRG_ERR_RANGE;
         for (uint32_t i = 0; i < nrec; ++i)
-            fill_plane_record(reinterpret_cast<unsigned char *>(planes12_out) + (size_t)i * 48u, meta_out + i, &bvh.tris[(size_t)i * 3], ctr);
+            fill_plane_record(reinterpret_cast<unsigned char *>(planes12_out) + (size_t)i * 48u, meta_out + i, &bvh.tris[(size_t)i * 3], ctr,
+                              (i < bvh.quad.size() && bvh.quad[i]) ? &bvh.tris[(size_t)(i + 1) * 3] : nullptr);
     }
     return TRG_OK;
 }

@@ -554,6 +554,23 @@ TRG_DEV bool tri_test_planes(const v4f a, const v4f b, const v4f c, V3 o, V3 d, 
     v = c.x * P.x + (c.y * P.y + (c.z * P.z + c.w));
     return (u >= 0.0f) && (v >= 0.0f) && ((u + v) <= 1.0f) && (t >= 0.0f) && (t <= tmax_ray);
 }
+// The same planes for a QUAD leaf (bvh_build.h): a / b / c are the parallelogram's -- P = p0 + s X.e1 + t Y.e2 -- and ONE test decides both
+// triangles: inside iff 0 <= s, t <= 1; s >= t is triangle X (record `first`) with weights (u, v) = (s - t, t), t > s triangle Y (the next
+// record) with (s, t - s).  `second` says which.  quad = false: the plain triangle test (inside iff s + t <= 1).
+TRG_DEV bool tri_test_planes_quad(const v4f a, const v4f b, const v4f c, V3 o, V3 d, float tmax_ray, bool quad, float &t, float &u, float &v, bool &second) {
+    const float den = a.x * d.x + a.y * d.y + a.z * d.z;
+    const float q = a.x * o.x + (a.y * o.y + (a.z * o.z - a.w));
+    t = -q * rcp_fast(den);
+    const V3 P = mk(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);
+    const float s0 = b.x * P.x + (b.y * P.y + (b.z * P.z + b.w));
+    const float t0 = c.x * P.x + (c.y * P.y + (c.z * P.z + c.w));
+    second = quad && (s0 < t0);
+    const bool in = (s0 >= 0.0f) && (t0 >= 0.0f) && (quad ? ((s0 <= 1.0f) && (t0 <= 1.0f)) : ((s0 + t0) <= 1.0f));
+    u = second ? s0 : (quad ? s0 - t0 : s0);
+    v = second ? t0 - s0 : t0;
+    return in && (t >= 0.0f) && (t <= tmax_ray);
+}
+constexpr uint32_t kLeafQuad = 7u;   // bvh_build.h: the count field of a QUAD leaf (two triangles of a parallelogram, X then Y)
 // the build's triangle test on an LDS-resident scene: planes + the u16 per record (shipped), or the Moeller-Trumbore rows (strict)
 constexpr bool kTriPlanes = !TRG_STRICT && TRG_TRI_PLANES;
 // ... and on a scene traversed from HBM: the leaf records of SceneDesc::off_fat_planes (rows 0..2 planes, words 30 / 31 index and mask)
@@ -794,17 +811,37 @@ TRG_DEV bool trav_tri_planes(const v4f a, const v4f b, const v4f c, uint32_t met
     tv.hit.v = take ? v : tv.hit.v;
     return any && ok;
 }
+// a QUAD leaf of an LDS-resident scene: one parallelogram test for the two records starting at `rec`
+template <bool COUNT>
+TRG_DEV bool trav_quad_planes(const SceneView &sc, const v4f *tr, uint32_t rec, Trav &tv, bool any, Counters &cnt) {
+    const uint32_t meta0 = sc.meta[rec];
+    const bool masked_in = (meta0 & tv.rmask) != 0u;   // (the two triangles of a quad have one material)
+    if (COUNT) { if (masked_in) cnt.tris++; if (mbcnt64(__ballot(1)) == 0) cnt.wtris++; }
+    float t, u, v;
+    bool second;
+    const bool ok = tri_test_planes_quad(tr[0], tr[1], tr[2], tv.o, tv.d, tv.best, true, t, u, v, second) && masked_in;
+    const int prim = (int)((second ? (uint32_t)sc.meta[rec + 1u] : meta0) >> 2);
+    const bool take = ok && (any || !tv.found || t < tv.best || (t == tv.best && prim < tv.hit.prim));
+    tv.found = tv.found || ok;
+    tv.best = take ? t : tv.best;
+    tv.hit.prim = take ? prim : tv.hit.prim;
+    tv.hit.u = take ? u : tv.hit.u;
+    tv.hit.v = take ? v : tv.hit.v;
+    return any && ok;
+}
 // ... and on a leaf RECORD of an HBM-resident scene (the hit keeps the record index; ties go to the lower original index, read back from the
 // held record only then): mask and prim are the record's last two words
 template <bool COUNT>
-TRG_DEV bool trav_tri_planes_rec(const v4f a, const v4f b, const v4f c, uint32_t mask, int prim, Trav &tv, bool any, Counters &cnt, uint32_t rec, const v4f *recs, V3 center) {
+TRG_DEV bool trav_tri_planes_rec(const v4f a, const v4f b, const v4f c, uint32_t mask, int prim, Trav &tv, bool any, Counters &cnt, uint32_t rec, const v4f *recs, V3 center, bool quad) {
     const bool masked_in = (mask & tv.rmask) != 0u;
     if (COUNT) { if (masked_in) cnt.tris++; if (mbcnt64(__ballot(1)) == 0) cnt.wtris++; }
     float t, u, v;
-    const bool ok = tri_test_planes(a, b, c, tv.o - center, tv.d, tv.best, t, u, v) && masked_in;   // (Trav::o is the path's origin here: trav_begin)
+    bool second;   // quad leaf: the hit lies in the SECOND triangle of the parallelogram (the next record)
+    const bool ok = tri_test_planes_quad(a, b, c, tv.o - center, tv.d, tv.best, quad, t, u, v, second) && masked_in;   // (Trav::o is the path's origin here: trav_begin)
+    rec += second ? 1u : 0u;
     const bool closer = any || !tv.found || t < tv.best;
     bool take = ok && closer;
-    if (ok && !closer && t == tv.best) take = prim < fat_prim(recs, (uint32_t)tv.hit.prim);
+    if (ok && !closer && t == tv.best) take = (second ? fat_prim(recs, rec) : prim) < fat_prim(recs, (uint32_t)tv.hit.prim);
     tv.found = tv.found || ok;
     tv.best = take ? t : tv.best;
     tv.hit.prim = take ? (int)rec : tv.hit.prim;
@@ -835,8 +872,10 @@ TRG_DEV const v4f *lds_records(const SceneView &sc, uint32_t first) {
 template <bool COUNT>
 TRG_DEV bool trav_leaf_test(const SceneView &sc, Trav &tv, int leaf, bool any, Counters &cnt) {
     const uint32_t code = (uint32_t)~leaf;
-    const uint32_t first = code >> 3, count = (code & 7u) + 1u;
+    const bool quad = (code & 7u) == kLeafQuad;
+    const uint32_t first = code >> 3, count = quad ? 2u : (code & 7u) + 1u;
     const v4f *tr = lds_records(sc, first);
+    if (kTriPlanes && quad) return trav_quad_planes<COUNT>(sc, tr, first, tv, any, cnt);
     bool stop = trav_tri_lds<COUNT>(sc, tr, first, tv, any, cnt);
     if (!stop && count > 1u) stop = trav_tri_lds<COUNT>(sc, tr + 3, first + 1u, tv, any, cnt);
     for (uint32_t k = 2; k < count && !stop; ++k) stop = trav_tri_lds<COUNT>(sc, tr + k * 3, first + k, tv, any, cnt);
@@ -846,13 +885,18 @@ TRG_DEV bool trav_leaf_test(const SceneView &sc, Trav &tv, int leaf, bool any, C
 template <bool COUNT, int BLOCK, typename STK>
 TRG_DEV bool trav_leaf_step(const SceneView &sc, Trav &tv, bool any, STK stk, Counters &cnt) {
     const uint32_t code = (uint32_t)~tv.node;
-    const uint32_t first = code >> 3, count = (code & 7u) + 1u;
+    const bool quad = (code & 7u) == kLeafQuad;   // the two triangles of a parallelogram (bvh_build.h): ONE plane test in the shipped build
+    const uint32_t first = code >> 3, count = quad ? 2u : (code & 7u) + 1u;
     bool stop = false;
-    {   // leaves of the host builder hold one or two triangles: those without a loop (-2 %); more only from other builders
+    {   // leaves of the host builder hold a quad, or one or two triangles: those without a loop (-2 %); more only from other builders
         const v4f *tr = lds_records(sc, first);
-        stop = trav_tri_lds<COUNT>(sc, tr, first, tv, any, cnt);
-        if (!stop && count > 1u) stop = trav_tri_lds<COUNT>(sc, tr + 3, first + 1u, tv, any, cnt);
-        for (uint32_t k = 2; k < count && !stop; ++k) stop = trav_tri_lds<COUNT>(sc, tr + k * 3, first + k, tv, any, cnt);
+        if (kTriPlanes && quad) {
+            stop = trav_quad_planes<COUNT>(sc, tr, first, tv, any, cnt);
+        } else {
+            stop = trav_tri_lds<COUNT>(sc, tr, first, tv, any, cnt);
+            if (!stop && count > 1u) stop = trav_tri_lds<COUNT>(sc, tr + 3, first + 1u, tv, any, cnt);
+            for (uint32_t k = 2; k < count && !stop; ++k) stop = trav_tri_lds<COUNT>(sc, tr + k * 3, first + k, tv, any, cnt);
+        }
     }
     const int sp = tv.sp - STK::unit;
     tv.node = stk.pop(sp);
@@ -987,13 +1031,18 @@ TRG_DEV void trav_step_wide(const SceneView &sc, Trav &tv, bool any, STK stk, Co
     if (inner) {
         trav_node4_math<COUNT, BLOCK>(q0, q1, q2, q3, tv, stk, cnt);
     } else {
-        const bool stop = kRecPlanes ? trav_tri_planes_rec<COUNT>(q0, q1, q2, (uint32_t)__float_as_int(q3.w), __float_as_int(q3.z), tv, any, cnt, first, sc.tris, sc.center)
+        // a QUAD leaf (count field 7, bvh_build.h): the shipped build decides both triangles with one parallelogram test; the strict build
+        // tests record `first`, then advances to the single-triangle code of record first + 1
+        const bool quad = left == kLeafQuad;
+        const bool stop = kRecPlanes ? trav_tri_planes_rec<COUNT>(q0, q1, q2, (uint32_t)__float_as_int(q3.w), __float_as_int(q3.z), tv, any, cnt, first, sc.tris, sc.center, quad)
                                      : trav_tri_math<COUNT, true>(q0, q1, q2, tv, any, cnt, first, sc.tris);
-        const bool more = left != 0u;
+        const bool more = kRecPlanes ? (left != 0u && !quad) : (left != 0u);
         const bool do_pop = !stop && !more;
         const int sp = tv.sp - (do_pop ? STK::unit : 0);
         const int popped = stk.pop(sp);  // the sentinel at level 0 when nothing is pending
-        const int advanced = tv.node - 7;   // ~(((first + 1) << 3) | (left - 1)) for left >= 1: the next triangle of the leaf
+        // the next triangle of the leaf: ~(((first + 1) << 3) | (left - 1)) = node - 7 for left >= 1; after the first triangle of a quad
+        // (strict build) ~(((first + 1) << 3) | 0) = node - 1
+        const int advanced = tv.node - ((!kRecPlanes && quad) ? 1 : 7);
         tv.node = stop ? kNodeDone : (more ? advanced : popped);
         tv.sp = sp;
     }
