@@ -24,8 +24,19 @@ for case in range(cases):
         if n > 10:
             tri[n // 2: n // 2 + n // 10] = tri[: n // 10]
         mats = rng.choice([1, 1, 1, 2, 3], n)
+        quads = rng.random(n) < rng.choice([0.0, 0.3, 0.8])     # (round 4: parallelograms in both index patterns of the reference's shapes -> quad leaves)
+        if n > 10:
+            quads[n // 2: n // 2 + n // 10] = quads[: n // 10]     # an exact duplicate of a parallelogram is a parallelogram (a lone triangle that
+            # duplicates HALF of a quad would z-fight in the shipped build: the quad's plane and the triangle's round t differently -- DESIGN.md)
         for k in range(n):
-            s.add_geometry(tri[k], [0, 1, 2], eye, rng.uniform(0.2, 0.9, 3), int(mats[k]))
+            if quads[k]:
+                p4 = np.concatenate([tri[k], (tri[k][0] + (tri[k][2] - tri[k][1]))[None, :]]).astype(np.float32)      # a, b, c, d = a + (c - b)
+                if rng.random() < 0.5:
+                    s.add_geometry(p4, [0, 1, 2, 0, 2, 3], eye, rng.uniform(0.2, 0.9, 3), int(mats[k]))
+                else:
+                    s.add_geometry(p4, [0, 2, 3, 0, 1, 2], eye, rng.uniform(0.2, 0.9, 3), int(mats[k]))      # (a, c, d)(a, b, c): the second is X
+            else:
+                s.add_geometry(tri[k], [0, 1, 2], eye, rng.uniform(0.2, 0.9, 3), int(mats[k]))
     w, h = int(rng.integers(1, 90)), int(rng.integers(1, 70))
     if FAST:
         w, h = max(w, 32), max(h, 32)

@@ -1910,9 +1910,10 @@ def test_plugin_on_a_device_group(capi, O, monkeypatch):
     assert np.array_equal(_bits(grouped), _bits(plain))
     lattice = host.Scene.cornell_lattice(12)     # 20,772 triangles: lives in HBM
     ref, _ = host.render_scene(lattice, 160, 120, 4, 3)
+    ref_dev, _ = host.render_scene(lattice, 160, 120, 4, 3, device_build=1)     # (the device builders make no quad leaves: another rounding of the same hits)
     for builder in (0, 1):
         got, _ = host.render_scene(lattice, 160, 120, 4, 3, device_build=builder, devices=[0])
-        assert np.array_equal(_bits(got), _bits(ref)), builder
+        assert np.array_equal(_bits(got), _bits(ref_dev if builder else ref)), builder
     v, n, col, tris = _uv_sphere(12, 8, 0.33, (0.25, 1.1, 0.15))
     uv = np.array([[p, t] for t in np.linspace(0.0, 1.0, 9) for p in np.linspace(0.0, 3.0, 12, endpoint=False)], np.float32)
     tex = host.Texture(rgba=_checker_texture(64, 8, (230, 60, 40), (40, 90, 220), 1))
@@ -1931,7 +1932,7 @@ def test_plugin_on_a_device_group(capi, O, monkeypatch):
     grouped3, _ = host.async_camera_move(w, h, fa, fb, eye_b, bnc, devices=[0, 0, 0])
     assert np.array_equal(_bits(grouped3), _bits(plain))
     got, _ = host.render_scene(lattice, 160, 120, 4, 3, device_build=1, devices=[0, 0])
-    assert np.array_equal(_bits(got), _bits(ref))
+    assert np.array_equal(_bits(got), _bits(ref_dev))
     b3, _ = host.render_scene(hs, 160, 120, 3, 3, devices=[0, 0, 0])
     assert np.array_equal(_bits(a), _bits(b3))
 

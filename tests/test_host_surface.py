@@ -257,6 +257,70 @@ def test_bvh_builder_is_sound(built, O):
     assert (seen == 1).all() and d2 <= 12
 
 
+def _quad_leaves(nodes):
+    refs = nodes[:, 12:14].copy().view(np.int32).reshape(-1)
+    return sorted((~int(r)) >> 3 for r in refs if r < 0 and ((~int(r)) & 7) == 7)
+
+
+def test_builder_pairs_parallelograms_into_quad_leaves(built, O):
+    """Round 4: two consecutive triangles that share their first vertex and the diagonal, of one material, whose fourth corner is where
+    a parallelogram has it become ONE primitive with a leaf of its own (count field 7), stored X first (the half s >= t), Y second --
+    both index patterns of the reference's shapes (Scene.cpp:37-55 cube faces (a,b,c)(a,c,d); :60-92 planes / light (a,b,c)(a,d,b)).
+    Everything else stays triangles: trapezoids, different materials, a shared edge that is not the diagonal, zero area, a bent
+    pair, and the whole feature with TRG_BVH_QUADS=0."""
+    from toyraygun_amd import capi
+    a, b, c, d = (np.array(v, np.float32) for v in ([0.25, 0.5, 1], [1.25, 0.5, 1.5], [1.5, 1.75, 1.25], [0.5, 1.75, 0.75]))   # d = a + (c - b)
+    far = np.array([5, 5, 5], np.float32)       # (a third primitive, so that the tree has more than the synthesised root)
+    extra = [far, far + [1, 0, 0], far + [0, 1, 0]]
+
+    def build(tris, mats=None):
+        pos = np.array([v for t in tris for v in t] + extra, np.float32)
+        n = len(tris) + 1
+        return capi.debug_build_bvh(pos, np.arange(3 * n, dtype=np.uint32), np.array((mats or [1] * len(tris)) + [1], np.uint32))
+
+    for pattern, x_id in (([(a, b, c), (a, c, d)], 0), ([(a, b, c), (a, d, b)], 1)):
+        if x_id == 1:
+            # pattern 2: (a, b', c')(a, d', b') with the diagonal b': a parallelogram a, d', b', c' -> c' = b' + ... choose b' = c, d' = b, c' = d
+            pattern = [(a, c, d), (a, b, c)]
+        nodes, tris, _ = build(pattern)
+        q = _quad_leaves(nodes)
+        assert len(q) == 1
+        X, Y = tris[q[0]], tris[q[0] + 1]
+        assert int(X[3:4].view(np.int32)[0]) == x_id and int(Y[3:4].view(np.int32)[0]) == 1 - x_id
+        assert np.array_equal(X[0:3], a) and np.array_equal(Y[0:3], a)
+        assert np.array_equal(X[8:11], Y[4:7])                             # X.e2 = Y.e1 = the diagonal
+        assert np.allclose(X[4:7] + Y[8:11], X[8:11], atol=1e-6)           # X.e1 + Y.e2 = the diagonal
+        seen, _ = _walk(nodes, tris, 3)
+        assert (seen == 1).all()
+    bent = d + np.array([0, 0, 0.01], np.float32)
+    for tris, mats in (([(a, b, c), (a, c, d + np.array([0.1, 0, 0], np.float32))], None),     # a trapezoid
+                       ([(a, b, c), (a, c, bent)], None),                                     # not planar
+                       ([(a, b, c), (a, c, d)], [1, 2]),                                      # two materials
+                       ([(a, b, c), (b, c, d)], None),                                        # no common first vertex
+                       ([(a, b, c), (a, b, d)], None),                                        # the shared edge is not the diagonal
+                       ([(a, b, a + 2 * (b - a)), (a, a + 2 * (b - a), a + (b - a))], None)): # zero area
+        nodes, recs, _ = build(tris, mats)
+        assert _quad_leaves(nodes) == []
+        assert (_walk(nodes, recs, 3)[0] == 1).all()
+    # a chain: (k, k+1) pair, k+2 pairs with k+1 too -- the first pair wins, k+2 stays a triangle
+    e = a + (d - a) + (d - a) - (c - b) * 0      # any point: (a, d, e') below is built so that (a,c,d)(a,d,e') is a parallelogram too
+    e2 = a + (d - a) + ((d - a) - (c - a))
+    nodes, recs, _ = build([(a, b, c), (a, c, d), (a, d, e2)])
+    assert len(_quad_leaves(nodes)) == 1 and (_walk(nodes, recs, 4)[0] == 1).all()
+    os.environ["TRG_BVH_QUADS"] = "0"
+    try:
+        nodes, recs, _ = build([(a, b, c), (a, c, d)])
+        assert _quad_leaves(nodes) == [] and (_walk(nodes, recs, 3)[0] == 1).all()
+        box = O.OracleScene.cornell_box().buffers()
+        assert _quad_leaves(capi.debug_build_bvh(box["positions"], box["indices"], box["material_ids"])[0]) == []
+    finally:
+        del os.environ["TRG_BVH_QUADS"]
+    # the reference's own shapes are quads throughout
+    for scene in (O.OracleScene.cornell_box(), O.OracleScene.cornell_lattice(3)):
+        bf = scene.buffers()
+        assert len(_quad_leaves(capi.debug_build_bvh(bf["positions"], bf["indices"], bf["material_ids"])[0])) == scene.ntris // 2
+
+
 def test_wide_bvh_is_sound(built, O):
     """The 4-wide collapse reaches every triangle exactly once, boxes enclose their subtrees, and the stack
     bound the kernel sizes its scratch from (3 * depth + 2) holds."""

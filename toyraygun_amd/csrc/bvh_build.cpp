@@ -144,7 +144,7 @@ inline float bits_f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 void build_bvh(const float *pos, const uint32_t *idx, const uint32_t *masks, uint32_t ntris, Bvh &out) {
     if (const char *e = getenv("TRG_BVH_MAXLEAF")) kMaxLeaf = (uint32_t)std::min(7, std::max(1, atoi(e)));
     if (const char *e = getenv("TRG_BVH_TRAVCOST")) kTravCost = (float)atof(e);
-    if (const char *e = getenv("TRG_BVH_QUADS")) kQuads = atoi(e) != 0;
+    { const char *e = getenv("TRG_BVH_QUADS"); kQuads = !e || atoi(e) != 0; }   // (read per build: the tests switch it)
     Builder B;
     std::vector<Prim> prim_store(ntris);
     B.prims = prim_store.data();
