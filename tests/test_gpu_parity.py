@@ -1278,23 +1278,27 @@ def test_plugin_device_build(capi, O):
     """HipRenderer::setDeviceBuild: the acceleration structure of the next loadScene is built on the device (the reference rebuilds
     its MPS structure on the GPU, MetalRenderer.mm:272-279).  The image does not depend on the tree -- host SAH, device SAH,
     LBVH and PLOC give the same accumulation buffer bit for bit (shipped build) -- and a scene that fits LDS ignores the option.
-    (Round 4: the host builder pairs the triangles of a parallelogram into QUAD leaves, which the shipped build decides with one
-    plane test -- a different rounding of the same hit: bit-equal to the device builders with TRG_BVH_QUADS=0, within the shipped
-    build's tolerance with quads.)"""
+    (Round 4: all four builders pair the triangles of a parallelogram into QUAD leaves, which the shipped build decides with one
+    plane test -- a different rounding of the same hit than two triangle tests: with TRG_BVH_QUADS=0 the four builders agree bit for
+    bit again, on an image within the shipped build's tolerance of the one with quads.)"""
     from toyraygun_amd import host
     w, h = 160, 120
     scene = host.Scene.cornell_lattice(12)     # 20,772 triangles: lives in HBM
-    os.environ["TRG_BVH_QUADS"] = "0"
-    try:
-        ref, ms_host = host.render_scene(scene, w, h, 4, 3, device_build=0)
-    finally:
-        del os.environ["TRG_BVH_QUADS"]
+    ref, ms_host = host.render_scene(scene, w, h, 4, 3, device_build=0)
     assert np.isfinite(ref).all() and ref[..., :3].max() > 0
     for builder in (1, 2, 3):
         got, ms_dev = host.render_scene(scene, w, h, 4, 3, device_build=builder)
         assert np.array_equal(_bits(got), _bits(ref)), builder
-    quads, _ = host.render_scene(scene, w, h, 4, 3, device_build=0)
-    d = np.linalg.norm(quads[..., :3].astype(np.float64) - ref[..., :3], axis=-1)
+    os.environ["TRG_BVH_QUADS"] = "0"
+    try:
+        plain, _ = host.render_scene(scene, w, h, 4, 3, device_build=0)
+        for builder in (1, 2, 3):
+            got, _ = host.render_scene(scene, w, h, 4, 3, device_build=builder)
+            assert np.array_equal(_bits(got), _bits(plain)), builder
+    finally:
+        del os.environ["TRG_BVH_QUADS"]
+    assert not np.array_equal(_bits(plain), _bits(ref))
+    d = np.linalg.norm(plain[..., :3].astype(np.float64) - ref[..., :3], axis=-1)
     inl = d <= 1e-4 * np.maximum(1.0, np.linalg.norm(ref[..., :3].astype(np.float64), axis=-1))
     assert inl.mean() >= 0.999 and np.sqrt(np.mean((d * d)[inl])) <= 1e-3, (inl.mean(), d.max())
     box = host.Scene.cornell_box()
@@ -1910,10 +1914,9 @@ def test_plugin_on_a_device_group(capi, O, monkeypatch):
     assert np.array_equal(_bits(grouped), _bits(plain))
     lattice = host.Scene.cornell_lattice(12)     # 20,772 triangles: lives in HBM
     ref, _ = host.render_scene(lattice, 160, 120, 4, 3)
-    ref_dev, _ = host.render_scene(lattice, 160, 120, 4, 3, device_build=1)     # (the device builders make no quad leaves: another rounding of the same hits)
     for builder in (0, 1):
         got, _ = host.render_scene(lattice, 160, 120, 4, 3, device_build=builder, devices=[0])
-        assert np.array_equal(_bits(got), _bits(ref_dev if builder else ref)), builder
+        assert np.array_equal(_bits(got), _bits(ref)), builder
     v, n, col, tris = _uv_sphere(12, 8, 0.33, (0.25, 1.1, 0.15))
     uv = np.array([[p, t] for t in np.linspace(0.0, 1.0, 9) for p in np.linspace(0.0, 3.0, 12, endpoint=False)], np.float32)
     tex = host.Texture(rgba=_checker_texture(64, 8, (230, 60, 40), (40, 90, 220), 1))
@@ -1932,7 +1935,7 @@ def test_plugin_on_a_device_group(capi, O, monkeypatch):
     grouped3, _ = host.async_camera_move(w, h, fa, fb, eye_b, bnc, devices=[0, 0, 0])
     assert np.array_equal(_bits(grouped3), _bits(plain))
     got, _ = host.render_scene(lattice, 160, 120, 4, 3, device_build=1, devices=[0, 0])
-    assert np.array_equal(_bits(got), _bits(ref_dev))
+    assert np.array_equal(_bits(got), _bits(ref))
     b3, _ = host.render_scene(hs, 160, 120, 3, 3, devices=[0, 0, 0])
     assert np.array_equal(_bits(a), _bits(b3))
 

@@ -141,34 +141,52 @@ inline float bits_f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 
 }  // namespace
 
+// Quads: triangles k and k + 1 with the same first vertex, one more shared vertex, equal material, and the fourth corner where a
+// parallelogram has it.  Pattern 1 (cube faces, Scene.cpp:37-55): (a, b, c) (a, c, d) -- X = k, Y = k + 1.  Pattern 2 (planes and the
+// light, Scene.cpp:60-92): (a, b, c) (a, d, b) -- X = k + 1, Y = k.  In both, X = (a, p1, diag), Y = (a, diag', p3) with diag = p1 + p3 - a.
+bool quad_pair(const float *pos, const uint32_t *idx, const uint32_t *masks, uint32_t ntris, uint32_t k, uint32_t &x, uint32_t &y) {
+    auto vtx = [&](uint32_t t, int j) { return &pos[(size_t)idx[t * 3 + j] * 3]; };
+    auto same = [](const float *p, const float *q) { return p[0] == q[0] && p[1] == q[1] && p[2] == q[2]; };
+    if (k + 1 >= ntris || masks[k] != masks[k + 1] || !same(vtx(k, 0), vtx(k + 1, 0))) return false;
+    const float *a = vtx(k, 0), *p1, *dg, *p3;
+    if (same(vtx(k, 2), vtx(k + 1, 1))) { x = k; y = k + 1; p1 = vtx(k, 1); dg = vtx(k, 2); p3 = vtx(k + 1, 2); }
+    else if (same(vtx(k, 1), vtx(k + 1, 2))) { x = k + 1; y = k; p1 = vtx(k + 1, 1); dg = vtx(k, 1); p3 = vtx(k, 2); }
+    else return false;
+    float big = 0.f;
+    for (int c = 0; c < 3; ++c) big = std::max({ big, std::fabs(a[c]), std::fabs(p1[c]), std::fabs(p3[c]), std::fabs(dg[c]) });
+    for (int c = 0; c < 3; ++c)
+        if (!(std::fabs((p1[c] - a[c]) + (p3[c] - a[c]) - (dg[c] - a[c])) <= 4e-6f * big)) return false;   // (also false for NaN)
+    const float e1[3] = { p1[0] - a[0], p1[1] - a[1], p1[2] - a[2] }, e2[3] = { p3[0] - a[0], p3[1] - a[1], p3[2] - a[2] };
+    const float n[3] = { e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0] };
+    const float area2 = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+    return area2 > 0.f && std::isfinite(area2);
+}
+
+bool quads_enabled() { const char *e = getenv("TRG_BVH_QUADS"); return !e || atoi(e) != 0; }
+
+uint32_t pair_quads(const float *pos, const uint32_t *idx, const uint32_t *masks, uint32_t ntris, std::vector<uint32_t> &px, std::vector<uint32_t> &py) {
+    px.clear(); py.clear();
+    px.reserve(ntris); py.reserve(ntris);
+    const bool on = quads_enabled();
+    uint32_t quads = 0;
+    for (uint32_t k = 0; k < ntris; ++k) {
+        uint32_t x = 0, y = 0;
+        if (on && quad_pair(pos, idx, masks, ntris, k, x, y)) { px.push_back(x); py.push_back(y); ++quads; ++k; }
+        else { px.push_back(k); py.push_back(~0u); }
+    }
+    return quads;
+}
+
 void build_bvh(const float *pos, const uint32_t *idx, const uint32_t *masks, uint32_t ntris, Bvh &out) {
     if (const char *e = getenv("TRG_BVH_MAXLEAF")) kMaxLeaf = (uint32_t)std::min(7, std::max(1, atoi(e)));
     if (const char *e = getenv("TRG_BVH_TRAVCOST")) kTravCost = (float)atof(e);
-    { const char *e = getenv("TRG_BVH_QUADS"); kQuads = !e || atoi(e) != 0; }   // (read per build: the tests switch it)
+    kQuads = quads_enabled();   // (read per build: the tests switch it)
     Builder B;
     std::vector<Prim> prim_store(ntris);
     B.prims = prim_store.data();
     Box scene;
-    // Quads: triangles k and k + 1 with the same first vertex, one more shared vertex, equal material, and the fourth corner where a
-    // parallelogram has it.  Pattern 1 (cube faces, Scene.cpp:37-55): (a, b, c) (a, c, d) -- X = k, Y = k + 1.  Pattern 2 (planes and the
-    // light, Scene.cpp:60-92): (a, b, c) (a, d, b) -- X = k + 1, Y = k.  In both, X = (a, p1, diag), Y = (a, diag', p3) with diag = p1 + p3 - a.
     auto vtx = [&](uint32_t k, int j) { return &pos[(size_t)idx[k * 3 + j] * 3]; };
-    auto same = [](const float *p, const float *q) { return p[0] == q[0] && p[1] == q[1] && p[2] == q[2]; };
-    auto quad_of = [&](uint32_t k, uint32_t &x, uint32_t &y) {
-        if (!kQuads || k + 1 >= ntris || masks[k] != masks[k + 1] || !same(vtx(k, 0), vtx(k + 1, 0))) return false;
-        const float *a = vtx(k, 0), *p1, *dg, *p3;
-        if (same(vtx(k, 2), vtx(k + 1, 1))) { x = k; y = k + 1; p1 = vtx(k, 1); dg = vtx(k, 2); p3 = vtx(k + 1, 2); }
-        else if (same(vtx(k, 1), vtx(k + 1, 2))) { x = k + 1; y = k; p1 = vtx(k + 1, 1); dg = vtx(k, 1); p3 = vtx(k, 2); }
-        else return false;
-        float big = 0.f, area2 = 0.f;
-        for (int c = 0; c < 3; ++c) big = std::max({ big, std::fabs(a[c]), std::fabs(p1[c]), std::fabs(p3[c]), std::fabs(dg[c]) });
-        for (int c = 0; c < 3; ++c)
-            if (!(std::fabs((p1[c] - a[c]) + (p3[c] - a[c]) - (dg[c] - a[c])) <= 4e-6f * big)) return false;   // (also false for NaN)
-        const float e1[3] = { p1[0] - a[0], p1[1] - a[1], p1[2] - a[2] }, e2[3] = { p3[0] - a[0], p3[1] - a[1], p3[2] - a[2] };
-        const float n[3] = { e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0] };
-        area2 = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
-        return area2 > 0.f && std::isfinite(area2);
-    };
+    auto quad_of = [&](uint32_t k, uint32_t &x, uint32_t &y) { return kQuads && quad_pair(pos, idx, masks, ntris, k, x, y); };
     uint32_t n_prims = 0;
     for (uint32_t k = 0; k < ntris; ++k) {
         Prim &p = B.prims[n_prims++];

@@ -48,6 +48,12 @@ struct Bvh {
     double sah_cost = 0.0;
 };
 
+// the pairing rule by itself (the device builders use it too): are triangles k and k + 1 the two halves of a parallelogram?  x / y = which is X, which Y
+bool quad_pair(const float *positions3, const uint32_t *indices, const uint32_t *masks, uint32_t ntris, uint32_t k, uint32_t &x, uint32_t &y);
+bool quads_enabled();   // TRG_BVH_QUADS != 0 (default on), read at every call
+// the primitives of a scene in index-buffer order: px[i] = the triangle (or the X of a quad), py[i] = the Y of a quad or ~0u; returns the number of quads
+uint32_t pair_quads(const float *positions3, const uint32_t *indices, const uint32_t *masks, uint32_t ntris, std::vector<uint32_t> &px, std::vector<uint32_t> &py);
+
 // positions3: nverts*3 floats; indices: ntris*3; masks: ntris (the reference's materialID buffer,
 // MetalRenderer.mm:276).  Deterministic for a given input.
 void build_bvh(const float *positions3, const uint32_t *indices, const uint32_t *masks, uint32_t ntris, Bvh &out);

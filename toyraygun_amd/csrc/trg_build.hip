@@ -37,15 +37,20 @@ __device__ __forceinline__ unsigned long long expand_bits21(uint32_t v) {
 }
 
 // per triangle: padded box, the sort key (63-bit Morton code of the box centre) and the sort value (triangle index)
-__global__ void prim_kernel(const float *pos, const uint32_t *idx, uint32_t ntris, float3 slo, float3 sinv, float pad,
+// (a primitive is a triangle, or -- px / py given -- the two triangles px[k], py[k] of a quad: bvh_build.h pair_quads; py[k] = ~0u: a lone triangle)
+__global__ void prim_kernel(const float *pos, const uint32_t *idx, const uint32_t *px, const uint32_t *py, uint32_t nprims, float3 slo, float3 sinv, float pad,
                             Box3 *boxes, unsigned long long *codes, uint32_t *order) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= ntris) return;
+    if (k >= nprims) return;
     Box3 b;
     for (int a = 0; a < 3; ++a) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; }
-    for (int j = 0; j < 3; ++j) {
-        const float *p = pos + (size_t)idx[k * 3 + j] * 3;
-        for (int a = 0; a < 3; ++a) { b.lo[a] = fminf(b.lo[a], p[a]); b.hi[a] = fmaxf(b.hi[a], p[a]); }
+    const uint32_t t2[2] = { px ? px[k] : k, px ? py[k] : ~0u };
+    for (int h = 0; h < 2; ++h) {
+        if (t2[h] == ~0u) continue;
+        for (int j = 0; j < 3; ++j) {
+            const float *p = pos + (size_t)idx[t2[h] * 3 + j] * 3;
+            for (int a = 0; a < 3; ++a) { b.lo[a] = fminf(b.lo[a], p[a]); b.hi[a] = fmaxf(b.hi[a], p[a]); }
+        }
     }
     const float cx = (0.5f * (b.lo[0] + b.hi[0]) - slo.x) * sinv.x;
     const float cy = (0.5f * (b.lo[1] + b.hi[1]) - slo.y) * sinv.y;
@@ -60,15 +65,29 @@ __global__ void prim_kernel(const float *pos, const uint32_t *idx, uint32_t ntri
 }
 
 // triangle records in sorted (leaf) order: (v0, prim) (e1, mask) (e2, -), same arithmetic as the host builder
-__global__ void record_kernel(const float *pos, const uint32_t *idx, const uint32_t *masks, const uint32_t *order,
-                              uint32_t ntris, float4 *tris) {
+// (quads: the primitive at sorted position r writes its X at record recbase[r] and its Y behind it, and flags the X record in quad_rec)
+__global__ void record_kernel(const float *pos, const uint32_t *idx, const uint32_t *masks, const uint32_t *order, const uint32_t *px, const uint32_t *py,
+                              const uint32_t *recbase, uint32_t nprims, float4 *tris, unsigned char *quad_rec) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= ntris) return;
-    const uint32_t k = order[r];
-    const float *a = pos + (size_t)idx[k * 3 + 0] * 3, *b = pos + (size_t)idx[k * 3 + 1] * 3, *c = pos + (size_t)idx[k * 3 + 2] * 3;
-    tris[(size_t)r * 3 + 0] = make_float4(a[0], a[1], a[2], __uint_as_float(k));
-    tris[(size_t)r * 3 + 1] = make_float4(b[0] - a[0], b[1] - a[1], b[2] - a[2], __uint_as_float(masks[k]));
-    tris[(size_t)r * 3 + 2] = make_float4(c[0] - a[0], c[1] - a[1], c[2] - a[2], 0.0f);
+    if (r >= nprims) return;
+    const uint32_t prim = order[r];
+    const uint32_t t2[2] = { px ? px[prim] : prim, px ? py[prim] : ~0u };
+    const uint32_t rec0 = recbase ? recbase[r] : r;
+    for (int h = 0; h < 2; ++h) {
+        const uint32_t k = t2[h];
+        if (k == ~0u) continue;
+        const float *a = pos + (size_t)idx[k * 3 + 0] * 3, *b = pos + (size_t)idx[k * 3 + 1] * 3, *c = pos + (size_t)idx[k * 3 + 2] * 3;
+        float4 *o = tris + (size_t)(rec0 + (uint32_t)h) * 3;
+        o[0] = make_float4(a[0], a[1], a[2], __uint_as_float(k));
+        o[1] = make_float4(b[0] - a[0], b[1] - a[1], b[2] - a[2], __uint_as_float(masks[k]));
+        o[2] = make_float4(c[0] - a[0], c[1] - a[1], c[2] - a[2], 0.0f);
+    }
+    if (quad_rec && t2[1] != ~0u) quad_rec[rec0] = 1;
+}
+// records a primitive occupies, by sorted position (the input of the exclusive scan that gives recbase)
+__global__ void prim_size_kernel(const uint32_t *order, const uint32_t *py, uint32_t nprims, uint32_t *size) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < nprims) size[r] = py[order[r]] != ~0u ? 2u : 1u;
 }
 
 // common-prefix length of sorted positions i and j; equal codes are told apart by the position itself
@@ -140,11 +159,14 @@ __global__ void refit_kernel(const Box3 *prim_boxes, const uint32_t *order, int 
 // leaves hold up to two triangles as well).  The root is exempt.
 // `root` is the BVH2 node the tree hangs from (0 for the Karras hierarchy, the last merge for PLOC); the two triangles must be
 // neighbours in the record order (always true below a Karras node, checked for PLOC merges).
-__device__ __forceinline__ bool is_pair(const int *left, const int *right, int i, int root) {
+// (quads: recbase = the first record of every sorted position, one entry past the end included; a quad -- two records -- is a leaf of its own)
+__device__ __forceinline__ bool is_quad_at(const uint32_t *recbase, uint32_t r) { return recbase && recbase[r + 1u] - recbase[r] == 2u; }
+__device__ __forceinline__ bool is_pair(const int *left, const int *right, int i, int root, const uint32_t *recbase) {
 #ifdef TRG_EXP_NO_PAIRS
     return false;
 #endif
-    return i != root && left[i] < 0 && right[i] < 0 && (~right[i]) == (~left[i]) + 1;
+    if (!(i != root && left[i] < 0 && right[i] < 0 && (~right[i]) == (~left[i]) + 1)) return false;
+    return !is_quad_at(recbase, (uint32_t)~left[i]) && !is_quad_at(recbase, (uint32_t)~right[i]);
 }
 
 // ---- greedy top-down collapse: level by level, every BVH2 node that becomes a 4-wide node
@@ -157,7 +179,7 @@ __device__ __forceinline__ float box_half_area(const Box3 &b) {
     return dx * dy + dy * dz + dz * dx;
 }
 __global__ void collapse_plan_kernel(const int *frontier, int n_cur, const int *left, const int *right, const Box3 *node_boxes,
-                                     int *slots4, uint32_t *cnt, int root) {
+                                     int *slots4, uint32_t *cnt, int root, const uint32_t *recbase) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_cur) return;
     const int i = frontier[j];
@@ -166,7 +188,7 @@ __global__ void collapse_plan_kernel(const int *frontier, int n_cur, const int *
     while (n < 4) {
         int best = -1; float best_area = -1.0f;
         for (int k = 0; k < n; ++k)
-            if (sl[k] >= 0 && !is_pair(left, right, sl[k], root)) {
+            if (sl[k] >= 0 && !is_pair(left, right, sl[k], root, recbase)) {
                 const float a = box_half_area(node_boxes[sl[k]]);
                 if (a > best_area) { best_area = a; best = k; }
             }
@@ -178,13 +200,13 @@ __global__ void collapse_plan_kernel(const int *frontier, int n_cur, const int *
     uint32_t m = 0;
     for (int k = 0; k < 4; ++k) {
         slots4[j * 4 + k] = sl[k];
-        if (sl[k] >= 0 && !is_pair(left, right, sl[k], root)) ++m;
+        if (sl[k] >= 0 && !is_pair(left, right, sl[k], root, recbase)) ++m;
     }
     cnt[j] = m;
 }
 __global__ void collapse_emit_kernel(const int *frontier, int n_cur, const int *slots4, const uint32_t *off, uint32_t wide_base_cur,
                                      uint32_t wide_base_next, const int *left, const int *right, const Box3 *node_boxes,
-                                     const Box3 *prim_boxes, const uint32_t *order, int *next_frontier, float4 *nodes4, int root) {
+                                     const Box3 *prim_boxes, const uint32_t *order, int *next_frontier, float4 *nodes4, int root, const uint32_t *recbase) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_cur) return;
     float v[6][4]; int ref[4];
@@ -195,9 +217,12 @@ __global__ void collapse_emit_kernel(const int *frontier, int n_cur, const int *
         const int c = slots4[j * 4 + k];
         if (c == kEmptyChild) continue;
         const Box3 *b;
-        if (c >= 0 && is_pair(left, right, c, root)) { b = &node_boxes[c]; ref[k] = ~(int)((((uint32_t)~left[c]) << 3) | 1u); }
+        if (c >= 0 && is_pair(left, right, c, root, recbase)) { b = &node_boxes[c]; const uint32_t r = (uint32_t)~left[c]; ref[k] = ~(int)(((recbase ? recbase[r] : r) << 3) | 1u); }
         else if (c >= 0) { b = &node_boxes[c]; const uint32_t w = off[j] + inner++; ref[k] = (int)(wide_base_next + w); next_frontier[w] = c; }
-        else { const uint32_t r = (uint32_t)~c; b = &prim_boxes[order[r]]; ref[k] = ~(int)(r << 3); }
+        else {   // one primitive: a triangle, or a quad (count field 7, bvh_build.h)
+            const uint32_t r = (uint32_t)~c; b = &prim_boxes[order[r]];
+            ref[k] = ~(int)(((recbase ? recbase[r] : r) << 3) | (is_quad_at(recbase, r) ? 7u : 0u));
+        }
         for (int a = 0; a < 3; ++a) { v[a * 2][k] = b->lo[a]; v[a * 2 + 1][k] = b->hi[a]; }
     }
     float4 *o = nodes4 + (size_t)(wide_base_cur + (uint32_t)j) * 8;
@@ -214,7 +239,7 @@ __global__ void validate_wide_kernel(const float4 *nodes4, uint32_t n4, uint32_t
     for (int k = 0; k < 4; ++k) {
         if (ref[k] == kEmptyChild) continue;
         if (ref[k] >= 0) { if ((uint32_t)ref[k] <= i || (uint32_t)ref[k] >= n4) atomicExch(bad, 1); }
-        else { const uint32_t code = (uint32_t)~ref[k]; if ((code >> 3) + (code & 7u) + 1u > ntris) atomicExch(bad, 1); }
+        else { const uint32_t code = (uint32_t)~ref[k]; if ((code >> 3) + ((code & 7u) == 7u ? 2u : (code & 7u) + 1u) > ntris) atomicExch(bad, 1); }
     }
 }
 
@@ -540,10 +565,16 @@ struct Tmp {
 // Builds the 4-wide tree and the leaf-ordered triangle records for `ntris` >= 2 triangles.
 // d_pos/d_idx/d_masks: device copies of the scene arrays.  d_nodes4 must hold (ntris - 1) * 8 float4 (upper
 // bound on wide nodes), d_tris ntris * 3 float4.  Returns the number of wide nodes and the wide depth.
+// Quads (round 4): d_px / d_py (device copies of bvh_build.h pair_quads' arrays, nprims entries) make the builders work on PRIMITIVES -- a lone
+// triangle or the two triangles of a parallelogram, which become one leaf with the count field 7 and two records, X first; d_quad_rec (ntris bytes,
+// zeroed by the caller) gets a 1 at every X record.  d_px == nullptr: every triangle is a primitive (nprims == ntris).
 hipError_t gpu_build_lbvh(const float *d_pos, const uint32_t *d_idx, const uint32_t *d_masks, uint32_t ntris,
                           const float scene_lo[3], const float scene_hi[3], float pad, float4 *d_nodes4, float4 *d_tris,
-                          uint32_t *n_nodes4, uint32_t *depth4, hipStream_t s, int mode) {
-    const int n = (int)ntris, n_int = n - 1;
+                          uint32_t *n_nodes4, uint32_t *depth4, hipStream_t s, int mode,
+                          const uint32_t *d_px, const uint32_t *d_py, uint32_t nprims, unsigned char *d_quad_rec) {
+    if (!d_px) nprims = ntris;
+    if (nprims < 2u || nprims > ntris) return hipErrorInvalidValue;
+    const int n = (int)nprims, n_int = n - 1;
     const int T = 256;
     Tmp boxes, keys_a, keys_b, ord_a, ord_b, left, right, par_i, par_l, nboxes, arrive, kept, widx, maxd, sort_tmp, scan_tmp;
     BCHK(boxes.alloc(sizeof(Box3) * n)); BCHK(keys_a.alloc(8 * (size_t)n)); BCHK(keys_b.alloc(8 * (size_t)n));
@@ -559,7 +590,7 @@ hipError_t gpu_build_lbvh(const float *d_pos, const uint32_t *d_idx, const uint3
     sinv.x = scene_hi[0] > scene_lo[0] ? 1.0f / (scene_hi[0] - scene_lo[0]) : 0.0f;
     sinv.y = scene_hi[1] > scene_lo[1] ? 1.0f / (scene_hi[1] - scene_lo[1]) : 0.0f;
     sinv.z = scene_hi[2] > scene_lo[2] ? 1.0f / (scene_hi[2] - scene_lo[2]) : 0.0f;
-    hipLaunchKernelGGL(prim_kernel, dim3((n + T - 1) / T), dim3(T), 0, s, d_pos, d_idx, ntris, slo, sinv, pad, boxes.as<Box3>(),
+    hipLaunchKernelGGL(prim_kernel, dim3((n + T - 1) / T), dim3(T), 0, s, d_pos, d_idx, d_px, d_py, nprims, slo, sinv, pad, boxes.as<Box3>(),
                        keys_a.as<unsigned long long>(), ord_a.as<uint32_t>());
     size_t tmp_bytes = 0;
     BCHK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_a.as<unsigned long long>(), keys_b.as<unsigned long long>(), ord_a.as<uint32_t>(),
@@ -568,8 +599,23 @@ hipError_t gpu_build_lbvh(const float *d_pos, const uint32_t *d_idx, const uint3
     BCHK(rocprim::radix_sort_pairs(sort_tmp.p, tmp_bytes, keys_a.as<unsigned long long>(), keys_b.as<unsigned long long>(), ord_a.as<uint32_t>(),
                                    ord_b.as<uint32_t>(), (size_t)n, 0, 63, s));
     const unsigned long long *codes = keys_b.as<unsigned long long>();   // sorted Morton codes
-    const uint32_t *keys = ord_b.as<uint32_t>();                         // record position -> triangle index
+    const uint32_t *keys = ord_b.as<uint32_t>();                         // sorted position -> primitive index
     int root = 0;
+    // quads: the first record of every sorted position (n + 1 entries: the last one is ntris)
+    Tmp psize, recb, rec_tmp;
+    const uint32_t *recbase = nullptr;
+    auto make_recbase = [&](const uint32_t *order) -> hipError_t {
+        if (!d_px) return hipSuccess;
+        if (!psize.p) { BCHK(psize.alloc(4 * (size_t)(n + 1))); BCHK(recb.alloc(4 * (size_t)(n + 1))); }
+        BCHK(hipMemsetAsync(psize.p, 0, 4 * (size_t)(n + 1), s));
+        hipLaunchKernelGGL(prim_size_kernel, dim3((n + T - 1) / T), dim3(T), 0, s, order, d_py, nprims, psize.as<uint32_t>());
+        size_t rb = 0;
+        BCHK(rocprim::exclusive_scan(nullptr, rb, psize.as<uint32_t>(), recb.as<uint32_t>(), 0u, (size_t)(n + 1), rocprim::plus<uint32_t>(), s));
+        if (!rec_tmp.p) BCHK(rec_tmp.alloc(rb));
+        BCHK(rocprim::exclusive_scan(rec_tmp.p, rb, psize.as<uint32_t>(), recb.as<uint32_t>(), 0u, (size_t)(n + 1), rocprim::plus<uint32_t>(), s));
+        recbase = recb.as<uint32_t>();
+        return hipSuccess;
+    };
     if (mode == 0) {
         hipLaunchKernelGGL(hierarchy_kernel, dim3((n_int + T - 1) / T), dim3(T), 0, s, codes, n, left.as<int>(), right.as<int>(), par_i.as<int>(),
                            par_l.as<int>());
@@ -683,8 +729,9 @@ hipError_t gpu_build_lbvh(const float *d_pos, const uint32_t *d_idx, const uint3
         if (node_base != n_int) return hipErrorUnknown;
         root = n_int - 1;   // the last merge
     }
-    // the triangle records, in leaf order
-    hipLaunchKernelGGL(record_kernel, dim3((n + T - 1) / T), dim3(T), 0, s, d_pos, d_idx, d_masks, keys, ntris, d_tris);
+    // the triangle records, in leaf order (`keys` is final here: the SAH builder re-orders the primitives level by level)
+    BCHK(make_recbase(keys));
+    hipLaunchKernelGGL(record_kernel, dim3((n + T - 1) / T), dim3(T), 0, s, d_pos, d_idx, d_masks, keys, d_px, d_py, recbase, nprims, d_tris, d_quad_rec);
     uint32_t n4 = 0, d4 = 0;
     {
         // greedy level-by-level collapse (kept / widx double as the two frontier buffers)
@@ -702,7 +749,7 @@ hipError_t gpu_build_lbvh(const float *d_pos, const uint32_t *d_idx, const uint3
             if (wide_base + n_cur > (uint32_t)n_int || d4 > 4096u) return hipErrorUnknown;  // cannot happen for a tree; never loop forever
             const dim3 g((n_cur + T - 1) / T);
             hipLaunchKernelGGL(collapse_plan_kernel, g, dim3(T), 0, s, front[cur], (int)n_cur, left.as<int>(), right.as<int>(), nboxes.as<Box3>(),
-                               slots.as<int>(), cnt.as<uint32_t>(), root);
+                               slots.as<int>(), cnt.as<uint32_t>(), root, recbase);
             size_t tb = tmp_bytes;
             BCHK(rocprim::exclusive_scan(scan_tmp.p, tb, cnt.as<uint32_t>(), off.as<uint32_t>(), 0u, (size_t)n_cur, rocprim::plus<uint32_t>(), s));
             uint32_t last_cnt = 0, last_off = 0;
@@ -712,7 +759,7 @@ hipError_t gpu_build_lbvh(const float *d_pos, const uint32_t *d_idx, const uint3
             const uint32_t n_next = last_off + last_cnt;
             hipLaunchKernelGGL(collapse_emit_kernel, g, dim3(T), 0, s, front[cur], (int)n_cur, slots.as<int>(), off.as<uint32_t>(), wide_base,
                                wide_base + n_cur, left.as<int>(), right.as<int>(), nboxes.as<Box3>(), boxes.as<Box3>(), keys, front[cur ^ 1],
-                               d_nodes4, root);
+                               d_nodes4, root, recbase);
             BCHK(hipGetLastError());
             wide_base += n_cur;
             n_cur = n_next;
@@ -758,7 +805,8 @@ __device__ void plane_rows(const float4 r0, const float4 r1, const float4 r2, fl
     if (ok) { o[0] = p0; o[1] = p1; o[2] = p2; }
 }
 
-__global__ void fatten_records_kernel(const float4 *tris48, const float *nrm, const float *col, uint32_t n, float4 *out, bool planes, float cx, float cy, float cz) {
+__global__ void fatten_records_kernel(const float4 *tris48, const float *nrm, const float *col, uint32_t n, float4 *out, bool planes, float cx, float cy, float cz,
+                                      const unsigned char *quad_rec) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t i = t >> 1, half = t & 1u;
     if (i >= n) return;
@@ -767,7 +815,10 @@ __global__ void fatten_records_kernel(const float4 *tris48, const float *nrm, co
     const float *N = nrm + (size_t)prim * 9, *C = col + (size_t)prim * 9;
     float4 *o = out + (size_t)i * 8;
     if (half == 0u) {
-        const float4 r1 = tris48[(size_t)i * 3 + 1], r2 = tris48[(size_t)i * 3 + 2];
+        const float4 r1 = tris48[(size_t)i * 3 + 1];
+        float4 r2 = tris48[(size_t)i * 3 + 2];
+        // the X record of a quad carries the parallelogram's planes: X.e1 and Y.e2 (trg_capi.cpp fill_plane_record)
+        if (planes && quad_rec && quad_rec[i] && i + 1u < n) r2 = tris48[(size_t)(i + 1u) * 3 + 2];
         if (planes) plane_rows(r0, r1, r2, cx, cy, cz, o);
         else { o[0] = r0; o[1] = r1; o[2] = r2; }
         o[3] = make_float4(N[0], N[1], N[2], N[3]);
@@ -780,10 +831,12 @@ __global__ void fatten_records_kernel(const float4 *tris48, const float *nrm, co
     }
 }
 
-hipError_t gpu_fatten_records(const float4 *d_tris48, const float *d_normals, const float *d_colors, uint32_t ntris, void *d_out, bool planes, const float center[3], hipStream_t s) {
+hipError_t gpu_fatten_records(const float4 *d_tris48, const float *d_normals, const float *d_colors, uint32_t ntris, void *d_out, bool planes, const float center[3], hipStream_t s,
+                              const unsigned char *d_quad_rec) {
     if (ntris == 0) return hipSuccess;
     const uint64_t threads = 2ull * ntris;
-    hipLaunchKernelGGL(fatten_records_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, d_tris48, d_normals, d_colors, ntris, static_cast<float4 *>(d_out), planes, center[0], center[1], center[2]);
+    hipLaunchKernelGGL(fatten_records_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, d_tris48, d_normals, d_colors, ntris, static_cast<float4 *>(d_out), planes, center[0], center[1], center[2],
+                       d_quad_rec);
     return hipGetLastError();
 }
 

@@ -372,17 +372,29 @@ static int load_scene_gpu_build(trg_ctx *c, const float *pos, const float *nrm, 
     float maxabs = 0.f;
     for (int a = 0; a < 3; ++a) maxabs = std::max({ maxabs, std::fabs(lo[a]), std::fabs(hi[a]) });
     const float pad = std::max(2e-5f * std::max(diag, 1e-3f), 4e-6f * maxabs);  // same conservative padding as bvh_build.cpp
-    struct Dev { void *p = nullptr; ~Dev() { if (p) (void)hipFree(p); } } d_pos, d_idx, d_mat, d_nodes4, d_tris;
+    struct Dev { void *p = nullptr; ~Dev() { if (p) (void)hipFree(p); } } d_pos, d_idx, d_mat, d_nodes4, d_tris, d_px, d_py, d_quad;
+    // quads (bvh_build.h): the pairing is one pass over the index buffer on the host; the builders then work on primitives
+    std::vector<uint32_t> px, py;
+    const uint32_t n_quads = pair_quads(pos, idx, mat, n_tris, px, py);
+    const uint32_t n_prims = (uint32_t)px.size();
+    const bool paired = n_quads > 0 && n_prims >= 2;
     HIPCHK(c, hipMalloc(&d_pos.p, (size_t)n_verts * 12)); HIPCHK(c, hipMalloc(&d_idx.p, (size_t)n_tris * 12));
     HIPCHK(c, hipMalloc(&d_mat.p, (size_t)n_tris * 4)); HIPCHK(c, hipMalloc(&d_nodes4.p, (size_t)(n_tris - 1) * 128));
     HIPCHK(c, hipMalloc(&d_tris.p, (size_t)n_tris * 48));
     HIPCHK(c, hipMemcpyAsync(d_pos.p, pos, (size_t)n_verts * 12, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_idx.p, idx, (size_t)n_tris * 12, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_mat.p, mat, (size_t)n_tris * 4, hipMemcpyHostToDevice, c->stream));
+    if (paired) {
+        HIPCHK(c, hipMalloc(&d_px.p, (size_t)n_prims * 4)); HIPCHK(c, hipMalloc(&d_py.p, (size_t)n_prims * 4)); HIPCHK(c, hipMalloc(&d_quad.p, (size_t)n_tris));
+        HIPCHK(c, hipMemcpyAsync(d_px.p, px.data(), (size_t)n_prims * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_py.p, py.data(), (size_t)n_prims * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemsetAsync(d_quad.p, 0, (size_t)n_tris, c->stream));
+    }
     uint32_t n4 = 0, depth4 = 0;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     hipError_t e = gpu_build_lbvh((const float *)d_pos.p, (const uint32_t *)d_idx.p, (const uint32_t *)d_mat.p, n_tris, lo, hi, pad,
-                                  (float4 *)d_nodes4.p, (float4 *)d_tris.p, &n4, &depth4, c->stream, c->opt_gpu_build == 2 ? 0 : c->opt_gpu_build == 3 ? 2 : 1);
+                                  (float4 *)d_nodes4.p, (float4 *)d_tris.p, &n4, &depth4, c->stream, c->opt_gpu_build == 2 ? 0 : c->opt_gpu_build == 3 ? 2 : 1,
+                                  paired ? (const uint32_t *)d_px.p : nullptr, paired ? (const uint32_t *)d_py.p : nullptr, n_prims, (unsigned char *)d_quad.p);
     if (e != hipSuccess) return fail(c, TRG_ERR_DEVICE, "GPU BVH build failed: %s", hipGetErrorString(e));
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     HIPCHK(c, hipEventSynchronize(c->ev1));
@@ -410,7 +422,8 @@ static int load_scene_gpu_build(trg_ctx *c, const float *pos, const float *nrm, 
         HIPCHK(c, hipMemcpyAsync(d_nrm.p, nrm, (size_t)n_tris * 36, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(d_col.p, col, (size_t)n_tris * 36, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, gpu_fatten_records((const float4 *)d_tris.p, (const float *)d_nrm.p, (const float *)d_col.p, n_tris, c->blob + sc.off_fat, false, sc.center, c->stream));
-        HIPCHK(c, gpu_fatten_records((const float4 *)d_tris.p, (const float *)d_nrm.p, (const float *)d_col.p, n_tris, c->blob + sc.off_fat_planes, true, sc.center, c->stream));
+        HIPCHK(c, gpu_fatten_records((const float4 *)d_tris.p, (const float *)d_nrm.p, (const float *)d_col.p, n_tris, c->blob + sc.off_fat_planes, true, sc.center, c->stream,
+                                     (const unsigned char *)d_quad.p));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     HIPCHK(c, gpu_quantize_nodes4((const float4 *)d_nodes4.p, n4, c->blob + sc.off_nodes4, c->stream));
