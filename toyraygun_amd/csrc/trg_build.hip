@@ -17,6 +17,7 @@
 
 #include "q4node.h"
 #include "trg_build.h"
+#include "trg_kernels.h"   // (TRG_REC_META_FIRST: the layout of the plane-form leaf records)
 
 namespace trg {
 namespace {
@@ -821,12 +822,19 @@ __global__ void fatten_records_kernel(const float4 *tris48, const float *nrm, co
         if (planes && quad_rec && quad_rec[i] && i + 1u < n) r2 = tris48[(size_t)(i + 1u) * 3 + 2];
         if (planes) plane_rows(r0, r1, r2, cx, cy, cz, o);
         else { o[0] = r0; o[1] = r1; o[2] = r2; }
-        o[3] = make_float4(N[0], N[1], N[2], N[3]);
+        // the plane form has no room for them in rows 0..2: the original index and the material id follow the planes (TRG_REC_META_FIRST)
+        // or close the record
+        if (planes && TRG_REC_META_FIRST) o[3] = make_float4(r0.w, r1.w, N[0], N[1]);
+        else o[3] = make_float4(N[0], N[1], N[2], N[3]);
+    } else if (planes && TRG_REC_META_FIRST) {
+        o[4] = make_float4(N[2], N[3], N[4], N[5]);
+        o[5] = make_float4(N[6], N[7], N[8], C[0]);
+        o[6] = make_float4(C[1], C[2], C[3], C[4]);
+        o[7] = make_float4(C[5], C[6], C[7], C[8]);
     } else {
         o[4] = make_float4(N[4], N[5], N[6], N[7]);
         o[5] = make_float4(N[8], C[0], C[1], C[2]);
         o[6] = make_float4(C[3], C[4], C[5], C[6]);
-        // the plane form has no room for them in rows 0..2: the original index and the material id close the record
         o[7] = planes ? make_float4(C[7], C[8], r0.w, tris48[(size_t)i * 3 + 1].w) : make_float4(C[7], C[8], 0.0f, 0.0f);
     }
 }

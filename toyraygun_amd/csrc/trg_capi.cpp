@@ -181,14 +181,20 @@ static void fill_plane_record(unsigned char *dst, uint16_t *meta, const F4 *rec4
     *meta = (uint16_t)((prim << 2) | (mask & 3u));
 }
 
-// The shipped build's 128-byte leaf record: rows 0..2 the three planes (fill_plane_record), the attributes where fill_fat_record puts them,
-// the original index and the material id in the last two words.
+// The shipped build's 128-byte leaf record: rows 0..2 the three planes (fill_plane_record), then the original index and the material id
+// (floats 12, 13), then the nine normal and nine colour floats (14..31).
 static void fill_fat_record_planes(unsigned char *dst, const F4 *rec48, const float *nrm, const float *col, uint32_t n_tris, const float *center, const F4 *quad_y) {
     fill_fat_record(dst, rec48, nrm, col, n_tris);
     uint16_t meta;
     fill_plane_record(dst, &meta, rec48, center, quad_y);
-    memcpy(dst + 120, &rec48[0].w, 4);   // float 30: original index
-    memcpy(dst + 124, &rec48[1].w, 4);   // float 31: material id = mask
+    if (TRG_REC_META_FIRST) {   // index and mask right behind the planes (the first 64 bytes are all a test reads), the attributes at floats 14..31
+        memmove(dst + 56, dst + 48, 72);
+        memcpy(dst + 48, &rec48[0].w, 4);   // float 12: original index
+        memcpy(dst + 52, &rec48[1].w, 4);   // float 13: material id = mask
+    } else {
+        memcpy(dst + 120, &rec48[0].w, 4);   // float 30: original index
+        memcpy(dst + 124, &rec48[1].w, 4);   // float 31: material id = mask
+    }
 }
 
 constexpr uint32_t kStackLdsLevels = TRG_STACK_LDS_LEVELS;

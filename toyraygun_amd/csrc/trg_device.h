@@ -576,8 +576,9 @@ constexpr bool kTriPlanes = !TRG_STRICT && TRG_TRI_PLANES;
 // ... and on a scene traversed from HBM: the leaf records of SceneDesc::off_fat_planes (rows 0..2 planes, words 30 / 31 index and mask)
 constexpr bool kRecPlanes = !TRG_STRICT && TRG_TRI_PLANES_HBM;
 
-TRG_DEV int fat_prim(const v4f *recs, uint32_t r) { return __float_as_int(kRecPlanes ? recs[(size_t)r * kRecV4 + 7].z : recs[(size_t)r * kRecV4].w); }
-TRG_DEV uint32_t fat_mask(const v4f *recs, uint32_t r) { return (uint32_t)__float_as_int(kRecPlanes ? recs[(size_t)r * kRecV4 + 7].w : recs[(size_t)r * kRecV4 + 1].w); }
+constexpr bool kRecMetaFirst = kRecPlanes && TRG_REC_META_FIRST;   // plane records: index / mask = floats 12, 13 (else 30, 31)
+TRG_DEV int fat_prim(const v4f *recs, uint32_t r) { return __float_as_int(kRecMetaFirst ? recs[(size_t)r * kRecV4 + 3].x : kRecPlanes ? recs[(size_t)r * kRecV4 + 7].z : recs[(size_t)r * kRecV4].w); }
+TRG_DEV uint32_t fat_mask(const v4f *recs, uint32_t r) { return (uint32_t)__float_as_int(kRecMetaFirst ? recs[(size_t)r * kRecV4 + 3].y : kRecPlanes ? recs[(size_t)r * kRecV4 + 7].w : recs[(size_t)r * kRecV4 + 1].w); }
 
 // Per-lane traversal stack, laid out [level][thread] so lane i always hits LDS bank i%32 (no conflicts).
 // Scenes staged in LDS have shallow trees and keep the whole stack in LDS (klds = all levels).  Scenes in
@@ -1026,7 +1027,8 @@ TRG_DEV void trav_step_wide(const SceneView &sc, Trav &tv, bool any, STK stk, Co
     const v4f q0 = ptr[0], q1 = ptr[1], q2 = ptr[2];
     // the fourth load: the children of a node, or -- plane records -- the last row of the leaf record (its index and mask); one instruction for both kinds
     v4f q3;
-    if (kRecPlanes) q3 = ptr[inner ? 3 : 7];
+    if (kRecMetaFirst) q3 = ptr[3];          // (the record's first 64 bytes hold all a test reads: one line half, like a node)
+    else if (kRecPlanes) q3 = ptr[inner ? 3 : 7];
     else if (inner) q3 = ptr[3];
     if (inner) {
         trav_node4_math<COUNT, BLOCK>(q0, q1, q2, q3, tv, stk, cnt);
@@ -1034,7 +1036,7 @@ TRG_DEV void trav_step_wide(const SceneView &sc, Trav &tv, bool any, STK stk, Co
         // a QUAD leaf (count field 7, bvh_build.h): the shipped build decides both triangles with one parallelogram test; the strict build
         // tests record `first`, then advances to the single-triangle code of record first + 1
         const bool quad = left == kLeafQuad;
-        const bool stop = kRecPlanes ? trav_tri_planes_rec<COUNT>(q0, q1, q2, (uint32_t)__float_as_int(q3.w), __float_as_int(q3.z), tv, any, cnt, first, sc.tris, sc.center, quad)
+        const bool stop = kRecPlanes ? trav_tri_planes_rec<COUNT>(q0, q1, q2, (uint32_t)__float_as_int(kRecMetaFirst ? q3.y : q3.w), __float_as_int(kRecMetaFirst ? q3.x : q3.z), tv, any, cnt, first, sc.tris, sc.center, quad)
                                      : trav_tri_math<COUNT, true>(q0, q1, q2, tv, any, cnt, first, sc.tris);
         const bool more = kRecPlanes ? (left != 0u && !quad) : (left != 0u);
         const bool do_pop = !stop && !more;
@@ -1298,7 +1300,7 @@ TRG_DEV Surf<FAT> surf_fetch(const SceneView &sc, int ref) {
     s.ref = ref;
     if (FAT) {
         const v4f *rec = sc.tris + (size_t)(uint32_t)ref * kRecV4;
-        s.mat = (uint32_t)__float_as_int(kRecPlanes ? rec[7].w : rec[1].w);
+        s.mat = (uint32_t)__float_as_int(kRecMetaFirst ? rec[3].y : kRecPlanes ? rec[7].w : rec[1].w);
         s.r3 = rec[3]; s.r4 = rec[4]; s.r5 = rec[5]; s.r6 = rec[6]; s.r7 = rec[7];
     } else {
         s.mat = sc.mats[ref];
@@ -1311,8 +1313,11 @@ TRG_DEV void surf_interp(const SceneView &sc, const Surf<FAT> &s, float cx, floa
     int prim = s.ref;
     if (FAT) {
         const float cz = 1.0f - cx - cy;
-        const V3 N0 = mk(s.r3.x, s.r3.y, s.r3.z), N1 = mk(s.r3.w, s.r4.x, s.r4.y), N2 = mk(s.r4.z, s.r4.w, s.r5.x);
-        const V3 C0 = mk(s.r5.y, s.r5.z, s.r5.w), C1 = mk(s.r6.x, s.r6.y, s.r6.z), C2 = mk(s.r6.w, s.r7.x, s.r7.y);
+        // (attributes at floats 12..29 of the record, or -- plane records with index / mask first -- at 14..31)
+        const V3 N0 = kRecMetaFirst ? mk(s.r3.z, s.r3.w, s.r4.x) : mk(s.r3.x, s.r3.y, s.r3.z), N1 = kRecMetaFirst ? mk(s.r4.y, s.r4.z, s.r4.w) : mk(s.r3.w, s.r4.x, s.r4.y);
+        const V3 N2 = kRecMetaFirst ? mk(s.r5.x, s.r5.y, s.r5.z) : mk(s.r4.z, s.r4.w, s.r5.x);
+        const V3 C0 = kRecMetaFirst ? mk(s.r5.w, s.r6.x, s.r6.y) : mk(s.r5.y, s.r5.z, s.r5.w), C1 = kRecMetaFirst ? mk(s.r6.z, s.r6.w, s.r7.x) : mk(s.r6.x, s.r6.y, s.r6.z);
+        const V3 C2 = kRecMetaFirst ? mk(s.r7.y, s.r7.z, s.r7.w) : mk(s.r6.w, s.r7.x, s.r7.y);
         vcol = cx * C0 + cy * C1 + cz * C2;
         nraw = cx * N0 + cy * N1 + cz * N2;
         if (sc.tex.uv) prim = fat_prim(sc.tris, (uint32_t)s.ref);   // textures are addressed by the original index

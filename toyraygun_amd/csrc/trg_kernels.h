@@ -234,6 +234,10 @@ struct TraceParams {
 #ifndef TRG_TRI_PLANES
 #define TRG_TRI_PLANES 1
 #endif
+#ifndef TRG_REC_META_FIRST
+#define TRG_REC_META_FIRST 1   // plane-form leaf records: 1 = the original index and the material id are floats 12, 13 -- everything a triangle TEST reads
+                               // sits in the first 64 bytes of the record, the attributes follow at floats 14..31; 0 = attributes at 12..29, index / mask last
+#endif
 #ifndef TRG_TRI_PLANES_HBM
 #define TRG_TRI_PLANES_HBM 1   // the same for scenes traversed from HBM (their own set of leaf records, SceneDesc::off_fat_planes)
 #endif
