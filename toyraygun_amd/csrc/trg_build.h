@@ -18,7 +18,7 @@ hipError_t gpu_quantize_nodes4(const float4 *d_nodes4, uint32_t n_nodes4, void *
 // 48-byte geometry records (leaf order) + normals / colours in original order (9 floats per triangle) -> 128-byte leaf records
 // (trg_device.h kRecV4) at d_out
 // planes: the shipped build's form -- rows 0..2 the triangle's three planes (computed in double, as trg_capi.cpp fill_plane_record does on the
-// host), the original index and the material id in the last two words
+// host), then the original index and the material id (floats 12, 13), then the attributes (floats 14..31): TRG_REC_META_FIRST
 // d_quad_rec (planes only): per record, 1 = the X of a quad leaf -- its planes are the parallelogram's (X.e1, the next record's e2)
 hipError_t gpu_fatten_records(const float4 *d_tris48, const float *d_normals, const float *d_colors, uint32_t ntris, void *d_out, bool planes, const float center[3], hipStream_t s,
                               const unsigned char *d_quad_rec = nullptr);

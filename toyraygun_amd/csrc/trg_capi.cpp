@@ -197,6 +197,53 @@ static void fill_fat_record_planes(unsigned char *dst, const F4 *rec48, const fl
     }
 }
 
+// float -> IEEE half, rounded toward +inf (up) or -inf: the slab planes of the half-precision LDS node (kHalfLds) may only move outward
+static float f16_to_f32(uint16_t h) {
+    const uint32_t s = (uint32_t)(h >> 15) << 31, e = (h >> 10) & 31u, m = h & 1023u;
+    uint32_t u;
+    if (e == 0) {
+        if (m == 0) u = s;
+        else { float f = (float)m * 5.9604644775390625e-8f; memcpy(&u, &f, 4); u |= s; }   // subnormal: m * 2^-24
+    } else if (e == 31) u = s | 0x7F800000u | (m << 13);
+    else u = s | ((e + 112u) << 23) | (m << 13);
+    float f; memcpy(&f, &u, 4);
+    return f;
+}
+static uint16_t f32_to_f16_directed(float f, bool up) {
+    if (f != f) return 0x7E00u;
+    // nearest first (round half away: good enough, the correction below makes it directed), then step to the neighbour on the wanted side
+    uint32_t u; memcpy(&u, &f, 4);
+    const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
+    const float a = std::fabs(f);
+    uint16_t mag;
+    if (a >= 65520.0f) mag = 0x7C00u;   // beyond the largest half: infinity (the correction brings a "down" back to 65504)
+    else if (a < 6.103515625e-5f) mag = (uint16_t)std::lrintf(a * 16777216.0f);   // subnormal: multiples of 2^-24 (1024 = the smallest normal: the bit patterns are contiguous)
+    else {
+        int ex; const float fr = std::frexp(a, &ex);   // a = fr * 2^ex, fr in [0.5, 1)
+        uint32_t m = (uint32_t)std::lrintf(fr * 2048.0f);   // 11 bits: 1024..2048
+        if (m == 2048u) { m = 1024u; ++ex; }
+        mag = (uint16_t)(((uint32_t)(ex + 14) << 10) + (m - 1024u));
+    }
+    uint16_t h = (uint16_t)(sign | mag);
+    auto next_up = [](uint16_t x) -> uint16_t {     // the next half towards +inf
+        if (x == 0x8000u) x = 0;
+        if (x == 0x7C00u) return x;
+        return (x & 0x8000u) ? (uint16_t)(x - 1u) : (uint16_t)(x + 1u);
+    };
+    auto next_down = [](uint16_t x) -> uint16_t {   // ... towards -inf
+        if (x == 0x0000u) x = 0x8000u;
+        if (x == 0xFC00u) return x;
+        return (x & 0x8000u) ? (uint16_t)(x + 1u) : (uint16_t)(x - 1u);
+    };
+    for (int it = 0; it < 2; ++it) {
+        const float g = f16_to_f32(h);
+        if (up && g < f) h = next_up(h);
+        else if (!up && g > f) h = next_down(h);
+        else break;
+    }
+    return h;
+}
+
 constexpr uint32_t kStackLdsLevels = TRG_STACK_LDS_LEVELS;
 #ifndef TRG_TAIL_AUTO_MIN_BOUNCES
 #define TRG_TAIL_AUTO_MIN_BOUNCES 4
@@ -735,8 +782,38 @@ int host_scene_build(trg_ctx *c, const float *pos, const float *nrm, const float
             memcpy(o + 36, ch, 8);
             memcpy(o + 44, ch, 8);
         }
+    } else if (sc.n_nodes && lds_candidate && kHalfLds) {
+        // the sign-ordered node in half precision (trg_kernels.h kHalfLds; trg_device.h trav_node_step_half): planes relative to the centre,
+        // lo rounded down, hi rounded up
+        for (uint32_t i = 0; i < sc.n_nodes; ++i) {
+            const F4 *n = &bvh.nodes[(size_t)i * 4];  // (ax0,ax1,ay0,ay1) (bx0,bx1,by0,by1) (az0,az1,bz0,bz1) (c0,c1,-,-)
+            unsigned char *o = &host[sc.off_nodes + (size_t)i * kLdsNodeBytes];
+            const float pl[3][4] = { { n[0].x, n[0].y, n[1].x, n[1].y }, { n[0].z, n[0].w, n[1].z, n[1].w }, { n[2].x, n[2].y, n[2].z, n[2].w } };   // per axis: lo_a, hi_a, lo_b, hi_b
+            uint16_t fwd[3][4], rev[3][4];
+            for (int a = 0; a < 3; ++a) {
+                uint16_t h[4];
+                for (int k = 0; k < 4; ++k) h[k] = f32_to_f16_directed(pl[a][k] - sc.center[a], (k & 1) != 0);
+                // (the subtraction rounds to nearest: one ulp of fp32, three orders of magnitude below the half's step and inside the builder's padding)
+                for (int k = 0; k < 4; ++k) { fwd[a][k] = h[k]; rev[a][k] = h[k ^ 1]; }
+            }
+            int32_t ch[2];
+            memcpy(ch, &n[3].x, 8);
+            for (int k = 0; k < 2; ++k)
+                if (ch[k] >= 0) ch[k] *= (int32_t)kLdsNodeBytes;
+            for (int sy = 0; sy < 2; ++sy)
+                for (int sx = 0; sx < 2; ++sx) {
+                    unsigned char *q = o + (sx + 2 * sy) * 16;
+                    memcpy(q, sx ? rev[0] : fwd[0], 8);
+                    memcpy(q + 8, sy ? rev[1] : fwd[1], 8);
+                }
+            for (int sz = 0; sz < 2; ++sz) {
+                unsigned char *q = o + 64 + sz * 16;
+                memcpy(q, sz ? rev[2] : fwd[2], 8);
+                memcpy(q + 8, ch, 8);
+            }
+        }
     } else if (sc.n_nodes) {
-        static_assert(kSignedLds || kWideLds || kLdsNodeBytes == 64u, "plain BVH2 nodes are 64 bytes");
+        static_assert(kSignedLds || kWideLds || kHalfLds || kLdsNodeBytes == 64u, "plain BVH2 nodes are 64 bytes");
         memcpy(&host[sc.off_nodes], bvh.nodes.data(), (size_t)sc.n_nodes * 64u);
     }
     if (lds_candidate) {

@@ -656,7 +656,12 @@ TRG_DEV void trav_begin(const SceneView &sc, Trav &tv, V3 o, V3 d, float tmax, u
     const float dx = clamp_away_from_zero(d.x), dy = clamp_away_from_zero(d.y), dz = clamp_away_from_zero(d.z);
     tv.o = (kTriPlanes && rel) ? o - sc.center : o; tv.d = d;
     tv.idx = rcp_fast(dx); tv.idy = rcp_fast(dy); tv.idz = rcp_fast(dz);
-    tv.oix = o.x * tv.idx; tv.oiy = o.y * tv.idy; tv.oiz = o.z * tv.idz;
+    if (TRG_TRAV_LDS == 7 && rel) {   // half-precision LDS nodes: their planes are relative to the centre, like the plane records
+        const V3 oc = o - sc.center;
+        tv.oix = oc.x * tv.idx; tv.oiy = oc.y * tv.idy; tv.oiz = oc.z * tv.idz;
+    } else {
+        tv.oix = o.x * tv.idx; tv.oiy = o.y * tv.idy; tv.oiz = o.z * tv.idz;
+    }
     tv.best = tmax; tv.rmask = rmask;
     tv.hit.t = -1.0f; tv.hit.prim = -1; tv.hit.u = 0.0f; tv.hit.v = 0.0f;
     tv.found = false;
@@ -667,6 +672,10 @@ TRG_DEV void trav_begin(const SceneView &sc, Trav &tv, V3 o, V3 d, float tmax, u
         tv.sx = (int)(node_base + ((__float_as_uint(dx) >> 31) << 4));
         tv.sy = (int)(node_base + 48u + ((__float_as_uint(dy) >> 31) << 4));
         tv.sz = (int)(node_base + 96u + ((__float_as_uint(dz) >> 31) << 4));
+    } else if (TRG_TRAV_LDS == 7) {   // ... in half precision: [X | Y] of the sign pair at +0 / +16 / +32 / +48, [Z | children] at +64 / +80
+        tv.sx = (int)(node_base + (((__float_as_uint(dx) >> 31) | ((__float_as_uint(dy) >> 31) << 1)) << 4));
+        tv.sy = 0;
+        tv.sz = (int)(node_base + 64u + ((__float_as_uint(dz) >> 31) << 4));
     } else {   // sign-ordered BVH2: the [X | Y] block of the sign pair at +0 / +32 / +64 / +96, Z+ Z- at +128 / +160
         tv.sx = (int)(node_base + (((__float_as_uint(dx) >> 31) | ((__float_as_uint(dy) >> 31) << 1)) << 5));
         tv.sy = 0;
@@ -759,9 +768,44 @@ TRG_DEV void trav_node_step_signed(const SceneView &sc, Trav &tv, STK stk, Count
     tv.node = next; tv.sp = sp;
 }
 
+// The same step on the HALF-precision sign-ordered node (TRG_TRAV_LDS == 7, trg_kernels.h kHalfLds): two 16-byte reads -- [X pair | Y pair] of this
+// ray's sign pair, [Z pair | child0 child1] of its Z sign --; the slab products convert in the multiply (v_fma_mix_f32 in the shipped build).
+template <bool COUNT, int BLOCK, typename STK>
+TRG_DEV void trav_node_step_half(const SceneView &sc, Trav &tv, STK stk, Counters &cnt) {
+    if (COUNT) { cnt.nodes++; if (mbcnt64(__ballot(1)) == 0) cnt.wnodes++; }
+    typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+    typedef __attribute__((address_space(3))) h8_t lds_h8_t;
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    const uint32_t az_addr = (uint32_t)(tv.node + tv.sz), axy_addr = (uint32_t)(tv.node + tv.sx);
+    const h8_t XY = *(const lds_h8_t *)(uintptr_t)axy_addr;
+    const h8_t ZH = *(const lds_h8_t *)(uintptr_t)az_addr;      // (halves 0..3: the Z pair; the other eight bytes: the two children)
+    const v4i_t ZC = __builtin_bit_cast(v4i_t, ZH);
+    const int c0 = ZC.z, c1 = ZC.w;
+    const float anx = (float)XY[0] * tv.idx - tv.oix, afx = (float)XY[1] * tv.idx - tv.oix, bnx = (float)XY[2] * tv.idx - tv.oix, bfx = (float)XY[3] * tv.idx - tv.oix;
+    const float any_ = (float)XY[4] * tv.idy - tv.oiy, afy = (float)XY[5] * tv.idy - tv.oiy, bny = (float)XY[6] * tv.idy - tv.oiy, bfy = (float)XY[7] * tv.idy - tv.oiy;
+    const float anz = (float)ZH[0] * tv.idz - tv.oiz, afz = (float)ZH[1] * tv.idz - tv.oiz, bnz = (float)ZH[2] * tv.idz - tv.oiz, bfz = (float)ZH[3] * tv.idz - tv.oiz;
+    const float amin = fmaxf(fmaxf(anx, any_), fmaxf(anz, 0.0f));
+    const float amax = fminf(fminf(afx, afy), min_raw(afz, tv.best));
+    const float bmin = fmaxf(fmaxf(bnx, bny), fmaxf(bnz, 0.0f));
+    const float bmax = fminf(fminf(bfx, bfy), min_raw(bfz, tv.best));
+    const bool ha = amin <= amax, hb = bmin <= bmax;
+    const bool both = ha && hb, none = !(ha || hb);
+    const bool first1 = hb && (!ha || bmin < amin);
+    const int nearc = first1 ? c1 : c0, farc = first1 ? c0 : c1;
+    stk.push(tv.sp, farc);
+    int sp = tv.sp + (both ? STK::unit : 0);
+    int next = nearc;
+    if (none) {
+        sp -= STK::unit;
+        next = stk.pop(sp);
+    }
+    tv.node = next; tv.sp = sp;
+}
+
 template <bool COUNT, int BLOCK, int LMODE = 0, typename STK>
 TRG_DEV void trav_node_step(const SceneView &sc, Trav &tv, STK stk, Counters &cnt) {
     if (LMODE == 4) { trav_node_step_signed<COUNT, BLOCK>(sc, tv, stk, cnt); return; }
+    if (LMODE == 7) { trav_node_step_half<COUNT, BLOCK>(sc, tv, stk, cnt); return; }
     const v4f *n = sc.nodes + tv.node * 4;
     const v4f n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
     trav_node_math<COUNT, BLOCK>(n0, n1, n2, n3, tv, stk, cnt);
@@ -831,7 +875,7 @@ TRG_DEV bool trav_quad_planes(const SceneView &sc, const v4f *tr, uint32_t rec, 
     return any && ok;
 }
 // ... and on a leaf RECORD of an HBM-resident scene (the hit keeps the record index; ties go to the lower original index, read back from the
-// held record only then): mask and prim are the record's last two words
+// held record only then): mask and prim are floats 13 and 12 of the record (TRG_REC_META_FIRST; its last two words before)
 template <bool COUNT>
 TRG_DEV bool trav_tri_planes_rec(const v4f a, const v4f b, const v4f c, uint32_t mask, int prim, Trav &tv, bool any, Counters &cnt, uint32_t rec, const v4f *recs, V3 center, bool quad) {
     const bool masked_in = (mask & tv.rmask) != 0u;
@@ -1005,7 +1049,7 @@ TRG_DEV void trav_node4_step_lds(const SceneView &sc, Trav &tv, STK stk, Counter
     wide_select<BLOCK>(t[0], t[1], t[2], t[3], __float_as_int(ch.x), __float_as_int(ch.y), __float_as_int(ch.z), __float_as_int(ch.w), tv, stk);
 }
 
-// the inner-node step of the while-while schedules: BVH2 (0), sign-ordered BVH2 in LDS (4), sign-ordered 4-wide in LDS (5)
+// the inner-node step of the while-while schedules: BVH2 (0), sign-ordered BVH2 in LDS (4), sign-ordered 4-wide in LDS (5), sign-ordered BVH2 in half precision (7)
 template <bool COUNT, int BLOCK, int LMODE, typename STK>
 TRG_DEV void trav_inner_step(const SceneView &sc, Trav &tv, STK stk, Counters &cnt) {
     if (LMODE == 6) tv.node = kNodeDone;   // the octant-threaded layout is walked by traverse() only: the pool / wavefront / pair loops trace nothing in that (experimental) build
@@ -1065,7 +1109,7 @@ TRG_DEV void trav_step_wide(const SceneView &sc, Trav &tv, bool any, STK stk, Co
 // LDS address of the node array when the traversal reads sign-ordered LDS nodes (UNIFIED = false selects the LDS schedule)
 template <bool UNIFIED>
 TRG_DEV uint32_t lds_node_base(const SceneView &sc) {
-    return (!UNIFIED && (TRG_TRAV_LDS == 4 || TRG_TRAV_LDS == 5 || TRG_TRAV_LDS == 6)) ? (uint32_t)(uintptr_t)(const lds_v4f_t *)sc.nodes : 0u;
+    return (!UNIFIED && (TRG_TRAV_LDS == 4 || TRG_TRAV_LDS == 5 || TRG_TRAV_LDS == 6 || TRG_TRAV_LDS == 7)) ? (uint32_t)(uintptr_t)(const lds_v4f_t *)sc.nodes : 0u;
 }
 
 // Nearest-hit (ANY=false) or any-hit (ANY=true) query for one ray per lane.

@@ -57,7 +57,7 @@ struct SceneDesc {
     // and, inside the staged part, one u16 per record: (original index << 2) | (material id & 3), the test's mask and the hit's primitive
     uint32_t off_tris_alt, off_meta, n_tris_rec;   // n_tris_rec = 48-byte records of the staged part (leaf order)
     // scenes traversed from HBM, shipped build (TRG_TRI_PLANES_HBM): a second set of 128-byte leaf records whose rows 0..2 are the triangle's
-    // three planes; its attributes sit where off_fat's do, the original index and the material id in the last two words (floats 30, 31)
+    // three planes, then the original index and the material id (floats 12, 13: TRG_REC_META_FIRST), then the attributes (floats 14..31)
     uint32_t off_fat_planes;
     // the planes are stored relative to this point (the centre of the scene's bounding box) and a ray's origin is shifted by it when its
     // traversal begins: n . o - d0 then cancels numbers of the size of the scene instead of its distance from the coordinate origin
@@ -265,8 +265,15 @@ constexpr bool kWideLds = (TRG_TRAV_LDS == 5);   // sign-ordered 4-wide float no
 // near-to-far order with a skip link each (next position when the box is missed): no stack, no near / far select.  Only traverse() walks it
 // (the direct, frame-parallel and tail kernels); the pool and wavefront schedules are not available in that build.
 constexpr bool kThreadedLds = (TRG_TRAV_LDS == 6);
-constexpr uint32_t kLdsNodeBytes = kWideLds ? 160u : (kSignedLds ? 208u : 64u);   // (sign-ordered BVH2: 192 bytes used + 16 of padding, trg_device.h kSignedNodeBytes)
-static_assert(!(kSignedLds || kWideLds || kThreadedLds) || kWideHbm, "the LDS node layouts replace the BVH2 array: the HBM kernels must use the 4-wide tree");
+// 7 (round-4 experiment): the sign-ordered BVH2 node with its slab planes in HALF precision, relative to SceneDesc::center and rounded outward
+// (lo down, hi up: the boxes only grow): [X pair | Y pair] of 8 + 8 bytes per sign pair at 0 / 16 / 32 / 48, [Z pair | child0 child1] at 64 / 80,
+// 96 bytes + 16 of padding (a 28-dword stride spreads 16 nodes over all bank groups).  A node step reads 2 x 16 bytes instead of 56; the slab
+// products take the half straight from the register (v_fma_mix_f32).  MEASURED SLOWER (profiles/r04/ab_half_precision_nodes.txt: C2 1.62 -> 1.83 ms
+// per step, C3 13.5 -> 15.0): twelve v_fma_mix_f32 cost about twice twelve v_fma_f32, more than the 6 LDS-array cycles per step they save.  Parity is
+// green in that build (the boxes only grow); it stays as an experiment like 5 and 6.
+constexpr bool kHalfLds = (TRG_TRAV_LDS == 7);
+constexpr uint32_t kLdsNodeBytes = kWideLds ? 160u : (kSignedLds ? 208u : (kHalfLds ? 112u : 64u));   // (sign-ordered BVH2: 192 bytes used + 16 of padding, trg_device.h kSignedNodeBytes)
+static_assert(!(kSignedLds || kWideLds || kThreadedLds || kHalfLds) || kWideHbm, "the LDS node layouts replace the BVH2 array: the HBM kernels must use the 4-wide tree");
 
 #define TRG_DECL_LAUNCHERS(SFX)                                                                                   \
     hipError_t launch_render_##SFX(const RenderParams &p, bool lds_scene, bool counters, uint32_t grid,          \
