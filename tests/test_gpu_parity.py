@@ -277,6 +277,51 @@ def test_gpu_built_bvh_gives_identical_images(capi, O, n, builder):
         c.close()
 
 
+@pytest.mark.parametrize("shape", ["one_quad", "quad_and_triangle", "two_quads", "quads_and_triangles"])
+@pytest.mark.parametrize("builder", [0, 1, 2, 3])
+def test_smallest_scenes_with_quads(capi, O, shape, builder):
+    """Quad leaves at the builders' smallest inputs (round 4): ONE quad (the device builders need two primitives and fall back to its two
+    triangles), a quad and a triangle (two primitives, the root's two leaves), two quads, and a handful mixed in both index patterns -- kept in
+    HBM so that the host builder (0) walks the same 4-wide path as the device builders.  Strict build: the oracle's records bit for bit; shipped
+    build (one plane test per quad): the same triangles and distances away from the edges."""
+    rng = np.random.default_rng(len(shape))
+    s = O.OracleScene()
+    eye = np.eye(4, dtype=np.float32)
+
+    def quad(pattern):
+        a = rng.uniform([-0.6, 0.4, -0.6], [0.2, 1.2, 0.2]).astype(np.float32)
+        e1, e2 = rng.normal(0, 0.5, 3).astype(np.float32), rng.normal(0, 0.5, 3).astype(np.float32)
+        p4 = np.stack([a, a + e1, a + e1 + e2, a + e2]).astype(np.float32)       # a, b, c, d = a + (c - b)
+        s.add_geometry(p4, [0, 1, 2, 0, 2, 3] if pattern == 1 else [0, 2, 3, 0, 1, 2], eye, rng.uniform(0.2, 0.9, 3), 1)
+
+    def tri():
+        t = (rng.uniform([-0.8, 0.2, -0.8], [0.8, 1.8, 0.8], (1, 3)) + rng.normal(0, 0.4, (3, 3))).astype(np.float32)
+        s.add_geometry(t, [0, 1, 2], eye, rng.uniform(0.2, 0.9, 3), 1)
+
+    {"one_quad": lambda: quad(1), "quad_and_triangle": lambda: (quad(2), tri()), "two_quads": lambda: (quad(1), quad(2)),
+     "quads_and_triangles": lambda: (tri(), quad(1), tri(), quad(2), quad(1), tri())}[shape]()
+    b = s.buffers()
+    rays = _rays(O, 20000, 91, lo=(-0.9, 0.1, -0.9), hi=(0.9, 1.9, 0.9))
+    ref = O.intersect_nearest(s, rays, brute=True)
+    assert (ref["distance"] >= 0).sum() > 200
+    c = capi.Context(16, 16)
+    try:
+        c.set_option(capi.OPT_FORCE_GLOBAL, 1)
+        c.set_option(capi.OPT_GPU_BUILD, builder)
+        c.load_scene(b["positions"], b["normals"], b["colors"], b["indices"], b["material_ids"])
+        c.set_option(capi.OPT_STRICT, 1)
+        assert np.array_equal(c.trace(rays).view(np.uint8), ref.view(np.uint8))
+        c.set_option(capi.OPT_STRICT, 0)
+        got = c.trace(rays)
+        same = got["primitiveIndex"] == ref["primitiveIndex"]
+        assert same.mean() > 0.998          # (a ray on an edge or on a quad's diagonal may name the neighbouring triangle)
+        hit = same & (ref["primitiveIndex"] >= 0)
+        assert np.allclose(got["distance"][hit], ref["distance"][hit], rtol=2e-5, atol=2e-6)
+        assert np.abs(got["coordinates"][hit] - ref["coordinates"][hit]).max() < 2e-4
+    finally:
+        c.close()
+
+
 def _random_soup(O, n, seed):
     """A hostile triangle soup inside the Cornell room: random triangles plus exact duplicates (tie-break by
     primitive index), coplanar overlapping pairs, zero-area and needle triangles, a few emissive / masked ones."""
