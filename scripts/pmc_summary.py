@@ -96,8 +96,8 @@ for cfg in cfgs:
         write = c.get("WRITE_SIZE", 0.0) * 1024.0
         dram32 = c.get("TCC_EA0_RDREQ_DRAM_32B_sum")
         rec = {"unit": "EVERY counter below is per bench step (one trg_render of the whole configuration): the sum over the kernels listed in `kernels`",
-               "kernel": " + ".join(sorted(k.split("(")[0].replace("void ", "").replace("trgk_fast::", "") for k in tk)),
-               "kernels": {k.split("(")[0].replace("void ", "").replace("trgk_fast::", ""): {"launches_per_step": launches(k) / steps, "launches_profiled": launches(k),
+               "kernel": " + ".join(sorted(k.split("(")[0].replace("void ", "").replace("trgk_regen_fast::", "").replace("trgk_fast::", "") for k in tk)),
+               "kernels": {k.split("(")[0].replace("void ", "").replace("trgk_regen_fast::", "").replace("trgk_fast::", ""): {"launches_per_step": launches(k) / steps, "launches_profiled": launches(k),
                            "valu_insts_per_launch": tk[k].get("SQ_INSTS_VALU", {}).get("median"),
                            "lanes_active_per_valu_inst": (tk[k]["SQ_THREAD_CYCLES_VALU"]["median"] / tk[k]["SQ_INSTS_VALU"]["median"]) if "SQ_THREAD_CYCLES_VALU" in tk[k] and tk[k].get("SQ_INSTS_VALU", {}).get("median") else None}
                            for k in tk},

@@ -7,7 +7,7 @@ import sys
 
 pat = sys.argv[1]
 flags = sys.argv[2:]
-subprocess.check_call(["hipcc", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-fvisibility=hidden", "-Iinclude", "--offload-arch=gfx950",
+subprocess.check_call(["hipcc", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-fvisibility=hidden", "-Iinclude", "--offload-arch=gfx950",
                        "-DTRG_STRICT=0"] + flags + ["-S", "--cuda-device-only", "toyraygun_amd/csrc/trg_kernels.hip", "-o", "/tmp/spill_map.s"],
                       stderr=subprocess.DEVNULL)
 lines = open("/tmp/spill_map.s").read().split("\n")

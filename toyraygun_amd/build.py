@@ -57,12 +57,19 @@ def build(force=False, verbose=False):
     # -fno-slp-vectorize: the SLP vectoriser pairs the Halton digit chains of two dimensions into v_pk_mul_f32 /
     # v_pk_fma_f32, which are not faster than two scalar ops on gfx950 and cost 10 VGPRs + scratch spills
     # (80 VGPRs + 48 B scratch -> 70 VGPRs, none): +9 % on C2, +2.5 % on C4 ('registers')
-    kern = dev + ["-fno-slp-vectorize"]
+    # -mllvm -amdgpu-sched-strategy=max-ilp (round 4): the instruction scheduler's ILP-first strategy; same instructions, other order --
+    # render_kernel<LDS scene> 61 VGPRs + 12 in scratch -> 63 and none, C2 -1.2 %, C3 -1.0 % time, C4 unchanged (profiles/r04/ab_sched_strategy.txt)
+    kern = dev + ["-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+    regen_only = ["-mllvm", "-enable-post-misched=0"]
 
     objs = []
     units = [
-        ("trg_kernels_fast.o", os.path.join(CSRC, "trg_kernels.hip"), kern + ["-DTRG_STRICT=0"]),
-        ("trg_kernels_strict.o", os.path.join(CSRC, "trg_kernels.hip"), kern + ["-DTRG_STRICT=1", "-ffp-contract=off"]),
+        # trg_kernels.hip as two translation units per build: 1 = everything but the path-regeneration kernels, 2 = those alone, without the
+        # post-RA scheduler (C4 -1.8 % time; the other kernels lose up to 0.4 % to that flag: profiles/r04/ab_sched_strategy.txt)
+        ("trg_kernels_fast.o", os.path.join(CSRC, "trg_kernels.hip"), kern + ["-DTRG_STRICT=0", "-DTRG_UNIT=1"]),
+        ("trg_kernels_fast_regen.o", os.path.join(CSRC, "trg_kernels.hip"), kern + regen_only + ["-DTRG_STRICT=0", "-DTRG_UNIT=2"]),
+        ("trg_kernels_strict.o", os.path.join(CSRC, "trg_kernels.hip"), kern + ["-DTRG_STRICT=1", "-ffp-contract=off", "-DTRG_UNIT=1"]),
+        ("trg_kernels_strict_regen.o", os.path.join(CSRC, "trg_kernels.hip"), kern + regen_only + ["-DTRG_STRICT=1", "-ffp-contract=off", "-DTRG_UNIT=2"]),
         ("trg_build.o", os.path.join(CSRC, "trg_build.hip"), dev),
         ("trg_capi.o", os.path.join(CSRC, "trg_capi.cpp"), ["-x", "hip", "--offload-arch=" + ARCH]),
         ("bvh_build.o", os.path.join(CSRC, "bvh_build.cpp"), ["-x", "hip", "--offload-arch=" + ARCH]),

@@ -22,7 +22,20 @@ using namespace trgdev;
 #define TRG_UNIFORMS_AT_USE 1
 #endif
 
-namespace SFX(trgk) {
+// Two translation units from this one file (build.py): TRG_UNIT 1 = everything but the path-regeneration kernels, TRG_UNIT 2 = the
+// path-regeneration kernels alone, in a namespace of their own (the helpers and small kernels both units contain are then different symbols)
+// and compiled WITHOUT the post-RA machine scheduler (-mllvm -enable-post-misched=0): -1.8 % on C4, where the other kernels lose 0 - 0.4 % to
+// that flag (profiles/r04/ab_sched_strategy.txt).  TRG_UNIT 0 (default: the developer tools) = one unit with everything.
+#ifndef TRG_UNIT
+#define TRG_UNIT 0
+#endif
+#if TRG_UNIT == 2
+#define TRG_KNS SFX(trgk_regen)
+#else
+#define TRG_KNS SFX(trgk)
+#endif
+
+namespace TRG_KNS {
 
 // Stage the scene blob into LDS (16-byte copies by the whole workgroup) or point at it in HBM.
 template <bool LDS_SCENE>
@@ -764,10 +777,11 @@ __global__ void offsets_kernel(uint32_t seed, uint32_t n, uint32_t *out) {
 }
 
 }  // namespace trgk_*
-using namespace SFX(trgk);
+using namespace TRG_KNS;
 
 namespace trg {
 
+#if TRG_UNIT != 2
 hipError_t SFX(launch_render)(const RenderParams &p, bool lds_scene, bool counters, uint32_t grid, size_t lds_bytes, hipStream_t s) {
     if (lds_scene) {
         if (counters) hipLaunchKernelGGL((render_kernel<true, true>), dim3(grid), dim3(kBlock), lds_bytes, s, p);
@@ -779,6 +793,8 @@ hipError_t SFX(launch_render)(const RenderParams &p, bool lds_scene, bool counte
     return hipGetLastError();
 }
 
+#endif  // TRG_UNIT != 2
+#if TRG_UNIT != 1
 hipError_t SFX(launch_render_regen)(const RenderParams &p, bool counters, uint32_t grid, size_t lds_bytes, hipStream_t s) {
     if (p.xq) {   // persistent workgroups popping from per-XCD job queues (TRG_OPT_TILE_ORDER 64 + n)
         if (counters) hipLaunchKernelGGL((render_regen_kernel<true, true>), dim3(grid), dim3(kBlock), lds_bytes, s, p);
@@ -794,6 +810,8 @@ hipError_t SFX(launch_regen_accumulate)(const RenderParams &p, uint32_t grid, hi
     hipLaunchKernelGGL(regen_accumulate_kernel, dim3(grid), dim3(kBlock), (size_t)p.spp * kBlock * 16u, s, p);
     return hipGetLastError();
 }
+#endif  // TRG_UNIT != 1
+#if TRG_UNIT != 2
 
 template <typename K>
 static hipError_t launch_big_lds(K kernel, const RenderParams &p, uint32_t grid, size_t lds_bytes, hipStream_t s) {
@@ -930,5 +948,7 @@ hipError_t SFX(launch_offsets)(uint32_t seed, uint32_t n, uint32_t *out, hipStre
     hipLaunchKernelGGL(offsets_kernel, dim3((n + 255) / 256), dim3(256), 0, s, seed, n, out);
     return hipGetLastError();
 }
+
+#endif  // TRG_UNIT != 2
 
 }  // namespace trg

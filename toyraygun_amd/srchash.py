@@ -24,7 +24,7 @@ def kernel_source_files():
 def _compile_flags():
     """The kernel compile flags of build.py (the `kern` / `common` lists and the -DTRG_* of the two kernel units), as source text."""
     src = open(os.path.join(_HERE, "build.py")).read()
-    keep = [l.strip() for l in src.splitlines() if re.search(r"^\s*(common|hidden|dev|kern)\s*=|trg_kernels_(fast|strict)\.o", l)]
+    keep = [l.strip() for l in src.splitlines() if re.search(r"^\s*(common|hidden|dev|kern|regen_only)\s*=|trg_kernels_(fast|strict)(_regen)?\.o", l)]
     return "\n".join(keep)
 
 
