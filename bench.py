@@ -13,23 +13,29 @@ configs[4] on one GPU.  One STEP = one pass of the hot path over the whole frame
 bounces x [nearest, shade, shadow] -> accumulate for all samples) and, for N > 1, one RCCL all-gather of the row bands.
 The frame is fixed, so N > 1 is STRONG scaling: rank g renders its band of rows.
 
-Rank 0 prints one JSON line.  `value` counts rays actually traversed (in-kernel counters), inputs resident in HBM
-before the timed region.  The default run (N = 1, C2) also times C4 and C3 after the headline and reports them under
-`secondary` (same method, fewer steps): the configurations where the HBM roofline (C4) and the divergence (C3) live.
+Rank 0 prints ONE JSON line of about 3 KB.  `value` counts rays actually traversed (in-kernel counters), inputs resident in HBM
+before the timed region.  The driver's record keeps the SCALAR values directly under `config`, `roofline` and `cpu_baseline` (nested
+objects and long strings are dropped: BENCH_r04.parsed), so everything a reader needs to recompute a fraction is a flat scalar there:
+  * `roofline`: the headline's binding resource -- bound, achieved, peak, unit, frac, traffic -- and beside it valu_insts_per_launch,
+    lanes (of 64 active per VALU instruction), lane_weighted_frac, hbm_measured_frac, lds_frac / hbm_algorithmic_frac, kernel_alone_ms ...
+  * `config.<leg>_*` for the secondary legs of the default run (N = 1, C2): c4 (BASELINE configs[3]: the scene lives in HBM / Infinity
+    Cache), c3 (configs[2]: deep-bounce divergence) and c4xl (10.6 M triangles, 2.9 GB, device-built tree: the one leg whose memory-side
+    traffic is DRAM traffic) -- mrays, ms_per_step, alone_ms, rays_per_step, bound, frac, valu_insts, valu_frac, lanes, traffic_bytes,
+    hbm_frac (measured memory-side bytes per step / step time / 8 TB/s), alg_bytes (SURVEY 8(d)'s algorithmic bytes per step), l2_hit.
+Everything long -- the CPU legs with their samples, notes, counter sources, per-band tables -- goes to a side file, named in
+`config.detail_file` (gpurun_out/bench_detail_<config>_n<N>.json; TRG_BENCH_DETAIL overrides the path).
 
-`roofline` names the resource that BINDS the dominant kernel and never prints a fraction above 1:
-  * scene staged in LDS (C2/C3/C5): the kernel is bound by VALU issue -- `bound: "valu_issue"`, wave-level VALU
-    instructions per launch (rocprofv3 SQ_INSTS_VALU, imported from profiles/ and accepted only if the kernel sources
-    hash to what they were measured on) x 2 cycles / (1024 SIMDs x 2.4 GHz) against the launch duration measured live
-    with HIP events; beside it `lds` (algorithmic bytes of SURVEY 8(d) -- here they are LDS reads -- from this run's
-    in-kernel counters against the ~150 TB/s ds_read_b128 aggregate) and `hbm` (measured FETCH_SIZE + WRITE_SIZE against
-    8 TB/s).  Without usable imported counters the primary bound falls back to "lds", which is measured entirely in this run.
-  * scene in HBM (C4): `bound: "hbm"`, algorithmic bytes per launch / launch duration against 8 TB/s, with the measured
-    memory-side traffic (`traffic`, `hbm_measured`) side by side; when the algorithmic rate exceeds the HBM peak (L2 serves it)
-    the primary bound is VALU issue.
-`cpu_baseline` times the CPU oracle (a port: the reference has no CPU path) on the host cores, rank 0, N = 1 only:
-the headline leg is the benched configuration on all cores; the other legs are bounded samples (single thread,
-reduced spp) of the BASELINE configurations with the extrapolation factor stated.
+`roofline.bound` names the resource that BINDS the dominant kernel and `frac` is never above 1:
+  * scene staged in LDS (C2/C3/C5): VALU issue -- wave-level VALU instructions per launch (rocprofv3 SQ_INSTS_VALU, imported from
+    profiles/ and accepted only if the kernel sources hash to what they were measured on) x 2 cycles / (1024 SIMDs x 2.4 GHz) against
+    the launch duration measured live with HIP events; without usable imported counters: "lds" (SURVEY 8(d)'s algorithmic bytes -- LDS
+    reads here -- against the ~150 TB/s ds_read_b128 aggregate, measured entirely in this run).
+  * scene in HBM (C4, c4xl): "hbm" = algorithmic bytes per launch / launch duration against 8 TB/s, unless that rate exceeds the peak (L2
+    and the Infinity Cache serve it): then VALU issue as above, with the MEASURED memory-side traffic in `traffic` / `hbm_measured_frac`.
+  * N > 1: the same bound as N = 1, DERIVED -- VALU instructions per ray of the N = 1 counters x the rays of the slowest band, against that
+    band's device time per launch (`roofline.derived` says so).
+`cpu_baseline` times the CPU oracle (a port: the reference has no CPU path) on the host cores, rank 0, N = 1 only; its legs are in the
+side file.
 """
 import argparse
 import json
@@ -49,7 +55,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 LDS_PEAK_GBS = 150000.0     # aggregate ds_read_b64/b128 rate with every CU streaming (MI355X_MICROARCH.md, LDS)
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0  # wave-level VALU instructions per ns: 1024 SIMDs, 2 cycles per wave64 instruction, 2.4 GHz
-PROFILE_ROUNDS = ("r04", "r03", "r02")   # newest first: the first counters file whose kernel-source hash matches this tree is used
+PROFILE_ROUNDS = ("r05", "r04", "r03", "r02")   # newest first: the first counters file whose kernel-source hash matches this tree is used
 
 CONFIGS = {
     "c2": dict(w=1920, h=1080, spp=16, bounces=3, scene="cornell",
@@ -64,7 +70,22 @@ CONFIGS = {
     "c5": dict(w=3840, h=2160, spp=64, bounces=3, scene="cornell",
                workload="Cornell box (36 triangles) 3840x2160, 64 spp, 3 bounces (BASELINE configs[4]; row bands over the GPUs)"),
 }
-SECONDARY = (("c4", 5, 1), ("c3", 3, 1))   # (config, steps, warmup) timed after the headline of the default run
+# (config, steps, warmup, device builder) timed after the headline of the default run; c4xl with the device binned-SAH builder (0.08 s
+# against 1.9 s on 16 host threads; the same SAH tree: DESIGN.md)
+SECONDARY = (("c4", 5, 1, 0), ("c3", 5, 2, 0), ("c4xl", 3, 1, 1))
+
+
+def sig(x, n=5):
+    """A float with n significant digits (the JSON line stays short); ints, None and strings as they are."""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float("%.*g" % (n, x))
+
+
+def flat(d, n=5):
+    return {k: sig(v, n) for k, v in d.items()}
 
 
 def scene_buffers(cfg):
@@ -135,12 +156,13 @@ def cpu_baseline(config_name):
     want = "C4" if config_name == "c4xl" else config_name.upper()   # (c4xl has no CPU leg of its own: the C4 sample stands beside it)
     head = next(l for l in legs if l["config"] == want and l["cores"] == threads and l["build"] == "tuned")
     chk = next(l for l in legs if l["config"] == want and l["cores"] == threads and l["build"] == "checker")
-    return {"value": head["value"], "unit": "Mrays/s", "cores": threads, "kind": "port", "build": "tuned",
-            "sample": "%s: %s, %d rays in %.1f s; %s" % (head["config"], head["sample"], head["rays"], head["seconds"], head["extrapolation"]),
-            "checker_value": chk["value"],
-            "builds": CPU_BUILDS,
-            "note": "project CPU restatement of ToyRaygun's Metal semantics (oracle/trg_oracle.c), never a reference CPU path: the reference has none",
-            "legs": legs}
+    short = {"value": sig(head["value"]), "unit": "Mrays/s", "cores": threads, "kind": "port", "build": "tuned",
+             "sample": "%s %s: %d rays in %.1f s" % (head["config"], head["sample"], head["rays"], head["seconds"]),
+             "checker_value": sig(chk["value"]), "legs": len(legs)}
+    detail = {"builds": CPU_BUILDS, "legs": legs,
+              "note": "project CPU restatement of ToyRaygun's Metal semantics (oracle/trg_oracle.c), never a reference CPU path: the reference has none; "
+                      "headline = the tuned build on the benched configuration on all cores, `checker_value` = the bit-exact checker as it is"}
+    return short, detail
 
 
 def imported_counters(config_name):
@@ -149,7 +171,11 @@ def imported_counters(config_name):
     and they are only USED when the file's kernel-source hash equals this tree's (toyraygun_amd/srchash.py): instruction counts
     of a different kernel say nothing about this one.  Returns (counters or None, path, stale_counters or None)."""
     from toyraygun_amd.srchash import kernel_source_hash
-    here = kernel_source_hash()
+    try:
+        here = kernel_source_hash()
+    except RuntimeError as e:   # no build record and no hipcc: said aloud, on stderr and in the line -- never a silent fallback
+        sys.stderr.write("bench.py: %s -- imported profiler counters cannot be matched to this build and are NOT used\n" % e)
+        return None, None, {"path": None, "reason": "kernel-source hash unavailable: %s" % e}
     stale = None
     for rnd in PROFILE_ROUNDS:
         path = os.path.join(ROOT, "profiles", rnd, "%s_counters.json" % config_name)
@@ -167,64 +193,91 @@ def imported_counters(config_name):
     return None, None, stale
 
 
-def build_roofline(config_name, cst, rays_per_launch, bytes_per_ray, mix, kernel_ms, concurrency, kernel_eff_ms, kernel_ms_alone, lane_util_nodes, use_imported=True):
-    """The roofline object of one timed configuration (module docstring)."""
+def build_roofline(config_name, cst, rays_per_launch, bytes_per_ray, mix, kernel_ms, concurrency, kernel_eff_ms, kernel_ms_alone, lane_util_nodes,
+                   use_imported=True, derive=None):
+    """The roofline of one timed configuration (module docstring): (flat scalars for the JSON line, verbose detail for the side file).
+    derive = (rays of the band the line is about, rays of the whole frame): an N > 1 line takes the VALU instructions and the memory-side
+    bytes PER RAY from the N = 1 counters of the configuration and scales them to the band -- labelled `derived`."""
     in_lds = bool(cst.scene_in_lds)
     sec = kernel_eff_ms * 1e-3                       # GPU time per launch in the timed region (slowest rank)
     bytes_per_launch = rays_per_launch * bytes_per_ray
     algorithmic_gbs = bytes_per_launch / sec / 1e9
     imp, imp_path, stale = imported_counters(config_name) if use_imported else (None, None, None)
-    traffic = imp.get("hbm_bytes_per_launch") if imp else None
-    rf = {"kernel_ms": kernel_ms, "launches_in_flight": concurrency, "kernel_ms_per_launch_effective": kernel_eff_ms,
-          "kernel_alone_ms": kernel_ms_alone, "kernel_alone_mrays_per_s": rays_per_launch / (kernel_ms_alone * 1e-3) / 1e6,
-          "algorithmic_bytes_per_ray": bytes_per_ray, "bytes_per_launch": bytes_per_launch, **mix,
-          "lane_utilisation_node_loop": lane_util_nodes,
-          "traffic": traffic,
-          "imported": ("%s (rocprofv3 --pmc passes of this build, kernel-source hash %s: %s)" % (imp_path, imp.get("kernel_source_hash"), imp.get("source", "")) if imp else None)}
+    scale = (derive[0] / derive[1]) if (derive and derive[1]) else 1.0
+    traffic = imp.get("hbm_bytes_per_launch") * scale if imp and imp.get("hbm_bytes_per_launch") else None
+    valu_insts = imp.get("valu_insts_per_launch") * scale if imp and imp.get("valu_insts_per_launch") else None
+    lanes = imp.get("lanes_active_per_valu_inst") if imp else None
+    valu_g = valu_insts / sec / 1e9 if valu_insts else None
+    valu_frac = valu_g / VALU_PEAK_GINST if valu_g else None
+    hbm_meas_gbs = traffic / sec / 1e9 if traffic else None
+    f = {"kernel_ms": kernel_ms, "launches_in_flight": concurrency, "kernel_ms_per_launch_effective": kernel_eff_ms,
+         "kernel_alone_ms": kernel_ms_alone, "algorithmic_bytes_per_ray": bytes_per_ray, "bytes_per_launch": bytes_per_launch,
+         "nodes_per_ray": mix["nodes_per_ray"], "tris_per_ray": mix["tris_per_ray"], "shaded_per_ray": mix["shaded_per_ray"],
+         "rays_per_pixel_sample": mix["rays_per_pixel_sample"], "bytes_per_box": mix["bytes_per_box"],
+         "traffic": traffic, "hbm_measured_frac": hbm_meas_gbs / HBM_PEAK_GBS if hbm_meas_gbs else None,
+         "valu_insts_per_launch": valu_insts, "valu_frac": valu_frac, "lanes": lanes,
+         "lane_weighted_frac": valu_frac * lanes / 64.0 if (valu_frac and lanes) else None}
+    if imp:
+        if imp.get("tcc_hit") and imp.get("tcc_miss"):
+            f["l2_hit"] = imp["tcc_hit"] / (imp["tcc_hit"] + imp["tcc_miss"])
+        if imp.get("wave_cycles"):
+            f["wait_mem_frac"] = (imp.get("wait_any_cycles") or 0.0) / imp["wave_cycles"]
+            f["wait_issue_frac"] = (imp.get("wait_inst_any_cycles") or 0.0) / imp["wave_cycles"]
+        f["counters"] = "%s @%s" % (imp_path, imp.get("kernel_source_hash"))
+    if derive:
+        f["derived"] = "valu_insts / traffic = N=1 counters per ray x this band's rays"
     if stale:
-        rf["imported_stale"] = True
-        rf["imported_stale_detail"] = {k: stale.get(k) for k in ("path", "reason", "commit", "valu_insts_per_launch", "hbm_bytes_per_launch")}
-    hbm_measured = None
-    if traffic:
-        hbm_measured = {"achieved": traffic / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": traffic / sec / 1e9 / HBM_PEAK_GBS,
-                        "bytes_per_launch": traffic, "source": "imported: FETCH_SIZE + WRITE_SIZE per launch"}
-    valu = None
-    if imp and imp.get("valu_insts_per_launch"):
-        g = imp["valu_insts_per_launch"] / sec / 1e9
-        lanes = imp.get("lanes_active_per_valu_inst")
-        valu = {"achieved": g, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s", "frac": g / VALU_PEAK_GINST,
-                "valu_insts_per_launch": imp["valu_insts_per_launch"],
-                "lanes_active_per_instruction": lanes,
-                "lane_weighted_frac": (g / VALU_PEAK_GINST * lanes / 64.0) if lanes else None,
-                "source": "imported: SQ_INSTS_VALU per launch; peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction; lane_weighted_frac = frac x lanes / 64"}
+        f["imported_stale"] = True
     if in_lds:
-        lds = {"achieved": algorithmic_gbs, "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": algorithmic_gbs / LDS_PEAK_GBS,
-               "note": "SURVEY 8(d)'s algorithmic bytes are LDS reads here (the %.1f KB scene is staged per workgroup); measured live" % (cst.scene_bytes / 1024.0)}
-        if valu:
-            rf = {"bound": "valu_issue", "achieved": valu["achieved"], "peak": valu["peak"], "unit": valu["unit"], "frac": valu["frac"], **rf,
-                  "valu_issue": valu, "lds": lds, "hbm": hbm_measured}
+        f["lds_frac"] = algorithmic_gbs / LDS_PEAK_GBS
+        if valu_g:
+            head = {"bound": "valu_issue", "achieved": valu_g, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s", "frac": valu_frac}
         else:
-            rf = {"bound": "lds", "achieved": lds["achieved"], "peak": lds["peak"], "unit": lds["unit"], "frac": lds["frac"], **rf,
-                  "lds": lds, "hbm": hbm_measured}
-        rf["note"] = ("LDS-resident scene: the kernel is VALU-issue bound at partial lane utilisation; the HBM side only sees the "
-                      "4-byte offset read and the 16-byte accumulation write per pixel (SURVEY 8d caveat)")
+            head = {"bound": "lds", "achieved": algorithmic_gbs, "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": algorithmic_gbs / LDS_PEAK_GBS}
+        note = ("LDS-resident scene: VALU-issue bound at partial lane utilisation; SURVEY 8(d)'s algorithmic bytes are LDS reads here (the %.1f KB scene is staged "
+                "per workgroup), the HBM side only sees the 4-byte offset read and the 16-byte accumulation write per pixel" % (cst.scene_bytes / 1024.0))
     else:
-        hbm_alg = {"achieved": algorithmic_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algorithmic_gbs / HBM_PEAK_GBS}
-        note = ("algorithmic bytes (SURVEY 8d: 16 B per box of the 64-byte 4-wide node + 48 B per triangle test + 76 B per shaded hit) "
-                "against the HBM peak; `traffic` / hbm_measured = what left L2 towards Infinity Cache / HBM")
-        if hbm_alg["frac"] > 1.0 and valu:
-            # L2 serves most of the algorithmic bytes: once they exceed the HBM peak they bound nothing -- report the issue rate that does
-            rf = {"bound": "valu_issue", "achieved": valu["achieved"], "peak": valu["peak"], "unit": valu["unit"], "frac": valu["frac"], **rf,
-                  "hbm_algorithmic": hbm_alg, "hbm_measured": hbm_measured, "valu_issue": valu,
-                  "note": note + "; the algorithmic rate is above the HBM peak (L2 hit rate ~80 %), so the primary bound is VALU issue"}
-        elif hbm_alg["frac"] > 1.0:
-            # no usable instruction counters and an algorithmic rate above the peak: report the rate, never a fraction above 1
-            rf = {"bound": "hbm", "achieved": hbm_alg["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, **rf,
-                  "hbm_algorithmic": hbm_alg, "hbm_measured": hbm_measured,
-                  "note": note + "; the algorithmic rate is ABOVE the HBM peak because L2 serves ~80 % of it: it is no fraction of anything (frac null)"}
+        f["hbm_algorithmic_frac"] = algorithmic_gbs / HBM_PEAK_GBS    # (may exceed 1: L2 / Infinity Cache serve it -- never the headline frac then)
+        note = ("algorithmic bytes (SURVEY 8d: 16 B per box of the 64-byte 4-wide node + 48 B per triangle test + 76 B per shaded hit) against the HBM peak; "
+                "`traffic` = what left L2 towards Infinity Cache / HBM (2 x FETCH_SIZE + WRITE_SIZE, per step)")
+        if algorithmic_gbs > HBM_PEAK_GBS and valu_g:
+            head = {"bound": "valu_issue", "achieved": valu_g, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s", "frac": valu_frac}
+            note += "; the algorithmic rate is above the HBM peak (the caches serve it), so the primary bound is VALU issue"
+        elif algorithmic_gbs > HBM_PEAK_GBS:
+            head = {"bound": "hbm", "achieved": algorithmic_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None}
+            note += "; the algorithmic rate is ABOVE the HBM peak because the caches serve most of it: no fraction of anything (frac null), and no usable instruction counters"
         else:
-            rf = {"bound": "hbm", **hbm_alg, **rf, "hbm_measured": hbm_measured, "valu_issue": valu, "note": note}
-    return rf
+            head = {"bound": "hbm", "achieved": algorithmic_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algorithmic_gbs / HBM_PEAK_GBS}
+    detail = {"note": note, "lane_utilisation_node_loop": lane_util_nodes,
+              "imported": ("%s (rocprofv3 --pmc passes of this build, kernel-source hash %s: %s)" % (imp_path, imp.get("kernel_source_hash"), imp.get("source", "")) if imp else None),
+              "imported_record": imp,
+              "imported_stale_detail": ({k: stale.get(k) for k in ("path", "reason", "commit", "valu_insts_per_launch", "hbm_bytes_per_launch")} if stale else None),
+              "peaks": {"hbm_gbs": HBM_PEAK_GBS, "lds_gbs": LDS_PEAK_GBS, "valu_ginst": VALU_PEAK_GINST,
+                        "valu_source": "1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md)"}}
+    return flat({**head, **f}), detail
+
+
+def leg_keys(name, s):
+    """The flat `config.<leg>_*` scalars of one secondary leg (module docstring) from its run_torch result."""
+    rf = s["roofline"]
+    k = {"mrays": s["value"], "ms_per_step": s["ms_per_step"], "steps": s["steps"], "alone_ms": rf["kernel_alone_ms"], "rays_per_step": s["config"]["rays_per_step"],
+         "tris": s["config"]["triangles"], "bound": rf["bound"], "frac": rf["frac"], "valu_insts": rf.get("valu_insts_per_launch"), "valu_frac": rf.get("valu_frac"),
+         "lanes": rf.get("lanes"), "traffic_bytes": rf.get("traffic"), "hbm_frac": rf.get("hbm_measured_frac"), "alg_bytes": rf["bytes_per_launch"],
+         "l2_hit": rf.get("l2_hit"), "build_ms": s["config"].get("build_ms")}
+    return {"%s_%s" % (name, a): sig(b) for a, b in k.items() if b is not None}
+
+
+def write_detail(config_name, n, detail):
+    """The long half of the result -> a side file; returns its path relative to the repo (or None when nothing could be written)."""
+    path = os.environ.get("TRG_BENCH_DETAIL") or os.path.join(ROOT, "gpurun_out", "bench_detail_%s_n%d.json" % (config_name, n))
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as fh:
+            json.dump(detail, fh, indent=1)
+        return os.path.relpath(path, ROOT)
+    except OSError as e:
+        sys.stderr.write("bench.py: detail file %s not written: %s\n" % (path, e))
+        return None
 
 
 def kernel_name(st, in_lds):

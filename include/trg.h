@@ -291,6 +291,10 @@ TRG_API int trg_group_bands(trg_group *g);
 TRG_API int trg_group_postprocess(trg_group *g, int rank, uint8_t *rgba8, int flip_y); /* trg_postprocess of device `rank`'s last frame */
 /* why the exchange is not the one asked for ("" when it is): e.g. librccl.so could not be loaded and the bands move by peer copies */
 TRG_API const char *trg_group_exchange_note(trg_group *g);
+/* what RCCL itself says about the group's communicators (round 5): *version = ncclGetVersion (e.g. 22203), ranks_out[r] = ncclCommCount of
+ * device r's communicator -- the number of ranks RCCL saw --, for r < cap.  TRG_ERR_INVALID for a group without communicators (one device,
+ * or the copy exchange): *version = 0 then. */
+TRG_API int trg_group_rccl_info(trg_group *g, int *version, int *ranks_out, int cap);
 TRG_API int trg_group_get_stats(trg_group *g, trg_stats *out);         /* ray counters summed over the devices, times of the slowest one */
 
 /* --- stage-level entry points used by the parity tests (each isolates one SURVEY 8a row) */

@@ -405,7 +405,11 @@ def test_intersector_far_from_the_origin(capi, O, scale, shift, gpu_build):
                 assert same.mean() > 0.999
                 hit = same & (ref["distance"] >= 0)
                 assert np.allclose(got["distance"][hit], ref["distance"][hit], rtol=1e-4, atol=1e-6 * scale)
-            assert np.array_equal(c.trace(rays, any_hit=True) >= 0, O.intersect_any(s, rays) >= 0) or not strict
+            got_any, ref_any = c.trace(rays, any_hit=True) >= 0, O.intersect_any(s, rays) >= 0
+            if strict:
+                assert np.array_equal(got_any, ref_any)
+            else:   # shipped build: an occlusion answer may flip only where a ray grazes an edge (bounded like test_intersector's any-hit leg)
+                assert (got_any != ref_any).mean() < 2e-3, (got_any != ref_any).mean()
     finally:
         c.close()
 
@@ -2114,3 +2118,104 @@ def test_distance_ties_in_leaf_records_go_to_the_lower_original_index(capi, O):
                     assert (g[g >= 0] < twin[g[g >= 0]]).all() and (g == ref["primitiveIndex"]).mean() > 0.999, builder
         finally:
             c.close()
+
+
+def test_trace_ray_masks_beyond_the_two_low_bits(capi, O):
+    """the shipped build's plane test on an LDS-resident scene reads its mask off a u16 per record, (original index << 2) |
+    (material id & 3).  A ray mask with bits >= 2 set (0xFFFFFFFF, 4, 0x14 ...) must not match primitive-INDEX bits, and a material id
+    of 4 or more must still be honoured by such a ray: trg_trace routes those rays through the HBM records, which keep the whole id
+    (MetalRenderer.mm:269,276: ray.mask & triangle mask).  Material id 0 is hit by no ray at all.  Strict build: the oracle's records
+    bit for bit; shipped build: the same primitive except on grazing rays."""
+    rng = np.random.default_rng(505)
+    n = 60
+    ctr = rng.uniform(-0.8, 0.8, (n, 3))
+    tri = (ctr[:, None, :] + rng.normal(0, 0.25, (n, 3, 3))).astype(np.float32)
+    mats = rng.choice([0, 1, 2, 3, 4, 5, 6, 8, 0x10, 0x80000000], n)
+    mats[:10] = [0, 0, 4, 4, 8, 1, 2, 3, 0x10, 5]
+    s = O.OracleScene()
+    eye = np.eye(4, dtype=np.float32)
+    for k in range(n):
+        s.add_geometry(tri[k], [0, 1, 2], eye, (0.5, 0.5, 0.5), int(mats[k]))
+    b = s.buffers()
+    m = 20000
+    rays = np.zeros(m, O.RAY_DTYPE)
+    rays["origin"] = rng.uniform(-1.5, 1.5, (m, 3)).astype(np.float32)
+    d = rng.normal(size=(m, 3))
+    rays["direction"] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    rays["maxDistance"] = np.inf
+    c = capi.Context(16, 16)
+    try:
+        c.load_scene(b["positions"], b["normals"], b["colors"], b["indices"], b["material_ids"])
+        assert c.stats().scene_in_lds == 1
+        for masks in ([0xFFFFFFFF], [4], [0x14, 8, 0x80000000], [1, 3], [0], [1, 2, 3, 4, 0xFFFFFFFF, 0xC]):
+            rays["mask"] = rng.choice(np.array(masks, np.uint64), m).astype(np.uint32)
+            ref = O.intersect_nearest(s, rays)
+            ref_any = O.intersect_any(s, rays) >= 0
+            hitm = np.asarray(b["material_ids"], np.uint32)[np.maximum(ref["primitiveIndex"], 0)]
+            assert ((hitm & rays["mask"]) != 0)[ref["primitiveIndex"] >= 0].all()          # the oracle itself honours the 32-bit mask
+            if masks == [0]:
+                assert (ref["primitiveIndex"] == -1).all()
+            for strict in (1, 0):
+                c.set_option(capi.OPT_STRICT, strict)
+                got = c.trace(rays)
+                got_any = c.trace(rays, any_hit=True) >= 0
+                if strict:
+                    assert np.array_equal(got.view(np.uint8), ref.view(np.uint8)), masks
+                    assert np.array_equal(got_any, ref_any), masks
+                else:
+                    diff = got["primitiveIndex"] != ref["primitiveIndex"]
+                    if diff.any():
+                        _, _, margin = O.nearest_f64(s, rays[diff])
+                        assert (margin < 1e-5).all(), (masks, int(diff.sum()))
+                    assert diff.mean() < 3e-3, (masks, diff.mean())
+                    assert (got_any != ref_any).mean() < 2e-3, masks
+                    hit = got["primitiveIndex"] >= 0
+                    gm = np.asarray(b["material_ids"], np.uint32)[np.maximum(got["primitiveIndex"], 0)]
+                    assert ((gm & rays["mask"]) != 0)[hit].all(), masks                     # never a masked-out triangle, never material id 0
+    finally:
+        c.close()
+
+
+def test_pipelined_interleaved_copy_exchange_every_step(capi, O, cornell, monkeypatch):
+    """ADVICE r04 (write-after-read on slot re-use): with interleaved bands a destination's exchange stream UNPACKS its own band of
+    frame[r][slot] too, so the render that re-uses the slot must also wait for taken[r][slot] -- and a gather to a root must make the root wait
+    for its own unpack.  Big frames and next-to-free renders (1 spp, 1 bounce at 1280 x 720: the unpack of step i is still running when
+    step i + depth wants the slot), depth 2, three contexts on one device; EVERY step's image is checked -- sequence length L ends on step
+    L -- against the plain context, on every rank that holds it.  After a gather to a root the other ranks still show their OWN micro-bands
+    (trg.h: read_accum returns the image either way)."""
+    monkeypatch.setenv("TRG_GROUP_EXCHANGE", "copy")
+    w, h, n = 1280, 720, 3
+    ref_ctx = make_ctx(O, cornell, w, h)
+    refs = {}
+    try:
+        ref_ctx.set_option(capi.OPT_STRICT, 1)
+        for bnc in (1, 2):
+            ref_ctx.render(0, 1, bnc)
+            refs[bnc] = ref_ctx.read_accum()
+    finally:
+        ref_ctx.close()
+    assert not np.array_equal(refs[1], refs[2])
+    own = [np.array([y for y in range(h) if (y // 8) % n == r]) for r in range(n)]    # image rows of rank r's micro-bands
+    g = _group_ready(capi, O, cornell, [0] * n, w, h)
+    try:
+        g.set_bands(capi.BANDS_INTERLEAVED)
+        g.set_pipeline(2)
+        for mode, root in ((capi.GATHER_ALL, 0), (capi.GATHER_ROOT, 1)):
+            for L in range(1, 8):
+                for i in range(L):
+                    g.render(0, 1, 1 + (i & 1), gather=mode, root=root)      # consecutive steps are DIFFERENT pictures
+                ref = refs[1 + ((L - 1) & 1)]
+                for r in range(n):
+                    img = g.read_accum(r)
+                    if mode == capi.GATHER_ALL or r == root:
+                        assert np.array_equal(_bits(img), _bits(ref)), (mode, L, r)
+                    else:
+                        assert np.array_equal(_bits(img[own[r]]), _bits(ref[own[r]])), (mode, L, r, "own band")
+        # reconfiguring a drained group must not use up the context's per-stream scratch slots (ADVICE r04: 16 slots, `depth` new streams per call)
+        for k in range(8):
+            g.set_pipeline(8 if k & 1 else 7)
+            g.render(0, 1, 1, gather=capi.GATHER_ALL)
+        g.sync()
+        assert np.array_equal(_bits(g.read_accum(0)), _bits(refs[1]))
+    finally:
+        g.close()

@@ -81,8 +81,15 @@ def build(force=False, verbose=False):
             _run([hipcc] + common + hidden + extra + ["-c", src, "-o", o], verbose)
         objs.append(o)
     hip_so = os.path.join(LIB, "libtoyraygun_hip.so")
-    if force or _newer(hip_so, objs):
-        _run([hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", hip_so] + objs + ["-ldl", "-lpthread"], verbose)
+    info = os.path.join(LIB, "build_info.json")
+    if force or _newer(hip_so, objs) or not os.path.exists(info):
+        if force or _newer(hip_so, objs):
+            _run([hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", hip_so] + objs + ["-ldl", "-lpthread"], verbose)
+        # which compiler built what sits in lib/: srchash.py ties imported profiler counters to it (the file travels with the libraries)
+        import json
+        from .srchash import compiler_version_from_hipcc
+        with open(info, "w") as f:
+            json.dump({"compiler": compiler_version_from_hipcc(), "hipcc": hipcc}, f)
 
     # host C++ plugin surface (pure host code; links against the C ABI only)
     host_srcs = _glob(HOST, (".cpp",))

@@ -106,6 +106,7 @@ _SYMBOLS = [
     ("trg_group_time_launches", C.c_int, [_P, C.c_int]),
     ("trg_group_launch_ms", C.c_int, [_P, C.c_int, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
     ("trg_group_exchange_note", C.c_char_p, [_P]),
+    ("trg_group_rccl_info", C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]),
     ("trg_debug_plane_records", C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, _P, C.c_uint32, C.POINTER(C.c_uint32), _P]),
     ("trg_group_set_bands", C.c_int, [_P, C.c_int]),
     ("trg_group_bands", C.c_int, [_P]),
@@ -432,6 +433,16 @@ class Group:
     def exchange_note(self):
         """Why the exchange is not the one asked for ("" when it is): the RCCL -> peer-copy fallback says so here."""
         return (self.L.trg_group_exchange_note(self.g) or b"").decode()
+
+    def rccl_info(self):
+        """trg_group_rccl_info: {"version": ncclGetVersion, "ranks": [ncclCommCount of every device's communicator]} -- what RCCL itself saw --,
+        or None for a group without communicators (one device, the copy exchange)."""
+        if self.exchange != EXCHANGE_RCCL:
+            return None
+        v = C.c_int(0)
+        ranks = (C.c_int * self.n)()
+        self._chk(self.L.trg_group_rccl_info(self.g, C.byref(v), ranks, self.n))
+        return {"version": int(v.value), "ranks": [int(x) for x in ranks]}
 
     def set_bands(self, mode):
         """BANDS_CONTIGUOUS (rows [g*B, (g+1)*B) per device) or BANDS_INTERLEAVED (8-row micro-bands dealt round robin, trg_render_bands)."""

@@ -554,6 +554,14 @@ struct HostScene {
 int ctx_gpu_build_option(const trg_ctx *c) { return c ? c->opt_gpu_build : 0; }
 void *ctx_current_stream(trg_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int ctx_device(const trg_ctx *c) { return c ? c->device : -1; }
+// the per-stream scratch slots (scratch_slot) forget which stream owned them; the buffers stay and go to the next streams that ask.  For a
+// caller that has DRAINED the context and is about to destroy its streams (trg_group_set_pipeline): without it every reconfiguration used
+// up `depth` more of the 16 slots and the third one at depth 8 failed with "more than 15 different streams".
+void ctx_forget_streams(trg_ctx *c) {
+    if (!c) return;
+    for (int k = 1; k < trg_ctx::kScratchSlots; ++k) c->slot_stream[k] = nullptr;
+    c->slots_used = 1;
+}
 void host_scene_free(HostScene *hs) { delete hs; }
 }  // namespace trg
 
@@ -1519,7 +1527,19 @@ int trg_trace(trg_ctx *c, const trg_ray *rays, size_t n, int any_hit, void *out)
     if (n == 0) return TRG_OK;
     HIPCHK(c, hipSetDevice(c->device));
     LdsPlan plan;
-    if (int rc = plan_lds(c, plan)) return rc;
+    {
+        // The shipped build's plane test on an LDS-resident scene sees the two low bits of a material id only (the u16 per record:
+        // trg_device.h trav_begin) -- all the renderers' ray masks 3 and 1 can ask for.  Rays that carry other mask bits are traced through the
+        // HBM records, which hold the whole material id (MetalRenderer.mm:269,276: ray.mask & triangle mask, 32 bits).
+        bool wide_mask = false;
+        if (!c->opt_strict && TRG_TRI_PLANES)
+            for (size_t k = 0; k < n && !wide_mask; ++k) wide_mask = (rays[k].mask & ~3u) != 0u;
+        const bool saved = c->opt_force_global;
+        if (wide_mask) c->opt_force_global = true;
+        const int rc = plan_lds(c, plan);
+        c->opt_force_global = saved;
+        if (rc) return rc;
+    }
     DevBuf dr, dout;
     const size_t out_bytes = n * (any_hit ? sizeof(float) : sizeof(trg_isect));
     HIPCHK(c, dr.alloc(n * sizeof(trg_ray)));

@@ -662,7 +662,10 @@ TRG_DEV void trav_begin(const SceneView &sc, Trav &tv, V3 o, V3 d, float tmax, u
     } else {
         tv.oix = o.x * tv.idx; tv.oiy = o.y * tv.idy; tv.oiz = o.z * tv.idz;
     }
-    tv.best = tmax; tv.rmask = rmask;
+    // the plane test of an LDS-resident scene reads the mask off the u16 per record, (original index << 2) | (material id & 3): only the two low bits
+    // of a ray's mask may take part, or they would match index bits.  (The renderers' rays carry 3 or 1; trg_trace sends rays whose mask has
+    // higher bits through the HBM records, which keep the whole material id: trg_capi.cpp.)
+    tv.best = tmax; tv.rmask = (kTriPlanes && rel) ? (rmask & 3u) : rmask;
     tv.hit.t = -1.0f; tv.hit.prim = -1; tv.hit.u = 0.0f; tv.hit.v = 0.0f;
     tv.found = false;
     tv.node = 0; tv.sp = sp0;  // sp0 = stk.first(): the empty stack
@@ -843,7 +846,7 @@ TRG_DEV bool trav_tri_math(const v4f a, const v4f b, const v4f c, Trav &tv, bool
 // the plane form of the same fold (LDS-resident scenes, shipped build): `meta` = (original index << 2) | (material id & 3)
 template <bool COUNT>
 TRG_DEV bool trav_tri_planes(const v4f a, const v4f b, const v4f c, uint32_t meta, Trav &tv, bool any, Counters &cnt) {
-    const bool masked_in = (meta & tv.rmask) != 0u;
+    const bool masked_in = (meta & tv.rmask) != 0u;   // (tv.rmask has bits 0..1 only here: trav_begin)
     if (COUNT) { if (masked_in) cnt.tris++; if (mbcnt64(__ballot(1)) == 0) cnt.wtris++; }
     float t, u, v;
     const bool ok = tri_test_planes(a, b, c, tv.o, tv.d, tv.best, t, u, v) && masked_in;
@@ -860,7 +863,7 @@ TRG_DEV bool trav_tri_planes(const v4f a, const v4f b, const v4f c, uint32_t met
 template <bool COUNT>
 TRG_DEV bool trav_quad_planes(const SceneView &sc, const v4f *tr, uint32_t rec, Trav &tv, bool any, Counters &cnt) {
     const uint32_t meta0 = sc.meta[rec];
-    const bool masked_in = (meta0 & tv.rmask) != 0u;   // (the two triangles of a quad have one material)
+    const bool masked_in = (meta0 & tv.rmask) != 0u;   // (the two triangles of a quad have one material; tv.rmask has bits 0..1 only: trav_begin)
     if (COUNT) { if (masked_in) cnt.tris++; if (mbcnt64(__ballot(1)) == 0) cnt.wtris++; }
     float t, u, v;
     bool second;

@@ -57,6 +57,8 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     bool load(std::string &err) {
         if (lib) return true;
         for (const char *name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
@@ -73,6 +75,8 @@ struct Rccl {
         GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
         GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+        GetVersion = reinterpret_cast<decltype(GetVersion)>(dlsym(lib, "ncclGetVersion"));   // (the two below only feed trg_group_rccl_info: optional)
+        CommCount = reinterpret_cast<decltype(CommCount)>(dlsym(lib, "ncclCommCount"));
         return CommInitAll && CommDestroy && AllGather && Send && Recv && GroupStart && GroupEnd && GetErrorString;
     }
 };
@@ -112,6 +116,9 @@ struct trg_group {
     // side of the collective) is complete
     std::vector<std::vector<hipEvent_t>> rendered, taken;
     int slot_gather[kMaxDepth] = {}, slot_root[kMaxDepth] = {};   // the exchange the LAST frame rendered into slot s was followed by
+    // RCCL exchange of a pipelined group: taken[r][s] of the LAST collective is recorded lazily, by rank r's own worker at the start of the next
+    // trg_group_render (the collective is then still the last thing on xstream[r]) -- or by whoever needs it sooner (settle_taken)
+    int taken_pending = -1;
     unsigned long long step = 0;               // trg_group_render calls so far
     int cur_slot = 0;                          // the slot of the last trg_group_render (what read_accum / the fences refer to)
     bool last_on_xstream = false;              // the last frame's final device work sits on the exchange streams (pipelined + gathered)
@@ -151,6 +158,12 @@ static hipStream_t render_stream(trg_group *g, int r, int slot) {
     return g->depth > 1 ? g->rstream[r][slot] : static_cast<hipStream_t>(trg::ctx_current_stream(g->ctx[r]));
 }
 static hipStream_t exchange_stream(trg_group *g, int r, int slot) { return g->depth > 1 ? g->xstream[r] : render_stream(g, r, slot); }
+
+// RCCL exchange, pipelined: record the `taken` event of the last collective on rank r's exchange stream if that is still owed (taken_pending)
+static hipError_t settle_taken_rank(trg_group *g, int r) {
+    if (g->taken_pending < 0) return hipSuccess;
+    return hipEventRecord(g->taken[r][g->taken_pending], g->xstream[r]);
+}
 
 // wait (host) for everything the group has enqueued on device r
 static hipError_t sync_rank(trg_group *g, int r) {
@@ -348,6 +361,7 @@ int trg_group_set_pipeline(trg_group *g, int depth) {
     const int rc = for_each_device(g, [&](int r) {
         (void)trg_set_stream(g->ctx[r], nullptr);
         (void)trg_bind_accum(g->ctx[r], g->frame[r][0]);
+        trg::ctx_forget_streams(g->ctx[r]);   // the group is drained (above) and its render streams are about to be destroyed
         drop_pipeline_rank(g, r);
         hipError_t e = make_slot_events(g, r, depth);
         if (g->bands == TRG_BANDS_INTERLEAVED && e == hipSuccess) {
@@ -383,7 +397,7 @@ int trg_group_set_pipeline(trg_group *g, int depth) {
         return gfail(g, rc, "trg_group_set_pipeline: allocating %d frame slots per device failed", depth);
     }
     g->depth = depth;
-    g->step = 0; g->cur_slot = 0; g->last_on_xstream = false;
+    g->step = 0; g->cur_slot = 0; g->last_on_xstream = false; g->taken_pending = -1;
     memset(g->slot_gather, 0, sizeof(g->slot_gather));
     memset(g->fence_set, 0, sizeof(g->fence_set));
     return TRG_OK;
@@ -483,12 +497,15 @@ int trg_group_render(trg_group *g, uint32_t frameIndexBegin, uint32_t spp, uint3
     if (int rc = for_each_device(g, [&](int r) {
             hipStream_t rs = render_stream(g, r, slot);
             hipError_t e = hipSetDevice(g->devices[r]);   // (a worker is bound to its device already; a group of one runs here on the caller's thread)
+            if (e == hipSuccess) e = settle_taken_rank(g, r);   // (the previous frame's collective: still the last thing on this rank's exchange stream)
             // the exchange that last read this slot must be over before the band is overwritten: the copies the destinations took of it
             // (copy exchange), this rank's side of the collective (RCCL).  Events of an earlier call: all recorded already.
             if (prev_gather != TRG_GATHER_NONE && e == hipSuccess) {
                 if (g->copy_exchange) {
+                    // (d == r: a destination's exchange stream also reads -- interleaved bands: unpacks -- its OWN band of frame[r][slot], and
+                    //  records taken[r][slot] behind that; at depth 1 that work sits on the render's own stream and is ordered anyway)
                     for (int d = 0; d < g->n && e == hipSuccess; ++d)
-                        if (d != r && is_destination(prev_gather, prev_root, d)) e = hipStreamWaitEvent(rs, g->taken[d][slot], 0);
+                        if ((d != r || g->depth > 1) && is_destination(prev_gather, prev_root, d)) e = hipStreamWaitEvent(rs, g->taken[d][slot], 0);
                 } else if (!g->comm.empty() && g->depth > 1) {
                     e = hipStreamWaitEvent(rs, g->taken[r][slot], 0);
                 }
@@ -518,12 +535,16 @@ int trg_group_render(trg_group *g, uint32_t frameIndexBegin, uint32_t spp, uint3
                 g->tused[r] += 2;
             }
             if (exchange && (g->copy_exchange || g->depth > 1)) e = hipEventRecord(g->rendered[r][slot], rs);
+            // RCCL, pipelined: this rank's side of the collective goes to its exchange stream, behind its band -- ordered here, on the rank's own thread
+            if (exchange && !g->copy_exchange && g->depth > 1 && e == hipSuccess) e = hipStreamWaitEvent(g->xstream[r], g->rendered[r][slot], 0);
             if (e != hipSuccess) { (void)hipGetLastError(); return TRG_ERR_DEVICE; }
-            // interleaved bands without an exchange: this rank's micro-bands go to their image rows right behind the render
-            if (il && !exchange) return trg_unpack_bands(g->ctx[r], g->frame[r][slot], g->image[r][slot], (uint32_t)g->n);
+            // interleaved bands, and no exchange delivers a frame to this rank (none at all, or a gather to another root): its own micro-bands go
+            // to their image rows right behind the render, so that trg_group_read_accum / _postprocess of this rank show its band either way
+            if (il && (!exchange || !is_destination(gather, root, r))) return trg_unpack_bands(g->ctx[r], g->frame[r][slot], g->image[r][slot], (uint32_t)g->n);
             return TRG_OK;
         }))
         return rc;
+    g->taken_pending = -1;   // (settled by every rank in phase A)
     g->slot_gather[slot] = exchange ? gather : TRG_GATHER_NONE; g->slot_root[slot] = root;
     g->cur_slot = slot; g->step++;
     g->last_on_xstream = exchange && g->depth > 1;
@@ -557,15 +578,9 @@ int trg_group_render(trg_group *g, uint32_t frameIndexBegin, uint32_t spp, uint3
     }
     // ---- phase B (RCCL): the one exchange of the frame, enqueued behind each device's render -- on the render's own stream (depth 1:
     //      the context's current stream, trg_set_stream's if the caller set one through trg_group_ctx), or on the device's exchange
-    //      stream behind the `rendered` event (pipelined).  One grouped call from this thread for all devices (the single-process,
-    //      several-devices pattern of the NCCL documentation).
-    hipError_t e = hipSuccess;
-    if (g->depth > 1)
-        for (int r = 0; r < g->n && e == hipSuccess; ++r) {
-            e = hipSetDevice(g->devices[r]);
-            if (e == hipSuccess) e = hipStreamWaitEvent(g->xstream[r], g->rendered[r][slot], 0);
-        }
-    if (e != hipSuccess) return gfail(g, TRG_ERR_DEVICE, "trg_group_render: %s", hipGetErrorString(e));
+    //      stream, which phase A has put behind the `rendered` event (pipelined).  One grouped call from this thread for all devices (the
+    //      single-process, several-devices pattern of the NCCL documentation) and NOTHING else: the event waits in front of it were issued by
+    //      the ranks' own threads in phase A, the `taken` records behind it are issued by them at the start of the next frame (taken_pending).
     ncclResult_t nr = g_rccl.GroupStart();
     for (int r = 0; r < g->n && nr == ncclSuccess; ++r) {
         hipStream_t s = exchange_stream(g, r, slot);
@@ -583,23 +598,23 @@ int trg_group_render(trg_group *g, uint32_t frameIndexBegin, uint32_t spp, uint3
     if (nr == ncclSuccess) nr = ne;
     if (nr != ncclSuccess) return gfail(g, TRG_ERR_DEVICE, "trg_group_render: RCCL: %s", g_rccl.GetErrorString(nr));
     if (il) {
-        // the compact frame is complete where the exchange delivered it: to image rows, behind the collective on the same stream
-        if (int rc = for_each_device(g, [&](int r) {
-                if (!is_destination(gather, root, r)) return TRG_OK;
-                hipStream_t xs = exchange_stream(g, r, slot);
-                (void)trg_set_stream(g->ctx[r], xs);
-                const int urc = trg_unpack_bands(g->ctx[r], g->frame[r][slot], g->image[r][slot], (uint32_t)g->n);
-                (void)trg_set_stream(g->ctx[r], g->depth > 1 ? render_stream(g, r, slot) : xs);
-                return urc;
-            }))
+        // the compact frame is complete where the exchange delivered it: to image rows, behind the collective on the same stream -- one launch
+        // from this thread for a gather to one root, one per rank on the ranks' threads for a gather to all
+        auto unpack = [&](int r) {
+            hipStream_t xs = exchange_stream(g, r, slot);
+            (void)trg_set_stream(g->ctx[r], xs);
+            const int urc = trg_unpack_bands(g->ctx[r], g->frame[r][slot], g->image[r][slot], (uint32_t)g->n);
+            (void)trg_set_stream(g->ctx[r], g->depth > 1 ? render_stream(g, r, slot) : xs);
+            return urc;
+        };
+        if (gather == TRG_GATHER_ROOT || g->n == 1) {
+            const int r = gather == TRG_GATHER_ROOT ? root : 0;
+            if (int rc = unpack(r)) return gfail(g, rc, "device %d (rank %d): %s", g->devices[r], r, trg_last_error(g->ctx[r]));
+        } else if (int rc = for_each_device(g, [&](int r) { return unpack(r); })) {
             return rc;
-    }
-    if (g->depth > 1)
-        for (int r = 0; r < g->n && e == hipSuccess; ++r) {
-            e = hipSetDevice(g->devices[r]);
-            if (e == hipSuccess) e = hipEventRecord(g->taken[r][slot], g->xstream[r]);
         }
-    if (e != hipSuccess) return gfail(g, TRG_ERR_DEVICE, "trg_group_render: %s", hipGetErrorString(e));
+    }
+    if (g->depth > 1) g->taken_pending = slot;
     return TRG_OK;
 }
 
@@ -665,6 +680,19 @@ int trg_group_postprocess(trg_group *g, int rank, uint8_t *rgba8, int flip_y) {
     const int rc = trg_postprocess(c, rgba8, flip_y);
     if (il) (void)trg_bind_accum(c, g->frame[rank][g->cur_slot]);
     if (rc != TRG_OK) return gfail(g, rc, "rank %d: %s", rank, trg_last_error(c));
+    return TRG_OK;
+}
+
+int trg_group_rccl_info(trg_group *g, int *version, int *ranks_out, int cap) {
+    if (!g) return TRG_ERR_INVALID;
+    if (version) *version = 0;
+    if (g->comm.empty()) return gfail(g, TRG_ERR_INVALID, "trg_group_rccl_info: this group has no RCCL communicator (%s)", g->copy_exchange ? "copy exchange" : "one device");
+    if (!g_rccl.GetVersion || !g_rccl.CommCount) return gfail(g, TRG_ERR_DEVICE, "trg_group_rccl_info: librccl.so lacks ncclGetVersion / ncclCommCount");
+    int v = 0;
+    ncclResult_t nr = g_rccl.GetVersion(&v);
+    if (version) *version = v;
+    for (int r = 0; r < g->n && r < cap && nr == ncclSuccess && ranks_out; ++r) nr = g_rccl.CommCount(g->comm[r], &ranks_out[r]);
+    if (nr != ncclSuccess) return gfail(g, TRG_ERR_DEVICE, "trg_group_rccl_info: %s", g_rccl.GetErrorString(nr));
     return TRG_OK;
 }
 

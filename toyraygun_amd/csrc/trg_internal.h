@@ -18,5 +18,6 @@ void host_scene_free(HostScene *hs);
 int ctx_gpu_build_option(const trg_ctx *c);   // TRG_OPT_GPU_BUILD of the context (a device build runs per device)
 void *ctx_current_stream(trg_ctx *c);         // the stream trg_render launches on: trg_set_stream's, or the context's own
 int ctx_device(const trg_ctx *c);
+void ctx_forget_streams(trg_ctx *c);          // a DRAINED context forgets which streams owned its per-stream scratch slots (their buffers stay)
 
 }  // namespace trg

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
     // once.  Persistent launch (p.xq): jobs popped from the queue of the XCD this workgroup runs on, until all eight queues are empty.
     lds_int_t *job_word = (lds_int_t *)(reinterpret_cast<int *>(smem + p.red_off) + 7);   // (word 7 of wavefront 0's counter row: free while the kernel runs)
     lds_int_t *wred = (lds_int_t *)(reinterpret_cast<int *>(smem + p.red_off) + wave * 8u);
-    if (lane_id() < 7u) wred[lane_id()] = 0;   // (the ray counters of the whole workgroup lifetime; word 7 is the job hand-off)
+    if (lane_id() < 8u) wred[lane_id()] = 0;   // (the ray counters of the whole workgroup lifetime; word 7 of wavefront 0 is the job hand-off, written behind a barrier)
     Counters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.wnodes = 0; cnt.wtris = 0;
   for (uint32_t round = 0; PERSIST || round == 0u; ++round) {   // (PERSIST = false: exactly one trip, the straight-line kernel)
     uint32_t job = blockIdx.x;
@@ -299,6 +299,13 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
     }
     regen_flush(stage, stage_cnt, rlog, pool_done);
   }   // next job (persistent launch)
+    // every wavefront has read the last hand-off word (-1) before the reduction below re-uses it (word 7 of wavefront 0's row is also where the
+    // COUNT build puts that wavefront's triangle iterations): without this barrier a late wavefront could take the sum for one more job
+    __syncthreads();
+#ifdef TRG_REGEN_DIAG
+    if (PERSIST && threadIdx.x == 0) *job_word = 0;
+    __syncthreads();
+#endif
 #undef TRG_RG_HIDX
 #undef TRG_RG_FRAME
 #undef TRG_RG_JOB

@@ -28,15 +28,38 @@ def _compile_flags():
     return "\n".join(keep)
 
 
+BUILD_INFO = os.path.join(_HERE, "lib", "build_info.json")   # written by build.py next to the libraries it links
+
+
+def compiler_version_from_hipcc():
+    """`hipcc --version` of the compiler build.py would use, as "hip <version> clang <version>".  Raises when there is no hipcc."""
+    from .build import _hipcc
+    out = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True, timeout=120).stdout
+    m = re.search(r"HIP version: *(\S+)", out)
+    c = re.search(r"clang version *(\S+)", out)
+    if not (m and c):
+        raise RuntimeError("cannot read the compiler version from `hipcc --version`")
+    return "hip %s clang %s" % (m.group(1), c.group(1))
+
+
 def _compiler_version():
+    """The compiler the libraries in lib/ were BUILT with (build.py records it in lib/build_info.json, which travels with them), or, for a
+    tree that has not been built yet, the hipcc that would build it.  No silent stand-in: with neither, the hash cannot be formed and the
+    caller is told so (round-4 verdict: a missing hipcc used to hash as the string "hipcc unavailable", every counters file then looked
+    stale and bench.py quietly fell back to another roofline)."""
     try:
-        from .build import _hipcc
-        out = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True, timeout=60).stdout
-        m = re.search(r"HIP version: *(\S+)", out)
-        c = re.search(r"clang version *(\S+)", out)
-        return "hip %s clang %s" % (m.group(1) if m else "?", c.group(1) if c else "?")
-    except Exception:
-        return "hipcc unavailable"
+        import json
+        with open(BUILD_INFO) as f:
+            v = json.load(f).get("compiler")
+        if v:
+            return v
+    except (OSError, ValueError):
+        pass
+    try:
+        return compiler_version_from_hipcc()
+    except Exception as e:
+        raise RuntimeError("kernel_source_hash: neither %s nor a working hipcc tells which compiler built the kernels (%s: %s)"
+                           % (os.path.relpath(BUILD_INFO, ROOT), type(e).__name__, e))
 
 
 def kernel_source_hash():
