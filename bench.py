@@ -58,16 +58,16 @@ VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0  # wave-level VALU instructions per ns: 10
 PROFILE_ROUNDS = ("r05", "r04", "r03", "r02")   # newest first: the first counters file whose kernel-source hash matches this tree is used
 
 CONFIGS = {
-    "c2": dict(w=1920, h=1080, spp=16, bounces=3, scene="cornell",
+    "c2": dict(w=1920, h=1080, spp=16, bounces=3, scene="cornell", short="C2: Cornell box 1920x1080, 16 spp, 3 bounces (BASELINE configs[1])",
                workload="Cornell box (36 triangles) 1920x1080, 16 spp, 3 bounces (BASELINE configs[1])"),
-    "c3": dict(w=1920, h=1080, spp=256, bounces=8, scene="cornell",
+    "c3": dict(w=1920, h=1080, spp=256, bounces=8, scene="cornell", short="C3: Cornell box 1920x1080, 256 spp, 8 bounces (BASELINE configs[2])",
                workload="Cornell box (36 triangles) 1920x1080, 256 spp, 8 bounces (BASELINE configs[2], deep-bounce divergence stress)"),
-    "c4": dict(w=1920, h=1080, spp=16, bounces=3, scene="lattice44",
+    "c4": dict(w=1920, h=1080, spp=16, bounces=3, scene="lattice44", short="C4: Cornell box + 44^3 cubes = 1,022,244 triangles, 1920x1080, 16 spp, 3 b (BASELINE configs[3])",
                workload="Cornell box + 44x44x44 replicated cubes = 1,022,244 triangles, 1920x1080, 16 spp, 3 bounces (BASELINE configs[3], BVH/HBM stress)"),
-    "c4xl": dict(w=1920, h=1080, spp=16, bounces=3, scene="lattice96",
+    "c4xl": dict(w=1920, h=1080, spp=16, bounces=3, scene="lattice96", short="c4xl: Cornell box + 96^3 cubes = 10,616,868 triangles (2.9 GB), 1920x1080, 16 spp, 3 b (not in BASELINE)",
                  workload="Cornell box + 96x96x96 replicated cubes = 10,616,868 triangles (2.9 GB on the device: beyond the 256 MiB Infinity Cache), 1920x1080, 16 spp, 3 bounces "
                           "(not a BASELINE configuration: the leg where memory-side traffic is DRAM traffic)"),
-    "c5": dict(w=3840, h=2160, spp=64, bounces=3, scene="cornell",
+    "c5": dict(w=3840, h=2160, spp=64, bounces=3, scene="cornell", short="C5: Cornell box 3840x2160, 64 spp, 3 bounces (BASELINE configs[4])",
                workload="Cornell box (36 triangles) 3840x2160, 64 spp, 3 bounces (BASELINE configs[4]; row bands over the GPUs)"),
 }
 # (config, steps, warmup, device builder) timed after the headline of the default run; c4xl with the device binned-SAH builder (0.08 s
@@ -267,6 +267,36 @@ def leg_keys(name, s):
     return {"%s_%s" % (name, a): sig(b) for a, b in k.items() if b is not None}
 
 
+def plugin_leg(frames=None):
+    """The reference's OWN hot loop through the drop-in boundary (round-4 verdict, item 5): Engine::init(1024, 768) -> createRenderer()->init()
+    -> loadScene(createCornellBoxScene()) -> K x renderFrame() -> finish(), exactly the call sequence of main.cpp:21-95, through
+    libtoyraygun.so (toyraygun_amd/csrc/host/capi_host.cpp trh_run_app) -- next to the same K samples through ONE renderFrames(K) = one
+    trg_render.  renderFrame() never waits (MetalRenderer.mm:377,385-387: three launches in flight); frames accepted while the device is busy
+    share the next launch (HipRenderer.cpp).  Wall time from the first renderFrame() to the completion of the last frame on the device."""
+    from toyraygun_amd import host
+    W, H = 1024, 768                                   # main.cpp:22
+    K = frames or int(os.environ.get("TRG_BENCH_PLUGIN_FRAMES", "1024"))
+    host.run_app(W, H, 64, 3, batch=False)             # warm-up: library, code objects, allocator
+    best = None
+    for _ in range(3):                                 # (the loop is a few tens of milliseconds: the best of three, both ways)
+        _, ms, rays, launches = host.run_app(W, H, K, 3, batch=False, want_launches=True)
+        if best is None or ms < best[0]:
+            best = (ms, rays, launches)
+    bbest = None
+    for _ in range(3):
+        _, msb, raysb, lb = host.run_app(W, H, K, 3, batch=True, want_launches=True)
+        if bbest is None or msb < bbest[0]:
+            bbest = (msb, raysb, lb)
+    ms, rays, launches = best
+    msb, raysb, lb = bbest
+    f = {"plugin_frames": K, "plugin_loop_ms": ms, "plugin_fps": K / (ms * 1e-3), "plugin_mrays": rays / (ms * 1e-3) / 1e6, "plugin_launches": launches,
+         "plugin_frames_per_launch": K / max(launches, 1), "plugin_batched_ms": msb, "plugin_batched_mrays": raysb / (msb * 1e-3) / 1e6,
+         "plugin_loop_over_batched": ms / msb}
+    d = {"what": "main.cpp:21-95 call sequence at 1024x768, 1 spp per renderFrame(), 3 bounces, through libtoyraygun.so; batched = the same samples through one renderFrames(K)",
+         "rays_loop": rays, "rays_batched": raysb, "launches_batched": lb}
+    return flat(f), d
+
+
 def write_detail(config_name, n, detail):
     """The long half of the result -> a side file; returns its path relative to the repo (or None when nothing could be written)."""
     path = os.environ.get("TRG_BENCH_DETAIL") or os.path.join(ROOT, "gpurun_out", "bench_detail_%s_n%d.json" % (config_name, n))
@@ -280,16 +310,22 @@ def write_detail(config_name, n, detail):
         return None
 
 
-def kernel_name(st, in_lds):
+def kernel_name_long(st, in_lds):
     return (("render_regen_kernel (path regeneration: a job pool per workgroup) + regen_accumulate_kernel" if getattr(st, "last_regen", 0)
              else "render_kernel" if st.last_frame_split <= 1 else "render_fp_kernel, %d frame lanes" % st.last_frame_split)
             + ("<LDS scene>" if in_lds else "<HBM scene, quantised 4-wide BVH, 128-byte leaf records>")
             + (" + tail compaction from bounce %d (render_head / render_tail kernels)" % st.last_tail_bounce if st.last_tail_bounce else "") + " (fast build)")
 
 
-def run_torch(config_name, steps, warmup, env, use_imported=True):
+def kernel_name(st, in_lds):
+    """Short form for the JSON line (the driver's record cuts strings at ~120 characters)."""
+    k = ("render_regen_kernel+regen_accumulate" if getattr(st, "last_regen", 0) else "render_kernel" if st.last_frame_split <= 1 else "render_fp_kernel/%d lanes" % st.last_frame_split)
+    return k + ("<LDS>" if in_lds else "<HBM>") + ("+head/tail from bounce %d" % st.last_tail_bounce if st.last_tail_bounce else "") + " fast build"
+
+
+def run_torch(config_name, steps, warmup, env, use_imported=True, gpu_build=None):
     """One configuration on this process' GPU (N = 1) or on its row band (one process per GPU under torch.distributed.run).
-    Returns the result dict on rank 0, None elsewhere."""
+    Returns (result dict, detail dict) on rank 0, (None, None) elsewhere."""
     import torch
     from toyraygun_amd import capi
     from toyraygun_amd.dist import DistributedRenderer
@@ -301,8 +337,10 @@ def run_torch(config_name, steps, warmup, env, use_imported=True):
     # images, so the next steps fill the CUs that the tail of step k leaves idle (or that a small row band never fills),
     # and the gather of k overlaps the renders that follow
     r = DistributedRenderer(W, H, local_rank, pipelined=not os.environ.get("TRG_BENCH_SERIAL"))
-    if os.environ.get("TRG_BENCH_GPU_BUILD"):   # 1 = device binned SAH, 2 = LBVH, 3 = PLOC (default: the host SAH builder)
-        r.ctx.set_option(capi.OPT_GPU_BUILD, int(os.environ["TRG_BENCH_GPU_BUILD"]))
+    if gpu_build is None:
+        gpu_build = int(os.environ.get("TRG_BENCH_GPU_BUILD", "0"))   # 1 = device binned SAH, 2 = LBVH, 3 = PLOC (default: the host SAH builder)
+    if gpu_build:
+        r.ctx.set_option(capi.OPT_GPU_BUILD, gpu_build)
     t_load = time.perf_counter()
     r.load_scene(buffers)
     load_s = time.perf_counter() - t_load
@@ -349,6 +387,8 @@ def run_torch(config_name, steps, warmup, env, use_imported=True):
     sync_all()
     r.ctx.reset_stats()
     r.time_launches = True   # HIP events around every launch, on the stream it runs on, no host sync
+    # THE TIMED REGION: `steps` steps, the exchange north_star names behind each (N > 1: the gather of the bands to rank 0, overlapping the
+    # renders that follow)
     t0 = time.perf_counter()
     for _ in range(steps):
         r.render(0, SPP, BOUNCES, gather=gather)
@@ -358,46 +398,78 @@ def run_torch(config_name, steps, warmup, env, use_imported=True):
     launch_ms = r.launch_ms()
     st = r.ctx.stats()
 
+    def timed_again(mode):   # the same steps with another exchange, after the timed region: reported beside the headline
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            r.render(0, SPP, BOUNCES, gather=mode)
+        sync_all()
+        return time.perf_counter() - t1
+    dt_all = timed_again("all") if gather else None
+    dt_none = timed_again(False) if gather else None
+
     rays_local = float(st.rays)
     # average launch duration over the timed region (what rocprofv3 --kernel-trace reports for the same command).  With
     # several launches in flight each one shares the GPU and lasts longer than alone; `concurrency` = sum of the launch
     # durations / wall time says how many overlapped, and kernel_ms / concurrency is the time the GPU spent per launch.
     kernel_ms = sum(launch_ms) / max(len(launch_ms), 1)
     concurrency = max(1.0, sum(launch_ms) / (dt * 1e3))
+    band_rays = float(rays_per_launch)
     if distributed:
-        t = torch.tensor([dt, rays_local, kernel_ms / concurrency], dtype=torch.float64, device=dev if env.get("backend") != "gloo" else "cpu")
+        cpu = env.get("backend") == "gloo"
+        t = torch.tensor([dt, rays_local, kernel_ms / concurrency, dt_all or 0.0, dt_none or 0.0], dtype=torch.float64, device="cpu" if cpu else dev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        # the slowest rank's band: its device time per launch and ITS rays (for the derived roofline)
+        mine = torch.tensor([kernel_ms / concurrency, band_rays, kernel_ms, concurrency, kernel_ms_alone], dtype=torch.float64, device="cpu" if cpu else dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        slow = max(range(world), key=lambda k: float(allr[k][0]))
         dt, rays_total, kernel_eff_ms = float(tmax[0]), float(tsum[1]), float(tmax[2])
+        dt_all, dt_none = float(tmax[3]), float(tmax[4])
+        band_rays, kernel_ms, concurrency, kernel_ms_alone = float(allr[slow][1]), float(allr[slow][2]), float(allr[slow][3]), float(allr[slow][4])
+        frame_rays = sum(float(a[1]) for a in allr)
     else:
         rays_total = rays_local
         kernel_eff_ms = kernel_ms / concurrency
+        frame_rays = band_rays
 
-    out = None
+    out, detail = None, None
     if rank == 0:
         in_lds = bool(cst.scene_in_lds)
-        rf = build_roofline(config_name, cst, rays_per_launch, bytes_per_ray, mix, kernel_ms, concurrency, kernel_eff_ms, kernel_ms_alone, lane_util_nodes,
-                            use_imported=use_imported and world == 1)
+        rf, rf_detail = build_roofline(config_name, cst, band_rays, bytes_per_ray, mix, kernel_ms, concurrency, kernel_eff_ms, kernel_ms_alone, lane_util_nodes,
+                                       use_imported=use_imported, derive=(band_rays, frame_rays) if world > 1 else None)
+        builder = {0: "host SAH", 1: "device binned SAH", 2: "device LBVH", 3: "device PLOC"}[gpu_build]
+        config = {"workload": cfg["short"], "name": config_name, "rays_per_step": rays_total / steps,
+                  "sharding": ("none" if not distributed else "%s bands, 1 process/GPU, %s gather to rank 0 per frame" % ("interleaved 8-row" if r.interleaved else "contiguous row", "gloo (host memory: rehearsal)" if env.get("backend") == "gloo" else "RCCL")),
+                  "pipeline": "%d frames in flight on alternating streams" % len(r.render_streams) if getattr(r, "_overlap", False) else "serial launches",
+                  "kernel": kernel_name(st, in_lds), "triangles": int(len(buffers["material_ids"])), "scene_bytes": int(cst.scene_bytes),
+                  "builder": builder, "build_ms": sig(cst.last_build_ms), "load_scene_s": sig(load_s), "bvh_depth4": int(cst.bvh_depth4), "nodes4": int(cst.bvh_nodes4)}
+        if gather:
+            config.update({"exchange": "root gather" if r.gather_mode == "root" else "all-gather",
+                           "gather_root_ms_per_step": sig(max(0.0, (dt - dt_none) / steps * 1e3)), "gather_all_ms_per_step": sig(max(0.0, (dt_all - dt_none) / steps * 1e3)),
+                           "ms_per_step_all_gather": sig(dt_all / steps * 1e3), "ms_per_step_without_gather": sig(dt_none / steps * 1e3)})
+            if distributed and env.get("backend") != "gloo":
+                try:
+                    v = torch.cuda.nccl.version()
+                    config["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+                except Exception:
+                    pass
+                config["rccl_ranks"] = dist.get_world_size()
         out = {
             "metric": "Mrays/s (primary+shadow+bounce) at %dx%d" % (W, H),
-            "value": rays_total / dt / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "value": sig(rays_total / dt / 1e6, 7), "unit": "Mrays/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": sig(dt / steps * 1e3, 6), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": cfg["workload"], "name": config_name,
-                       "rays_per_step": rays_total / steps, "sharding": (("%s + RCCL all-gather, one process per GPU (gather of step k overlaps the renders that follow)" if env.get("backend") != "gloo" else "%s, one process per rank, bands exchanged through host memory over gloo (TRG_BENCH_BACKEND=gloo: rehearsal / no RCCL)")
-                                    % ("interleaved 8-row micro-bands (rank r renders bands r, r + N, ...; compact frame, unpacked after the gather)" if r.interleaved else "contiguous row bands")) if distributed else "none",
-                       "pipeline": ("%d frames in flight on alternating streams: later steps fill the CUs the tail of step k leaves idle "
-                                    "(roofline.kernel_ms = average launch duration while they overlap; kernel_alone_ms = one launch by itself)" % len(r.render_streams)) if getattr(r, "_overlap", False) else "serial launches",
-                       "kernel": kernel_name(st, in_lds),
-                       "triangles": int(len(buffers["material_ids"])), "scene_bytes": int(cst.scene_bytes),
-                       "scene_build": {"builder": {0: "host SAH", 1: "device binned SAH", 2: "device LBVH", 3: "device PLOC"}[int(os.environ.get("TRG_BENCH_GPU_BUILD", "0"))],
-                                       "build_ms": cst.last_build_ms, "load_scene_s": load_s, "bvh_depth4": int(cst.bvh_depth4), "nodes4": int(cst.bvh_nodes4)}},
-            "roofline": rf,
+            "config": config, "roofline": rf,
         }
+        detail = {"workload": cfg["workload"], "roofline": rf_detail,
+                  "pipeline": "frames in flight on alternating streams: later steps fill the CUs the tail of step k leaves idle (roofline.kernel_ms = average launch duration "
+                              "while they overlap; kernel_alone_ms = one launch by itself)",
+                  "kernel": kernel_name_long(st, in_lds)}
     r.close()
-    return out
+    return out, detail
 
 
 def run_group(args, n=None, use_imported=False):
@@ -466,10 +538,13 @@ def run_group(args, n=None, use_imported=False):
             return dt_
 
         timed(capi.GATHER_NONE, depth)            # priming: every render stream's per-launch scratch exists before anything is timed
-        timed(capi.GATHER_ALL, max(args.warmup, 1))
+        # THE TIMED REGION: north_star's exchange -- the GATHER of the bands to device 0 (grouped ncclSend / ncclRecv: the root ingests N - 1 bands
+        # over N - 1 independent xGMI links) -- behind every step; the in-place all-gather and no exchange at all are timed after it and reported beside it
+        timed(capi.GATHER_ROOT, max(args.warmup, 1))
         g.reset_stats()
-        dt = timed(capi.GATHER_ALL, args.steps, timeit=True)
+        dt = timed(capi.GATHER_ROOT, args.steps, timeit=True)
         launch = [g.launch_ms(r) for r in range(n)]
+        dt_all = timed(capi.GATHER_ALL, args.steps)
         dt_nogather = timed(capi.GATHER_NONE, args.steps)
         in_lds = bool(cst.scene_in_lds)
         exchange = g.exchange
@@ -478,38 +553,42 @@ def run_group(args, n=None, use_imported=False):
         conc = [max(1.0, sum(l) / (dt * 1e3)) for l in launch]          # launches of a rank in flight on average
         eff = [p / c for p, c in zip(piped, conc)]                      # device time per launch and rank
         slow = max(range(n), key=lambda r: eff[r])
-        rf = build_roofline(args.config, cst, rays_per_step, bytes_per_ray, mix, piped[slow], conc[slow], eff[slow], kernel_ms_alone, None,
-                            use_imported=use_imported and n == 1)
+        rf, rf_detail = build_roofline(args.config, cst, float(per_rank_rays[slow]), bytes_per_ray, mix, piped[slow], conc[slow], eff[slow], alone[slow], None,
+                                       use_imported=use_imported, derive=(float(per_rank_rays[slow]), rays_per_step) if n > 1 else None)
 
         def spread(v):
             m = sum(v) / len(v)
             return {"per_rank": [round(x, 4) for x in v], "slowest": max(v), "mean": m, "max_over_mean": (max(v) / m) if m > 0 else None}
+        rccl = g.rccl_info()   # {"version", "ranks": [ncclCommCount per communicator]} -- None without communicators (one device, copy exchange)
+        xname = {capi.EXCHANGE_RCCL: "rccl", capi.EXCHANGE_COPY: "copy"}.get(exchange, "none")
+        config = {"workload": cfg["short"], "name": args.config, "rays_per_step": rays_per_step,
+                  "sharding": "1 process, trg_group: %d contexts + host threads, %s bands" % (n, "interleaved 8-row" if interleaved else "contiguous ceil(h/N)-row"),
+                  "pipeline": "%d frames in flight per device, exchange on its own stream" % depth if depth > 1 else "serial launches",
+                  "exchange": xname, "exchange_mode": "root gather (ncclSend/ncclRecv to device 0)" if xname == "rccl" else ("root gather (peer copies)" if xname == "copy" else "none"),
+                  "rccl_version": rccl["version"] if rccl else None, "rccl_ranks": min(rccl["ranks"]) if rccl else None,
+                  "devices": ",".join(str(d) for d in devices), "shared_device": shared,
+                  "gather_root_ms_per_step": sig(max(0.0, (dt - dt_nogather) / args.steps * 1e3)),
+                  "gather_all_ms_per_step": sig(max(0.0, (dt_all - dt_nogather) / args.steps * 1e3)),
+                  "ms_per_step_all_gather": sig(dt_all / args.steps * 1e3), "ms_per_step_without_gather": sig(dt_nogather / args.steps * 1e3),
+                  "band_ms_slowest": sig(max(eff)), "band_ms_max_over_mean": sig(max(eff) / (sum(eff) / n)), "band_rays_max_over_mean": sig(max(per_rank_rays) / (sum(per_rank_rays) / n)),
+                  "kernel": ("bands of: " if n > 1 else "") + kernel_name(st0, in_lds),
+                  "triangles": int(len(buffers["material_ids"])), "scene_bytes": int(cst.scene_bytes)}
         out = {
             "metric": "Mrays/s (primary+shadow+bounce) at %dx%d" % (W, H),
-            "value": rays_per_step * args.steps / dt / 1e6, "unit": "Mrays/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "value": sig(rays_per_step * args.steps / dt / 1e6, 7), "unit": "Mrays/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": sig(dt / args.steps * 1e3, 6), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": cfg["workload"], "name": args.config, "rays_per_step": rays_per_step,
-                       "sharding": "single process, trg_group: %d contexts + persistent host threads, %s, %s" % (
-                           n, "interleaved 8-row micro-bands (device g renders bands g, g + N, ...; compact frame, unpacked after the exchange)" if interleaved else "bands of ceil(h / N) rows",
-                           "one in-place ncclAllGather per frame over xGMI" if exchange == capi.EXCHANGE_RCCL else
-                           ("no exchange (one device)" if exchange == capi.EXCHANGE_NONE else "bands exchanged by hipMemcpyPeerAsync + events (TRG_GROUP_EXCHANGE=copy or no librccl.so)")),
-                       "pipeline": ("%d frames in flight per device on alternating streams, the exchange of frame i on the device's exchange stream behind the "
-                                    "renders that follow (trg_group_set_pipeline)" % depth) if depth > 1 else "serial launches, the exchange behind each render on its stream",
-                       "exchange": {capi.EXCHANGE_RCCL: "rccl", capi.EXCHANGE_COPY: "copy"}.get(exchange, "none"), "exchange_note": g.exchange_note or None,
-                       "devices": devices,
-                       "per_rank_rays_per_step": per_rank_rays,
-                       "bands": {"rays": spread([float(x) for x in per_rank_rays]),
-                                 "kernel_alone_ms": spread(alone), "kernel_ms_in_pipeline": spread(piped), "device_ms_per_launch": spread(eff),
-                                 "note": ("the contexts SHARE a device (rehearsal): their `alone` launches ran side by side on it" if shared else
-                                          "HIP events per rank on the stream of each launch; alone = 3 launches per band with nothing else on its GPU")},
-                       "ms_per_step_without_gather": dt_nogather / args.steps * 1e3,
-                       "gather_ms_per_step": max(0.0, (dt - dt_nogather) / args.steps * 1e3),
-                       "kernel": ("per-band launches of: " if n > 1 else "") + kernel_name(st0, in_lds),
-                       "triangles": int(len(buffers["material_ids"])), "scene_bytes": int(cst.scene_bytes)},
-            "roofline": rf,
+            "config": config, "roofline": rf,
         }
-        return out
+        detail = {"workload": cfg["workload"], "roofline": rf_detail, "exchange_note": g.exchange_note or None, "rccl": rccl,
+                  "per_rank_rays_per_step": per_rank_rays,
+                  "bands": {"rays": spread([float(x) for x in per_rank_rays]),
+                            "kernel_alone_ms": spread(alone), "kernel_ms_in_pipeline": spread(piped), "device_ms_per_launch": spread(eff),
+                            "note": ("the contexts SHARE a device (rehearsal): their `alone` launches ran side by side on it" if shared else
+                                     "HIP events per rank on the stream of each launch; alone = 3 launches per band with nothing else on its GPU")},
+                  "kernel": ("per-band launches of: " if n > 1 else "") + kernel_name_long(st0, in_lds),
+                  "exchange_model": "DESIGN.md section 5: bytes per device and per xGMI link, expected ms and efficiency for the root gather and the all-gather"}
+        return out, detail
     finally:
         g.close()
 
@@ -533,9 +612,10 @@ def main(argv=None):
     if not launched and (args.gpus > 1 or os.environ.get("TRG_BENCH_GROUP")):
         # plain invocation: the single-process design of SURVEY 8(e); nothing is re-executed.  (TRG_BENCH_GROUP=1: N = 1 through the same
         # group path, to check it against the headline)
-        out = run_group(args, use_imported=True)
+        out, detail = run_group(args, use_imported=True)
         if args.gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.config)
+            out["cpu_baseline"], detail["cpu_baseline"] = cpu_baseline(args.config)
+        out["config"]["detail_file"] = write_detail(args.config, args.gpus, {"line": out, **detail})
         print(json.dumps(out), flush=True)
         return
     if args.gpus != world:
@@ -563,25 +643,33 @@ def main(argv=None):
             dist.init_process_group("gloo")
     env = dict(dist=dist, distributed=distributed, rank=rank, world=world, local_rank=device_index, backend=backend if (distributed or launched) else None)
 
-    out = run_torch(args.config, args.steps, args.warmup, env)
+    out, detail = run_torch(args.config, args.steps, args.warmup, env)
     secondary_failed = []
     if rank == 0 and world == 1 and args.config == "c2" and not args.no_secondary:
-        # the configurations where the roofline question lives, timed in the same (driver-witnessed) run: same method, fewer steps
-        sec = {}
-        for name, k, wu in SECONDARY:
+        # the configurations where the roofline question lives, timed in the same (driver-witnessed) run: same method, fewer steps.  Their
+        # numbers go into `config` as flat scalars (module docstring), their verbose halves into the side file
+        detail["secondary"] = {}
+        for name, k, wu, builder in SECONDARY:
             try:
-                s = run_torch(name, k, wu, env)
-                sec[name] = {"value": s["value"], "unit": s["unit"], "ms_per_step": s["ms_per_step"], "steps": k, "warmup": wu,
-                             "kernel_alone_ms": s["roofline"]["kernel_alone_ms"], "workload": s["config"]["workload"], "kernel": s["config"]["kernel"],
-                             "rays_per_step": s["config"]["rays_per_step"], "roofline": s["roofline"]}
+                s_out, s_detail = run_torch(name, k, wu, env, gpu_build=builder)
+                out["config"].update(leg_keys(name, s_out))
+                detail["secondary"][name] = {"line": s_out, **s_detail}
             except Exception as e:   # the headline is still printed -- and the run then ends NON-ZERO: a failed leg is not a green run
-                sec[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+                out["config"]["%s_error" % name] = ("%s: %s" % (type(e).__name__, e))[:110]
                 secondary_failed.append(name)
                 break                # (a device error leaves the context in doubt: no further leg on it)
-        out["secondary"] = sec
+        if not secondary_failed and not os.environ.get("TRG_BENCH_NO_PLUGIN"):
+            try:
+                p_flat, p_detail = plugin_leg()
+                out["config"].update(p_flat)
+                detail["plugin"] = p_detail
+            except Exception as e:
+                out["config"]["plugin_error"] = ("%s: %s" % (type(e).__name__, e))[:110]
+                secondary_failed.append("plugin")
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.config)
+            out["cpu_baseline"], detail["cpu_baseline"] = cpu_baseline(args.config)
+        out["config"]["detail_file"] = write_detail(args.config, world, {"line": out, **detail})
         print(json.dumps(out), flush=True)
     if distributed or launched:
         dist.barrier()

@@ -1,5 +1,6 @@
-// trg_wavefront.inc.h -- the WAVEFRONT schedule of the same path tracer (TRG_KERNEL_WAVEFRONT), included by trg_kernels.hip
-// inside namespace trgk_{fast,strict}.
+// experiments/trg_wavefront.inc.h -- EXPERIMENT, not in the shipped library: the WAVEFRONT schedule of the same path tracer
+// (TRG_KERNEL_WAVEFRONT), included by toyraygun_amd/csrc/trg_kernels.hip inside namespace trgk_{fast,strict} when TRG_EXPERIMENTS=1
+// (experiments/build.py).  Bit-exact against the oracle; 2.5x slower than the megakernel on C4, 18x on C2 -- NOTEBOOK.md, "Wavefront schedule".
 //
 // Why a second schedule.  The megakernel gives a path to one lane for its whole life: perfect when the scene sits in LDS and a
 // ray is a few dozen instructions away from its hit, poor when the scene lives in HBM.  On the 1 M-triangle scene (C4) the
@@ -117,13 +118,12 @@ __global__ __launch_bounds__(trg::kBlock, 8) void wf_trace_kernel(const trg::WfP
     uint32_t *head = &p.b.ctr[4u * p.stage];
     const uint32_t lane = threadIdx.x & 63u;
     constexpr bool UNIFIED = !LDS_SCENE;
-    constexpr int mode = UNIFIED ? TRG_TRAV_HBM : TRG_TRAV_LDS;
     Counters cnt; cnt.nodes = 0; cnt.tris = 0; cnt.wnodes = 0; cnt.wtris = 0;
 
     bool busy = false, exhausted = false, any = false;
     uint32_t pid = 0;
     Trav tv;
-    trav_begin(sc, tv, mk(0.0f, 0.0f, 0.0f), mk(0.0f, 0.0f, 1.0f), 0.0f, 0u, stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED && TRG_TRAV_LDS == 5, !UNIFIED);
+    trav_begin(sc, tv, mk(0.0f, 0.0f, 0.0f), mk(0.0f, 0.0f, 1.0f), 0.0f, 0u, stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED);
     tv.node = kNodeDone;
     // This wavefront's reserved slice [cur, end) of the queue.  A slice is taken with ONE atomic on the queue head and then handed
     // out to idle lanes with a ballot / mbcnt prefix, no memory traffic: one word sustains only ~90 atomics per microsecond
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(trg::kBlock, 8) void wf_trace_kernel(const trg::WfP
                 const v4f r0 = wf_ld(&w.ray_o[pid]);
                 const v4f r1 = any ? wf_ld(&w.sh[pid]) : wf_ld(&w.ray_d[pid]);
                 trav_begin(sc, tv, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), any ? r1.w : r0.w, any ? 1u : (uint32_t)__float_as_int(r1.w),
-                           stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED && TRG_TRAV_LDS == 5, !UNIFIED);
+                           stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED);
                 busy = true;
             }
             const uint32_t n_idle = (uint32_t)__popcll(idle);
@@ -167,10 +167,10 @@ __global__ __launch_bounds__(trg::kBlock, 8) void wf_trace_kernel(const trg::WfP
         if (__ballot(busy) == 0ull) break;
         if (busy) {
             for (;;) {
-                if (mode == 3) {
+                if (UNIFIED) {
                     trav_step_wide<COUNT, trg::kBlock>(sc, tv, any, stk, cnt);
                 } else {
-                    while (tv.node >= 0) trav_inner_step<COUNT, trg::kBlock, (mode >= 4 ? mode : 0)>(sc, tv, stk, cnt);
+                    while (tv.node >= 0) trav_node_step_signed<COUNT, trg::kBlock>(sc, tv, stk, cnt);
                     if (tv.node == kNodeDone) break;
                     if (trav_leaf_step<COUNT, trg::kBlock>(sc, tv, any, stk, cnt)) tv.node = kNodeDone;
                 }
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void wf_shade_kernel(const trg::WfParams p) {
     const WfView w = wf_view(p);
     const trg::SceneDesc &sd = p.sc;
     SceneView sc;
-    sc.nodes = nullptr; sc.htab = nullptr; sc.thr_entries = 0u; sc.meta = nullptr; sc.center = mk(sd.center[0], sd.center[1], sd.center[2]);
+    sc.nodes = nullptr; sc.htab = nullptr; sc.meta = nullptr; sc.center = mk(sd.center[0], sd.center[1], sd.center[2]);
     sc.tex = p.tex;
     sc.tris = FAT ? reinterpret_cast<const v4f *>(sd.blob + (kRecPlanes ? sd.off_fat_planes : sd.off_fat)) : nullptr;
     sc.normals = FAT ? nullptr : reinterpret_cast<const float *>(sd.blob + sd.off_normals);

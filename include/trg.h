@@ -291,6 +291,9 @@ TRG_API int trg_group_bands(trg_group *g);
 TRG_API int trg_group_postprocess(trg_group *g, int rank, uint8_t *rgba8, int flip_y); /* trg_postprocess of device `rank`'s last frame */
 /* why the exchange is not the one asked for ("" when it is): e.g. librccl.so could not be loaded and the bands move by peer copies */
 TRG_API const char *trg_group_exchange_note(trg_group *g);
+/* 1 in experiments/lib/libtoyraygun_hip_exp.so -- this library plus the schedules that were built, measured and lost (TRG_KERNEL_POOL,
+ * TRG_KERNEL_WAVEFRONT: experiments/README.md) --, 0 in the product library, whose trg_set_option refuses those two.  Host-only. */
+TRG_API int trg_library_experiments(void);
 /* what RCCL itself says about the group's communicators (round 5): *version = ncclGetVersion (e.g. 22203), ranks_out[r] = ncclCommCount of
  * device r's communicator -- the number of ranks RCCL saw --, for r < cap.  TRG_ERR_INVALID for a group without communicators (one device,
  * or the copy exchange): *version = 0 then. */

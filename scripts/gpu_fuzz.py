@@ -73,6 +73,8 @@ for case in range(cases):
         c.set_option(capi.OPT_STRICT, 0 if FAST else 1)
         c.set_option(capi.OPT_FORCE_GLOBAL, opts["force_global"])
         c.set_option(capi.OPT_FRAME_SPLIT, opts["fsplit"])
+        if not capi.has_experiments():
+            opts["kernel"] = 0            # (the product library has the direct megakernel only; TRG_HIP_SO=experiments/lib/... fuzzes the pool / wavefront schedules too)
         c.set_option(capi.OPT_KERNEL, opts["kernel"])
         c.set_option(capi.OPT_LAUNCHES_IN_FLIGHT, opts["in_flight"])
         c.set_option(capi.OPT_COUNTERS, opts["counters"])

@@ -604,7 +604,7 @@ def test_one_band_rule(built):
             assert all(k in (B, h - r0) or k == 0 for r0, k in rows)
 
 
-def test_bench_runs_plainly_with_several_gpus(built, monkeypatch, capsys):
+def test_bench_runs_plainly_with_several_gpus(built, monkeypatch, capsys, tmp_path):
     """`python bench.py --gpus 2` WITHOUT a launcher must not die in argument handling (the driver's scaling run invokes it like
     that): it takes the single-process device group (trg_group_*).  Rehearsed with a stand-in for the group so that no GPU is needed:
     the JSON line, its sharding description, per-rank ray counts and the separated gather time are produced; too few devices is a
@@ -626,6 +626,7 @@ def test_bench_runs_plainly_with_several_gpus(built, monkeypatch, capsys):
         def set_pixel_offsets_seed(self, seed=0): pass
         def set_option(self, o, v): calls.append(("opt", o, v))
         exchange, exchange_note = capi.EXCHANGE_RCCL, ""
+        def rccl_info(self): return {"version": 22203, "ranks": [self.n] * self.n}
         def render(self, f0, spp, b, gather=capi.GATHER_ALL, root=0):
             calls.append(("render", gather))
             if self.timing: self.timed += 1
@@ -654,19 +655,28 @@ def test_bench_runs_plainly_with_several_gpus(built, monkeypatch, capsys):
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
     for k in ("RANK", "WORLD_SIZE", "MASTER_PORT", "LOCAL_RANK"):
         monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("TRG_BENCH_DETAIL", str(tmp_path / "detail.json"))
     bench.main(["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
     line = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1]
+    assert len(line) < 4096                                           # the driver keeps an 8 KB tail: the whole line must sit in it
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0 and out["scaling"] == "strong" and out["unit"] == "Mrays/s"
-    assert "single process" in out["config"]["sharding"] and out["config"]["per_rank_rays_per_step"] == [1100, 1100]
-    assert out["config"]["gather_ms_per_step"] >= 0 and "bound" in out["roofline"]   # (the stand-in renders in no time: its rates mean nothing)
+    # the driver's record keeps the SCALARS directly under config / roofline: nothing a reader needs may hide in a nested object
+    assert all(not isinstance(v, (dict, list)) for v in out["config"].values()) and all(not isinstance(v, (dict, list)) for v in out["roofline"].values())
+    cfgo = out["config"]
+    assert "1 process" in cfgo["sharding"] and "interleaved" in cfgo["sharding"] and cfgo["exchange"] == "rccl" and "root gather" in cfgo["exchange_mode"]
+    assert cfgo["rccl_version"] == 22203 and cfgo["rccl_ranks"] == 2                     # "did RCCL see N ranks" is answerable from the line
+    assert cfgo["gather_root_ms_per_step"] >= 0 and cfgo["gather_all_ms_per_step"] >= 0 and "bound" in out["roofline"]   # (the stand-in renders in no time: its rates mean nothing)
     assert ("create", [0, 1], 1920, 1080) in calls and ("close",) in calls
-    assert ("pipeline", 4) in calls and "4 frames in flight" in out["config"]["pipeline"]
-    assert ("bands", capi.BANDS_INTERLEAVED) in calls and "interleaved" in out["config"]["sharding"]
-    bands = out["config"]["bands"]
+    assert ("pipeline", 4) in calls and "4 frames in flight" in cfgo["pipeline"]
+    assert ("bands", capi.BANDS_INTERLEAVED) in calls
+    detail = json.load(open(tmp_path / "detail.json"))
+    assert detail["line"]["value"] == out["value"] and detail["per_rank_rays_per_step"] == [1100, 1100] and detail["rccl"]["ranks"] == [2, 2]
+    bands = detail["bands"]
     assert len(bands["kernel_alone_ms"]["per_rank"]) == 2 and bands["kernel_ms_in_pipeline"]["max_over_mean"] == 1.0 and bands["rays"]["per_rank"] == [1100.0, 1100.0]
-    # gathered: warm-up 1 + timed 3; without the exchange: counters 1 + alone 3 + priming 4 + timed 3
-    assert sum(1 for c in calls if c == ("render", capi.GATHER_ALL)) == 1 + 3 and sum(1 for c in calls if c == ("render", capi.GATHER_NONE)) == 1 + 3 + 4 + 3
+    # the TIMED exchange is north_star's gather to one root: warm-up 1 + timed 3; the all-gather beside it: 3; without an exchange: counters 1 + alone 3 + priming 4 + timed 3
+    n_of = lambda mode: sum(1 for c in calls if c == ("render", mode))
+    assert n_of(capi.GATHER_ROOT) == 1 + 3 and n_of(capi.GATHER_ALL) == 3 and n_of(capi.GATHER_NONE) == 1 + 3 + 4 + 3
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
     with pytest.raises(SystemExit) as e:
         bench.main(["--gpus", "2", "--no-cpu-baseline"])
@@ -674,7 +684,7 @@ def test_bench_runs_plainly_with_several_gpus(built, monkeypatch, capsys):
     monkeypatch.setenv("TRG_BENCH_DEVICES", "0,0")   # the one-GPU rehearsal: an explicit device list (contexts sharing a device)
     bench.main(["--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"])
     out = json.loads([l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1])
-    assert out["config"]["devices"] == [0, 0] and ("create", [0, 0], 1920, 1080) in calls
+    assert out["config"]["devices"] == "0,0" and out["config"]["shared_device"] is True and ("create", [0, 0], 1920, 1080) in calls
     monkeypatch.setenv("TRG_BENCH_DEVICES", "0")
     with pytest.raises(SystemExit):
         bench.main(["--gpus", "2", "--no-cpu-baseline"])

@@ -66,6 +66,7 @@ _SYMBOLS = [
     ("trg_create", C.c_int, [C.POINTER(_P), C.c_int, C.c_uint32, C.c_uint32]),
     ("trg_destroy", None, [_P]),
     ("trg_last_error", C.c_char_p, [_P]),
+    ("trg_library_experiments", C.c_int, []),
     ("trg_load_scene", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint32, C.c_uint32]),
     ("trg_load_textures", C.c_int, [_P, _P, _P, C.c_uint32, C.POINTER(_P), _P, _P, C.c_uint32]),
     ("trg_set_uniforms", C.c_int, [_P, C.POINTER(Uniforms)]),
@@ -149,6 +150,11 @@ def load():
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+def has_experiments():
+    """True when the loaded library is experiments/lib/libtoyraygun_hip_exp.so (TRG_HIP_SO): it has the path-pool and wavefront schedules."""
+    return bool(load().trg_library_experiments())
 
 
 class TrgError(RuntimeError):

@@ -197,53 +197,6 @@ static void fill_fat_record_planes(unsigned char *dst, const F4 *rec48, const fl
     }
 }
 
-// float -> IEEE half, rounded toward +inf (up) or -inf: the slab planes of the half-precision LDS node (kHalfLds) may only move outward
-static float f16_to_f32(uint16_t h) {
-    const uint32_t s = (uint32_t)(h >> 15) << 31, e = (h >> 10) & 31u, m = h & 1023u;
-    uint32_t u;
-    if (e == 0) {
-        if (m == 0) u = s;
-        else { float f = (float)m * 5.9604644775390625e-8f; memcpy(&u, &f, 4); u |= s; }   // subnormal: m * 2^-24
-    } else if (e == 31) u = s | 0x7F800000u | (m << 13);
-    else u = s | ((e + 112u) << 23) | (m << 13);
-    float f; memcpy(&f, &u, 4);
-    return f;
-}
-static uint16_t f32_to_f16_directed(float f, bool up) {
-    if (f != f) return 0x7E00u;
-    // nearest first (round half away: good enough, the correction below makes it directed), then step to the neighbour on the wanted side
-    uint32_t u; memcpy(&u, &f, 4);
-    const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
-    const float a = std::fabs(f);
-    uint16_t mag;
-    if (a >= 65520.0f) mag = 0x7C00u;   // beyond the largest half: infinity (the correction brings a "down" back to 65504)
-    else if (a < 6.103515625e-5f) mag = (uint16_t)std::lrintf(a * 16777216.0f);   // subnormal: multiples of 2^-24 (1024 = the smallest normal: the bit patterns are contiguous)
-    else {
-        int ex; const float fr = std::frexp(a, &ex);   // a = fr * 2^ex, fr in [0.5, 1)
-        uint32_t m = (uint32_t)std::lrintf(fr * 2048.0f);   // 11 bits: 1024..2048
-        if (m == 2048u) { m = 1024u; ++ex; }
-        mag = (uint16_t)(((uint32_t)(ex + 14) << 10) + (m - 1024u));
-    }
-    uint16_t h = (uint16_t)(sign | mag);
-    auto next_up = [](uint16_t x) -> uint16_t {     // the next half towards +inf
-        if (x == 0x8000u) x = 0;
-        if (x == 0x7C00u) return x;
-        return (x & 0x8000u) ? (uint16_t)(x - 1u) : (uint16_t)(x + 1u);
-    };
-    auto next_down = [](uint16_t x) -> uint16_t {   // ... towards -inf
-        if (x == 0x0000u) x = 0x8000u;
-        if (x == 0xFC00u) return x;
-        return (x & 0x8000u) ? (uint16_t)(x + 1u) : (uint16_t)(x - 1u);
-    };
-    for (int it = 0; it < 2; ++it) {
-        const float g = f16_to_f32(h);
-        if (up && g < f) h = next_up(h);
-        else if (!up && g > f) h = next_down(h);
-        else break;
-    }
-    return h;
-}
-
 constexpr uint32_t kStackLdsLevels = TRG_STACK_LDS_LEVELS;
 #ifndef TRG_TAIL_AUTO_MIN_BOUNCES
 #define TRG_TAIL_AUTO_MIN_BOUNCES 4
@@ -259,23 +212,19 @@ constexpr uint32_t kTailAutoMinBounces = TRG_TAIL_AUTO_MIN_BOUNCES, kTailAutoK =
 #ifndef TRG_XCD_AUTO_COLS
 #define TRG_XCD_AUTO_COLS 0   // TRG_OPT_TILE_ORDER -1 for scenes in HBM: 0 = image columns (measured faster, see choose_xcd_cols), 2 = XCD-aware 2 x 4
 #endif
-#ifndef TRG_WAVEFRONT_FOR_HBM
-#define TRG_WAVEFRONT_FOR_HBM 0   // what TRG_KERNEL_AUTO picks for a scene traversed from HBM (1 = the wavefront schedule)
-#endif  // HBM scenes: stack levels kept in LDS (deeper ones spill to global scratch)
 
 struct LdsPlan { bool lds_scene; uint32_t stack_off, red_off, pool_off, acc_off, total, klds, overflow_levels; };
 static bool plan_lds_as(const trg_ctx *c, LdsPlan &p, bool lds_scene, bool pool, uint32_t fp_slots, uint32_t &limit, bool park = true) {
     p.lds_scene = lds_scene;
     uint32_t levels;
     if (p.lds_scene) {
-        // the sentinel at level 0 + BVH2, near child first: at most one pending entry per level + the scratch slot above the top;
-        // 4-wide LDS tree: up to three pending entries per level (its branch-free pushes write at most into those slots)
+        // the sentinel at level 0 + BVH2, near child first: at most one pending entry per level + the scratch slot above the top
         // (BVH2: leaves sit at depth <= bvh_depth, so inner nodes at depths 0 .. bvh_depth - 1 hold at most bvh_depth pending entries in levels
         //  1 .. bvh_depth, and the step at an inner node of depth k stores its far child at level <= k + 1: bvh_depth + 1 levels are used, one is spare)
-        levels = kThreadedLds ? 1u : (kWideLds ? 3 * c->bvh_depth4 + 2 : c->bvh_depth + 2);   // (the threaded walk has no stack: only the sentinel level)
+        levels = c->bvh_depth + 2;
         p.klds = levels;
     } else {
-        levels = kWideHbm ? 3 * c->bvh_depth4 + 3 : c->bvh_depth + 3;  // the sentinel at level 0; 4-wide: up to three pending entries per level
+        levels = 3 * c->bvh_depth4 + 3;  // the sentinel at level 0; 4-wide: up to three pending entries per level
         p.klds = std::min(levels, (uint32_t)c->opt_stack_levels);
     }
     p.overflow_levels = levels - p.klds;
@@ -284,10 +233,12 @@ static bool plan_lds_as(const trg_ctx *c, LdsPlan &p, bool lds_scene, bool pool,
     p.red_off = p.stack_off + p.klds * kBlock * 4u;
     p.pool_off = align16(p.red_off + 4u * 8u * 4u);
     p.total = p.pool_off;
+#if TRG_EXPERIMENTS
     if (pool) {
         const uint32_t slots = (uint32_t)kBlock * (uint32_t)kPoolS;
         p.total = p.pool_off + slots * kPoolSlotBytes + 4u * slots * 2u + 16u;  // slots, two lists of 2P u16, counters
     }
+#endif
     if (fp_slots) p.total = p.pool_off + fp_slots * (uint32_t)kBlock * 12u;  // render_fp_kernel: parked radiances, 3 floats x 256 pixel-frames per slot group
     // render_kernel on an HBM-resident scene parks the running average in LDS between frames (three VGPRs less across every
     // traversal; an LDS-resident scene has neither the room -- 8 workgroups of 20 KB per CU -- nor the need: it is spill-free)
@@ -398,7 +349,9 @@ static int ensure_stack_scratch(trg_ctx *c, const LdsPlan &plan, uint64_t grid_t
     return TRG_OK;
 }
 
+#if TRG_EXPERIMENTS
 static int render_wavefront(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces, uint32_t row0, uint32_t rows, int slot);
+#endif
 
 // Per-launch scratch (traversal-stack overflow, wavefront buffers) is keyed on the STREAM a launch goes to: launches on one stream
 // are ordered and may share a buffer, launches on different streams may overlap and never do -- whatever order the caller uses
@@ -415,7 +368,6 @@ static int scratch_slot(trg_ctx *c) {
 // trg_load_scene with TRG_OPT_GPU_BUILD: LBVH on the device (trg_build.hip), 4-wide nodes only (never LDS-staged).
 static int load_scene_gpu_build(trg_ctx *c, const float *pos, const float *nrm, const float *col, const uint32_t *idx,
                                 const uint32_t *mat, uint32_t n_verts, uint32_t n_tris) {
-    if (!kWideHbm) return fail(c, TRG_ERR_INVALID, "GPU build needs the 4-wide HBM traversal");
     float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
     for (size_t i = 0; i < (size_t)n_tris * 3; ++i) {
         const float *p = pos + (size_t)idx[i] * 3;
@@ -490,58 +442,9 @@ static int load_scene_gpu_build(trg_ctx *c, const float *pos, const float *nrm, 
     return plan_lds(c, plan, c->opt_kernel == TRG_KERNEL_POOL);
 }
 
-// TRG_KERNEL_WAVEFRONT: the frames of the launch in batches of at most kWfMaxPaths pixel-samples; per batch
-//   raygen, bounces x [persistent trace, shade + compacting append], one more trace for the last shadow rays, accumulate.
-// Nothing synchronises with the host: queue lengths stay on the device.
-static int render_wavefront(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t bounces, uint32_t row0, uint32_t rows, int slot) {
-    LdsPlan plan;
-    if (int rc = plan_lds(c, plan, false, 0, false)) return rc;   // the tracer's LDS: scene (if staged) + stacks only
-    const uint64_t npix = (uint64_t)c->w * rows;
-    const uint32_t fb = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(spp, kWfMaxPaths / std::max<uint64_t>(npix, 1)));
-    const uint64_t nb_max = npix * fb;
-    if (nb_max >= (1ull << 31)) return fail(c, TRG_ERR_RANGE, "trg_render: %llu pixels in one band are too many for the wavefront schedule", (unsigned long long)npix);
-    // layout of the slot: 7 float4 arrays, two lists of 2 nb entries, the stage counters
-    const size_t arr = (size_t)nb_max * 16u, lst = (size_t)nb_max * 2u * 4u;
-    const size_t need = 7u * arr + 2u * lst + kWfMaxStages * 16u + 256u;
-    if (need > c->wf_bytes[slot]) {
-        if (c->wf_mem[slot]) { (void)hipDeviceSynchronize(); (void)hipFree(c->wf_mem[slot]); c->wf_mem[slot] = nullptr; c->wf_bytes[slot] = 0; }
-        hipError_t e = hipMalloc((void **)&c->wf_mem[slot], need);
-        if (e != hipSuccess) return fail(c, TRG_ERR_NOMEM, "wavefront buffers hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
-        c->wf_bytes[slot] = need;
-    }
-    unsigned char *m = c->wf_mem[slot];
-    WfParams p{};
-    p.u = c->u; p.sc = c->sc; p.offsets = c->offsets; p.accum = c->accum; p.counters = c->counters;
-    p.tex = c->tex;
-    p.b.ray_o = m; p.b.ray_d = m + arr; p.b.sh = m + 2 * arr; p.b.hit = m + 3 * arr; p.b.thr = m + 4 * arr; p.b.rad = m + 5 * arr; p.b.scol = m + 6 * arr;
-    p.b.list[0] = reinterpret_cast<uint32_t *>(m + 7 * arr); p.b.list[1] = reinterpret_cast<uint32_t *>(m + 7 * arr + lst);
-    p.b.ctr = reinterpret_cast<uint32_t *>(m + 7 * arr + 2 * lst);
-    p.npix = (uint32_t)npix; p.pix0 = row0 * c->w; p.bounces = bounces;
-    p.stack_off = plan.stack_off;
-    // the persistent tracer: as many workgroups as the chip holds at 8 waves/SIMD; late ones find the queue empty
-    const uint32_t trace_grid = (uint32_t)c->cu_count * 8u;
-    if (int rc = ensure_stack_scratch(c, plan, (uint64_t)trace_grid * kBlock, p.stack, slot)) return rc;
-    const uint32_t shade_grid = (uint32_t)c->cu_count * 8u;
-    const bool strict = c->opt_strict;
-    for (uint32_t f0 = 0; f0 < spp; f0 += fb) {
-        p.frame0 = frame_begin + f0;
-        p.nframes = std::min(fb, spp - f0);
-        p.nb = p.npix * p.nframes;
-        HIPCHK(c, hipMemsetAsync(p.b.ctr, 0, kWfMaxStages * 16u, c->stream));
-        HIPCHK(c, strict ? launch_wf_raygen_strict(p, c->stream) : launch_wf_raygen_fast(p, c->stream));
-        for (uint32_t b = 0; b <= bounces; ++b) {
-            if (bounces == 0) break;
-            p.stage = b; p.bounce = b;
-            HIPCHK(c, strict ? launch_wf_trace_strict(p, plan.lds_scene, c->opt_counters, trace_grid, plan.total, c->stream)
-                             : launch_wf_trace_fast(p, plan.lds_scene, c->opt_counters, trace_grid, plan.total, c->stream));
-            if (b == bounces) break;   // that was the trace of the last bounce's shadow rays
-            HIPCHK(c, strict ? launch_wf_shade_strict(p, plan.lds_scene, shade_grid, c->stream) : launch_wf_shade_fast(p, plan.lds_scene, shade_grid, c->stream));
-        }
-        HIPCHK(c, strict ? launch_wf_accumulate_strict(p, c->stream) : launch_wf_accumulate_fast(p, c->stream));
-    }
-    return TRG_OK;
-}
-
+#if TRG_EXPERIMENTS
+#include "../../experiments/trg_capi_wavefront.inc.h"   // render_wavefront (TRG_KERNEL_WAVEFRONT)
+#endif
 
 namespace trg {
 struct HostScene {
@@ -568,6 +471,7 @@ void host_scene_free(HostScene *hs) { delete hs; }
 extern "C" {
 
 const char *trg_last_error(trg_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+int trg_library_experiments(void) { return TRG_EXPERIMENTS ? 1 : 0; }
 
 int trg_create(trg_ctx **out, int device, uint32_t width, uint32_t height) {
     if (!out || width == 0 || height == 0 || (uint64_t)width * height > 0x7FFFFFFFull)
@@ -674,16 +578,13 @@ int host_scene_build(trg_ctx *c, const float *pos, const float *nrm, const float
     // [ LDS nodes | 48-byte triangle records | normals | colours | material ids | Halton tables ] [ quantised 4-wide nodes ] [ 128-byte leaf records ]
     // The first bracket is what a workgroup stages into LDS; only a scene small enough for that has it.  The other two are what
     // the HBM kernels traverse (a small scene kept in HBM -- TRG_OPT_FORCE_GLOBAL, a tree too deep for LDS stacks -- uses them too).
-    // TRG_TRAV_LDS == 6: 2 entries of 64 bytes per BVH2 node, then 8 order tables of (entries + 1) words, counted in 64-byte units
-    const uint32_t thr_entries = 2u * bvh.n_nodes, thr_units = thr_entries + (8u * (thr_entries + 1u) * 4u + 63u) / 64u;
-    const uint32_t lds_nodes = kThreadedLds ? thr_units : (kWideLds ? bvh.n_nodes4 : bvh.n_nodes);
+    const uint32_t lds_nodes = bvh.n_nodes;
     const uint64_t small_bytes = (uint64_t)lds_nodes * kLdsNodeBytes + (uint64_t)nt_rec * 50u + (uint64_t)attr_tris * 76u + 80u + kHtabBytes;
-    const bool lds_candidate = small_bytes <= kMaxLdsScene && (!kThreadedLds || thr_units * 64u < 65536u) && n_tris < (1u << 14);   // (u16 per record: index << 2 | mask)
+    const bool lds_candidate = small_bytes <= kMaxLdsScene && n_tris < (1u << 14);   // (u16 per record: index << 2 | mask)
     SceneDesc sc{};
     sc.n_nodes = lds_candidate ? lds_nodes : 0u; sc.n_tris = n_tris;
     sc.n_tris_rec = lds_candidate ? nt_rec : 0u;
     for (int a = 0; a < 3; ++a) sc.center[a] = n_tris ? 0.5f * (hs->lo[a] + hs->hi[a]) : 0.0f;
-    sc.thr_entries = (kThreadedLds && lds_candidate) ? thr_entries : 0u;
     const uint32_t node_bytes = kLdsNodeBytes;
     sc.n_nodes4 = bvh.n_nodes4;
     uint64_t total = 0;
@@ -693,73 +594,7 @@ int host_scene_build(trg_ctx *c, const float *pos, const float *nrm, const float
     }
     std::vector<unsigned char> &host = hs->blob;
     host.assign(sc.blob_bytes, 0);
-    if (sc.n_nodes && lds_candidate && kThreadedLds) {
-        // Octant-threaded BVH2 (experiment).  Entry 2 n + s = child s of node n: per axis (lo, hi, hi, lo) so that an 8-byte read at +0 gives
-        // (near, far) for a positive direction and at +8 for a negative one; word 12 = the leaf code (< 0) or 0 for an inner child.
-        unsigned char *base = &host[sc.off_nodes];
-        for (uint32_t n = 0; n < bvh.n_nodes; ++n) {
-            const F4 *nd = &bvh.nodes[(size_t)n * 4];
-            int32_t ch[2];
-            memcpy(ch, &nd[3].x, 8);
-            for (int k = 0; k < 2; ++k) {
-                const float lo[3] = { k ? nd[1].x : nd[0].x, k ? nd[1].z : nd[0].z, k ? nd[2].z : nd[2].x };
-                const float hi[3] = { k ? nd[1].y : nd[0].y, k ? nd[1].w : nd[0].w, k ? nd[2].w : nd[2].y };
-                float *e = reinterpret_cast<float *>(base + (size_t)(2u * n + (uint32_t)k) * 64u);
-                for (int a = 0; a < 3; ++a) { e[a * 4 + 0] = lo[a]; e[a * 4 + 1] = hi[a]; e[a * 4 + 2] = hi[a]; e[a * 4 + 3] = lo[a]; }
-                const int32_t code = ch[k] < 0 ? ch[k] : 0;
-                memcpy(&e[12], &code, 4);
-            }
-        }
-        // the eight orders: depth first, the child that lies first along the octant's direction first; word = entry byte offset | skip << 16
-        uint32_t *tables = reinterpret_cast<uint32_t *>(base + (size_t)thr_entries * 64u);
-        for (uint32_t oct = 0; oct < 8u; ++oct) {
-            uint32_t *tab = tables + (size_t)oct * (thr_entries + 1u);
-            uint32_t pos = 0;
-            struct Item { uint32_t node; int stage; uint32_t k[2]; int first; };
-            std::vector<Item> st;
-            st.push_back(Item{ 0u, 0, { 0u, 0u }, 0 });
-            while (!st.empty()) {
-                Item &it = st.back();
-                const F4 *nd = &bvh.nodes[(size_t)it.node * 4];
-                int32_t ch[2];
-                memcpy(ch, &nd[3].x, 8);
-                if (it.stage == 0) {   // which child comes first for this octant: the smaller centre along every axis the ray moves up, the larger where it moves down
-                    const float c0[3] = { nd[0].x + nd[0].y, nd[0].z + nd[0].w, nd[2].x + nd[2].y }, c1[3] = { nd[1].x + nd[1].y, nd[1].z + nd[1].w, nd[2].z + nd[2].w };
-                    float k0 = 0.f, k1 = 0.f;
-                    for (int a = 0; a < 3; ++a) { const float sgn = ((oct >> a) & 1u) ? -1.f : 1.f; k0 += sgn * c0[a]; k1 += sgn * c1[a]; }
-                    it.first = k1 < k0 ? 1 : 0;
-                }
-                if (it.stage >= 1) tab[it.k[it.stage - 1]] |= pos << 16;   // the skip link of the child whose subtree has just been laid out
-                if (it.stage == 2) { st.pop_back(); continue; }
-                const int slot = it.stage == 0 ? it.first : 1 - it.first;
-                it.k[it.stage] = pos;
-                tab[pos++] = (2u * it.node + (uint32_t)slot) * 64u;
-                const int32_t child = ch[slot];
-                it.stage++;
-                if (child >= 0) st.push_back(Item{ (uint32_t)child, 0, { 0u, 0u }, 0 });   // (invalidates `it`: not used below)
-            }
-            tab[thr_entries] = 0xFFFFu | (thr_entries << 16);   // end marker (never read: the walk stops at position == entries)
-        }
-    } else if (sc.n_nodes && lds_candidate && kWideLds) {
-        // sign-ordered 4-wide LDS nodes (trav_node4_step_lds): per axis [lo x4 | hi x4 | lo x4] = 48 bytes, so that a 32-byte read at
-        // +0 gives (near, far) for a positive direction and at +16 for a negative one; then the four children (inner: byte offset
-        // of the node; leaf code < 0; unused slot: 0x80000000 behind an inverted box that no ray enters)
-        for (uint32_t i = 0; i < sc.n_nodes; ++i) {
-            const F4 *n = &bvh.nodes4[(size_t)i * 8];   // lo.x hi.x lo.y hi.y lo.z hi.z children pad
-            float *o = reinterpret_cast<float *>(&host[sc.off_nodes + (size_t)i * kLdsNodeBytes]);
-            int32_t ch[4];
-            memcpy(ch, &n[6].x, 16);
-            for (int a = 0; a < 3; ++a) {
-                float lo[4] = { n[a * 2].x, n[a * 2].y, n[a * 2].z, n[a * 2].w }, hi[4] = { n[a * 2 + 1].x, n[a * 2 + 1].y, n[a * 2 + 1].z, n[a * 2 + 1].w };
-                for (int k = 0; k < 4; ++k)
-                    if (ch[k] == (int32_t)0x80000000) { lo[k] = INFINITY; hi[k] = -INFINITY; }
-                memcpy(o + a * 12, lo, 16); memcpy(o + a * 12 + 4, hi, 16); memcpy(o + a * 12 + 8, lo, 16);
-            }
-            for (int k = 0; k < 4; ++k)
-                if (ch[k] >= 0) ch[k] *= (int32_t)kLdsNodeBytes;
-            memcpy(o + 36, ch, 16);
-        }
-    } else if (sc.n_nodes && lds_candidate && kSignedLds) {
+    if (sc.n_nodes && lds_candidate) {
         // sign-ordered LDS nodes (trav_node_step_signed): per axis the slab planes of both children as
         // (lo_a, hi_a, lo_b, hi_b) and swapped; children of inner nodes become byte offsets
         for (uint32_t i = 0; i < sc.n_nodes; ++i) {
@@ -790,39 +625,6 @@ int host_scene_build(trg_ctx *c, const float *pos, const float *nrm, const float
             memcpy(o + 36, ch, 8);
             memcpy(o + 44, ch, 8);
         }
-    } else if (sc.n_nodes && lds_candidate && kHalfLds) {
-        // the sign-ordered node in half precision (trg_kernels.h kHalfLds; trg_device.h trav_node_step_half): planes relative to the centre,
-        // lo rounded down, hi rounded up
-        for (uint32_t i = 0; i < sc.n_nodes; ++i) {
-            const F4 *n = &bvh.nodes[(size_t)i * 4];  // (ax0,ax1,ay0,ay1) (bx0,bx1,by0,by1) (az0,az1,bz0,bz1) (c0,c1,-,-)
-            unsigned char *o = &host[sc.off_nodes + (size_t)i * kLdsNodeBytes];
-            const float pl[3][4] = { { n[0].x, n[0].y, n[1].x, n[1].y }, { n[0].z, n[0].w, n[1].z, n[1].w }, { n[2].x, n[2].y, n[2].z, n[2].w } };   // per axis: lo_a, hi_a, lo_b, hi_b
-            uint16_t fwd[3][4], rev[3][4];
-            for (int a = 0; a < 3; ++a) {
-                uint16_t h[4];
-                for (int k = 0; k < 4; ++k) h[k] = f32_to_f16_directed(pl[a][k] - sc.center[a], (k & 1) != 0);
-                // (the subtraction rounds to nearest: one ulp of fp32, three orders of magnitude below the half's step and inside the builder's padding)
-                for (int k = 0; k < 4; ++k) { fwd[a][k] = h[k]; rev[a][k] = h[k ^ 1]; }
-            }
-            int32_t ch[2];
-            memcpy(ch, &n[3].x, 8);
-            for (int k = 0; k < 2; ++k)
-                if (ch[k] >= 0) ch[k] *= (int32_t)kLdsNodeBytes;
-            for (int sy = 0; sy < 2; ++sy)
-                for (int sx = 0; sx < 2; ++sx) {
-                    unsigned char *q = o + (sx + 2 * sy) * 16;
-                    memcpy(q, sx ? rev[0] : fwd[0], 8);
-                    memcpy(q + 8, sy ? rev[1] : fwd[1], 8);
-                }
-            for (int sz = 0; sz < 2; ++sz) {
-                unsigned char *q = o + 64 + sz * 16;
-                memcpy(q, sz ? rev[2] : fwd[2], 8);
-                memcpy(q + 8, ch, 8);
-            }
-        }
-    } else if (sc.n_nodes) {
-        static_assert(kSignedLds || kWideLds || kHalfLds || kLdsNodeBytes == 64u, "plain BVH2 nodes are 64 bytes");
-        memcpy(&host[sc.off_nodes], bvh.nodes.data(), (size_t)sc.n_nodes * 64u);
     }
     if (lds_candidate) {
         memcpy(&host[sc.off_tris], bvh.tris.data(), bvh.tris.size() * sizeof(F4));
@@ -1022,13 +824,10 @@ static int render_impl(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t 
     const int slot = scratch_slot(c);
     if (slot < 0) return fail(c, TRG_ERR_RANGE, "trg_render: more than %d different streams used with this context", trg_ctx::kScratchSlots - 1);
     int kernel = c->opt_kernel;
-    if (kernel == TRG_KERNEL_AUTO) {
-        LdsPlan probe;
-        if (int rc = plan_lds(c, probe)) return rc;
-        kernel = (!probe.lds_scene && TRG_WAVEFRONT_FOR_HBM) ? TRG_KERNEL_WAVEFRONT : TRG_KERNEL_DIRECT;
-    }
+    if (kernel == TRG_KERNEL_AUTO) kernel = TRG_KERNEL_DIRECT;
     if (il_n > 1u && kernel != TRG_KERNEL_DIRECT)
         return fail(c, TRG_ERR_INVALID, "trg_render_bands: interleaved bands are rendered by the direct megakernel only (TRG_OPT_KERNEL %d)", kernel);
+#if TRG_EXPERIMENTS
     if (kernel == TRG_KERNEL_WAVEFRONT) {
         if (c->opt_timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
         if (int rc = render_wavefront(c, frame_begin, spp, bounces, row0, rows, slot)) return rc;
@@ -1042,8 +841,11 @@ static int render_impl(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t 
         }
         return TRG_OK;
     }
-    c->last_kernel = (uint32_t)kernel;
     const bool pool = kernel == TRG_KERNEL_POOL;
+#else
+    const bool pool = false;
+#endif
+    c->last_kernel = (uint32_t)kernel;
     // frame lanes per workgroup (render_fp_kernel) -- see choose_fsplit
     uint32_t fsplit = pool ? 1u : choose_fsplit(c, spp, rows);
     // a large scene in HBM: the path-regeneration kernel takes the frame lanes itself (so many workgroups per tile)
@@ -1201,10 +1003,13 @@ static int render_impl(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t 
 
     if (c->opt_timing) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     hipError_t e;
+#if TRG_EXPERIMENTS
     if (pool)
         e = c->opt_strict ? launch_render_pool_strict(p, plan.lds_scene, c->opt_counters, grid, plan.total, c->stream)
                           : launch_render_pool_fast(p, plan.lds_scene, c->opt_counters, grid, plan.total, c->stream);
-    else if (fsplit > 1)
+    else
+#endif
+    if (fsplit > 1)
         e = c->opt_strict ? launch_render_fp_strict(p, plan.lds_scene, c->opt_counters, grid, plan.total, c->stream)
                           : launch_render_fp_fast(p, plan.lds_scene, c->opt_counters, grid, plan.total, c->stream);
     else
@@ -1318,6 +1123,9 @@ int trg_set_option(trg_ctx *c, int option, int64_t value) {
     case TRG_OPT_KERNEL:
         if (value != TRG_KERNEL_DIRECT && value != TRG_KERNEL_POOL && value != TRG_KERNEL_WAVEFRONT && value != TRG_KERNEL_AUTO)
             return fail(c, TRG_ERR_INVALID, "trg_set_option: unknown kernel %lld", (long long)value);
+        if (!TRG_EXPERIMENTS && (value == TRG_KERNEL_POOL || value == TRG_KERNEL_WAVEFRONT))
+            return fail(c, TRG_ERR_INVALID, "trg_set_option: the %s schedule is an experiment that lost to the direct megakernel and is not in this library: "
+                                            "experiments/lib/libtoyraygun_hip_exp.so has it (experiments/README.md)", value == TRG_KERNEL_POOL ? "path-pool" : "wavefront");
         c->opt_kernel = (int)value;
         break;
     default: return fail(c, TRG_ERR_INVALID, "trg_set_option: unknown option %d", option);

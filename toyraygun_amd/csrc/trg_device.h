@@ -517,7 +517,6 @@ struct SceneView {
     trg::TexDesc tex;       // albedo textures in global memory (tex.uv == nullptr: none)
     const unsigned short *meta;   // LDS scene: per record (original index << 2) | (material id & 3) (the plane test of the shipped build)
     V3 center;              // shipped build: the point the plane records are relative to (SceneDesc::center); Trav::o is relative to it too
-    uint32_t thr_entries;   // TRG_TRAV_LDS == 6: entries of the octant-threaded tree behind `nodes`
     uint32_t rec_delta;     // HBM scene: byte distance from `nodes` to `tris` (the records follow the nodes in the blob)
 };
 // original index / material id of leaf record r of an HBM-resident scene: the .w of rows 0 / 1 (Moeller-Trumbore records), or the last two
@@ -636,7 +635,7 @@ struct Trav {
     Hit hit;           // prim, u, v of the accepted hit; hit.t is filled in by trav_hit() only (it is `best`)
     bool found;
     int node, sp;
-    int sx, sy, sz;  // sign-ordered LDS nodes (TRG_TRAV_LDS == 4): byte offset of the slab pair to read per axis
+    int sx, sz;      // sign-ordered LDS nodes: LDS address of this ray's [X | Y] block and of its Z block in node 0 (added to a node's byte offset)
 };
 
 TRG_DEV float clamp_away_from_zero(float v) {
@@ -647,7 +646,7 @@ TRG_DEV float clamp_away_from_zero(float v) {
 // The plane tests want the ray origin RELATIVE to the scene's centre (SceneView::center).  A traversal of an LDS-resident scene (`rel`) keeps
 // o - centre in Trav::o -- nothing but the triangle test reads it there, the kernels keep the path's own origin --; the HBM step subtracts per
 // test instead, because the regeneration kernel's Trav::o IS the path's origin (one copy, read back by the shading event).
-TRG_DEV void trav_begin(const SceneView &sc, Trav &tv, V3 o, V3 d, float tmax, uint32_t rmask, int sp0, uint32_t node_base = 0u, bool wide_lds = false, bool rel = false) {
+TRG_DEV void trav_begin(const SceneView &sc, Trav &tv, V3 o, V3 d, float tmax, uint32_t rmask, int sp0, uint32_t node_base = 0u, bool rel = false) {
     // Reciprocal direction with zero components pushed to +-1e-30: the slab products stay finite (no
     // inf - inf = NaN whose fmin/fmax would pick the wrong endpoint), and a ray that moves 1e-30 per
     // unit t along an axis is parallel to the slab for every practical purpose.
@@ -656,12 +655,7 @@ TRG_DEV void trav_begin(const SceneView &sc, Trav &tv, V3 o, V3 d, float tmax, u
     const float dx = clamp_away_from_zero(d.x), dy = clamp_away_from_zero(d.y), dz = clamp_away_from_zero(d.z);
     tv.o = (kTriPlanes && rel) ? o - sc.center : o; tv.d = d;
     tv.idx = rcp_fast(dx); tv.idy = rcp_fast(dy); tv.idz = rcp_fast(dz);
-    if (TRG_TRAV_LDS == 7 && rel) {   // half-precision LDS nodes: their planes are relative to the centre, like the plane records
-        const V3 oc = o - sc.center;
-        tv.oix = oc.x * tv.idx; tv.oiy = oc.y * tv.idy; tv.oiz = oc.z * tv.idz;
-    } else {
-        tv.oix = o.x * tv.idx; tv.oiy = o.y * tv.idy; tv.oiz = o.z * tv.idz;
-    }
+    tv.oix = o.x * tv.idx; tv.oiy = o.y * tv.idy; tv.oiz = o.z * tv.idz;
     // the plane test of an LDS-resident scene reads the mask off the u16 per record, (original index << 2) | (material id & 3): only the two low bits
     // of a ray's mask may take part, or they would match index bits.  (The renderers' rays carry 3 or 1; trg_trace sends rays whose mask has
     // higher bits through the HBM records, which keep the whole material id: trg_capi.cpp.)
@@ -669,55 +663,15 @@ TRG_DEV void trav_begin(const SceneView &sc, Trav &tv, V3 o, V3 d, float tmax, u
     tv.hit.t = -1.0f; tv.hit.prim = -1; tv.hit.u = 0.0f; tv.hit.v = 0.0f;
     tv.found = false;
     tv.node = 0; tv.sp = sp0;  // sp0 = stk.first(): the empty stack
-    // sign-ordered LDS nodes: LDS address of the slab copy to read per axis, for node 0 (node_base = LDS address of the
-    // node array; layout: trav_node_step_signed).
-    if (wide_lds) {   // 4-wide LDS nodes: [lo4 | hi4 | lo4] per axis at +0 / +48 / +96, read at +16 for a negative direction
-        tv.sx = (int)(node_base + ((__float_as_uint(dx) >> 31) << 4));
-        tv.sy = (int)(node_base + 48u + ((__float_as_uint(dy) >> 31) << 4));
-        tv.sz = (int)(node_base + 96u + ((__float_as_uint(dz) >> 31) << 4));
-    } else if (TRG_TRAV_LDS == 7) {   // ... in half precision: [X | Y] of the sign pair at +0 / +16 / +32 / +48, [Z | children] at +64 / +80
-        tv.sx = (int)(node_base + (((__float_as_uint(dx) >> 31) | ((__float_as_uint(dy) >> 31) << 1)) << 4));
-        tv.sy = 0;
-        tv.sz = (int)(node_base + 64u + ((__float_as_uint(dz) >> 31) << 4));
-    } else {   // sign-ordered BVH2: the [X | Y] block of the sign pair at +0 / +32 / +64 / +96, Z+ Z- at +128 / +160
-        tv.sx = (int)(node_base + (((__float_as_uint(dx) >> 31) | ((__float_as_uint(dy) >> 31) << 1)) << 5));
-        tv.sy = 0;
-        tv.sz = (int)(node_base + 128u + ((__float_as_uint(dz) >> 31) << 5));
-    }
+    // sign-ordered LDS nodes: LDS address of the slab copy to read per axis, for node 0 (node_base = LDS address of the node array; layout:
+    // trav_node_step_signed): the [X | Y] block of the sign pair at +0 / +32 / +64 / +96, Z+ Z- at +128 / +160
+    tv.sx = (int)(node_base + (((__float_as_uint(dx) >> 31) | ((__float_as_uint(dy) >> 31) << 1)) << 5));
+    tv.sz = (int)(node_base + 128u + ((__float_as_uint(dz) >> 31) << 5));
 }
 
-// One inner-node step: test both child boxes, descend into the nearer hit child, push the other, or pop.
-// Written with selects and two predicated LDS stack accesses instead of a four-way branch: the branchy
-// form spent more scalar instructions on exec-mask bookkeeping than vector instructions on the boxes.
-template <bool COUNT, int BLOCK, typename STK>
-TRG_DEV void trav_node_math(const v4f n0, const v4f n1, const v4f n2, const v4f n3, Trav &tv, STK stk, Counters &cnt) {
-    if (COUNT) { cnt.nodes++; if (mbcnt64(__ballot(1)) == 0) cnt.wnodes++; }
-    // slab tests; (b - o) * inv written as b*inv - o*inv so the fast build gets one fma each.
-    // Boxes are padded by 2e-5 x scene extent on the host, far more than the rounding of these
-    // products, so a triangle the Moeller-Trumbore test accepts is never culled.
-    const float ax0 = n0.x * tv.idx - tv.oix, ax1 = n0.y * tv.idx - tv.oix, ay0 = n0.z * tv.idy - tv.oiy, ay1 = n0.w * tv.idy - tv.oiy;
-    const float bx0 = n1.x * tv.idx - tv.oix, bx1 = n1.y * tv.idx - tv.oix, by0 = n1.z * tv.idy - tv.oiy, by1 = n1.w * tv.idy - tv.oiy;
-    const float az0 = n2.x * tv.idz - tv.oiz, az1 = n2.y * tv.idz - tv.oiz, bz0 = n2.z * tv.idz - tv.oiz, bz1 = n2.w * tv.idz - tv.oiz;
-    const float amin = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fmaxf(fminf(az0, az1), 0.0f));
-    const float amax = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fminf(fmaxf(az0, az1), tv.best));
-    const float bmin = fmaxf(fmaxf(fminf(bx0, bx1), fminf(by0, by1)), fmaxf(fminf(bz0, bz1), 0.0f));
-    const float bmax = fminf(fminf(fmaxf(bx0, bx1), fmaxf(by0, by1)), fminf(fmaxf(bz0, bz1), tv.best));
-    const bool ha = amin <= amax, hb = bmin <= bmax;
-    const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-    const bool both = ha && hb, none = !(ha || hb);
-    const bool first1 = hb && (!ha || bmin < amin);  // child 1 is the (nearer) one to enter
-    const int nearc = first1 ? c1 : c0, farc = first1 ? c0 : c1;
-    if (both) stk.push(tv.sp, farc);
-    int sp = tv.sp + (both ? STK::unit : 0);
-    int next = nearc;
-    if (none) {
-        sp -= STK::unit;
-        next = stk.pop(sp);  // the sentinel at level 0 when nothing is pending
-    }
-    tv.node = next; tv.sp = sp;
-}
-
-// The same step on a SIGN-ORDERED node (LDS-resident scenes, TRG_TRAV_LDS == 4).  A 208-byte node keeps, per axis,
+// One inner-node step of an LDS-resident scene: test both child boxes of a SIGN-ORDERED BVH2 node, descend into the nearer hit child,
+// keep the other on the stack, or pop -- selects and two LDS stack accesses instead of a four-way branch (the branchy form spent more
+// scalar instructions on exec-mask bookkeeping than vector instructions on the boxes).  A 208-byte node keeps, per axis,
 // the four slab planes of its two children twice: as (lo_a, hi_a, lo_b, hi_b) and as (hi_a, lo_a, hi_b, lo_b).  A
 // lane reads the copy that matches the sign of its ray direction (an LDS address fixed per ray, trav_begin), so
 // x = near plane, y = far plane without the 12 min/max that order them -- the values are the same floats the
@@ -769,49 +723,6 @@ TRG_DEV void trav_node_step_signed(const SceneView &sc, Trav &tv, STK stk, Count
         next = stk.pop(sp);  // the sentinel at level 0 when nothing is pending
     }
     tv.node = next; tv.sp = sp;
-}
-
-// The same step on the HALF-precision sign-ordered node (TRG_TRAV_LDS == 7, trg_kernels.h kHalfLds): two 16-byte reads -- [X pair | Y pair] of this
-// ray's sign pair, [Z pair | child0 child1] of its Z sign --; the slab products convert in the multiply (v_fma_mix_f32 in the shipped build).
-template <bool COUNT, int BLOCK, typename STK>
-TRG_DEV void trav_node_step_half(const SceneView &sc, Trav &tv, STK stk, Counters &cnt) {
-    if (COUNT) { cnt.nodes++; if (mbcnt64(__ballot(1)) == 0) cnt.wnodes++; }
-    typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
-    typedef __attribute__((address_space(3))) h8_t lds_h8_t;
-    typedef int v4i_t __attribute__((ext_vector_type(4)));
-    const uint32_t az_addr = (uint32_t)(tv.node + tv.sz), axy_addr = (uint32_t)(tv.node + tv.sx);
-    const h8_t XY = *(const lds_h8_t *)(uintptr_t)axy_addr;
-    const h8_t ZH = *(const lds_h8_t *)(uintptr_t)az_addr;      // (halves 0..3: the Z pair; the other eight bytes: the two children)
-    const v4i_t ZC = __builtin_bit_cast(v4i_t, ZH);
-    const int c0 = ZC.z, c1 = ZC.w;
-    const float anx = (float)XY[0] * tv.idx - tv.oix, afx = (float)XY[1] * tv.idx - tv.oix, bnx = (float)XY[2] * tv.idx - tv.oix, bfx = (float)XY[3] * tv.idx - tv.oix;
-    const float any_ = (float)XY[4] * tv.idy - tv.oiy, afy = (float)XY[5] * tv.idy - tv.oiy, bny = (float)XY[6] * tv.idy - tv.oiy, bfy = (float)XY[7] * tv.idy - tv.oiy;
-    const float anz = (float)ZH[0] * tv.idz - tv.oiz, afz = (float)ZH[1] * tv.idz - tv.oiz, bnz = (float)ZH[2] * tv.idz - tv.oiz, bfz = (float)ZH[3] * tv.idz - tv.oiz;
-    const float amin = fmaxf(fmaxf(anx, any_), fmaxf(anz, 0.0f));
-    const float amax = fminf(fminf(afx, afy), min_raw(afz, tv.best));
-    const float bmin = fmaxf(fmaxf(bnx, bny), fmaxf(bnz, 0.0f));
-    const float bmax = fminf(fminf(bfx, bfy), min_raw(bfz, tv.best));
-    const bool ha = amin <= amax, hb = bmin <= bmax;
-    const bool both = ha && hb, none = !(ha || hb);
-    const bool first1 = hb && (!ha || bmin < amin);
-    const int nearc = first1 ? c1 : c0, farc = first1 ? c0 : c1;
-    stk.push(tv.sp, farc);
-    int sp = tv.sp + (both ? STK::unit : 0);
-    int next = nearc;
-    if (none) {
-        sp -= STK::unit;
-        next = stk.pop(sp);
-    }
-    tv.node = next; tv.sp = sp;
-}
-
-template <bool COUNT, int BLOCK, int LMODE = 0, typename STK>
-TRG_DEV void trav_node_step(const SceneView &sc, Trav &tv, STK stk, Counters &cnt) {
-    if (LMODE == 4) { trav_node_step_signed<COUNT, BLOCK>(sc, tv, stk, cnt); return; }
-    if (LMODE == 7) { trav_node_step_half<COUNT, BLOCK>(sc, tv, stk, cnt); return; }
-    const v4f *n = sc.nodes + tv.node * 4;
-    const v4f n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
-    trav_node_math<COUNT, BLOCK>(n0, n1, n2, n3, tv, stk, cnt);
 }
 
 // One ray/triangle test folded into the traversal state; returns true when an any-hit query is satisfied.
@@ -913,23 +824,9 @@ TRG_DEV Hit trav_hit(const Trav &tv) {
 
 // One leaf: test its 1..8 triangles.  ~node = (first << 3) | (count - 1).  Pops the next node (the sentinel kNodeDone when
 // nothing is pending) and returns true when an any-hit query is satisfied -- the caller then stops whatever was popped.
-// the triangles of one leaf, without touching the stack (the octant-threaded walk, TRG_TRAV_LDS == 6)
 TRG_DEV const v4f *lds_records(const SceneView &sc, uint32_t first) {
     return reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(sc.tris) + __umul24(first, 48u));
 }
-template <bool COUNT>
-TRG_DEV bool trav_leaf_test(const SceneView &sc, Trav &tv, int leaf, bool any, Counters &cnt) {
-    const uint32_t code = (uint32_t)~leaf;
-    const bool quad = (code & 7u) == kLeafQuad;
-    const uint32_t first = code >> 3, count = quad ? 2u : (code & 7u) + 1u;
-    const v4f *tr = lds_records(sc, first);
-    if (kTriPlanes && quad) return trav_quad_planes<COUNT>(sc, tr, first, tv, any, cnt);
-    bool stop = trav_tri_lds<COUNT>(sc, tr, first, tv, any, cnt);
-    if (!stop && count > 1u) stop = trav_tri_lds<COUNT>(sc, tr + 3, first + 1u, tv, any, cnt);
-    for (uint32_t k = 2; k < count && !stop; ++k) stop = trav_tri_lds<COUNT>(sc, tr + k * 3, first + k, tv, any, cnt);
-    return stop;
-}
-
 template <bool COUNT, int BLOCK, typename STK>
 TRG_DEV bool trav_leaf_step(const SceneView &sc, Trav &tv, bool any, STK stk, Counters &cnt) {
     const uint32_t code = (uint32_t)~tv.node;
@@ -1029,37 +926,6 @@ TRG_DEV void trav_node4_math(const v4f q0, const v4f q1, const v4f q2, const v4f
     wide_select<BLOCK>(t[0], t[1], t[2], t[3], c0, c1, c2, c3, tv, stk);
 }
 
-// One 4-wide step on a sign-ordered FLOAT node in LDS (TRG_TRAV_LDS == 5; trg_capi.cpp stages the layout): six 16-byte reads give
-// the near and far planes of the four children per axis in the order the ray meets them (the address carries the direction sign,
-// trav_begin), one more the children.  24 fma + 8 three-operand min/max + 8 min/max; any-hit rays skip the ordering.
-template <bool COUNT, int BLOCK, typename STK>
-TRG_DEV void trav_node4_step_lds(const SceneView &sc, Trav &tv, STK stk, Counters &cnt, uint32_t child_base) {
-    if (COUNT) { cnt.nodes += 2; if (mbcnt64(__ballot(1)) == 0) cnt.wnodes++; }
-    const v4f nx = *(const lds_v4f_t *)(uintptr_t)(uint32_t)(tv.node + tv.sx), fx = *(const lds_v4f_t *)(uintptr_t)(uint32_t)(tv.node + tv.sx + 16);
-    const v4f ny = *(const lds_v4f_t *)(uintptr_t)(uint32_t)(tv.node + tv.sy), fy = *(const lds_v4f_t *)(uintptr_t)(uint32_t)(tv.node + tv.sy + 16);
-    const v4f nz = *(const lds_v4f_t *)(uintptr_t)(uint32_t)(tv.node + tv.sz), fz = *(const lds_v4f_t *)(uintptr_t)(uint32_t)(tv.node + tv.sz + 16);
-    const v4f ch = *(const lds_v4f_t *)(uintptr_t)(uint32_t)(tv.node + child_base);
-    float t[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float tnx = nx[k] * tv.idx - tv.oix, tfx = fx[k] * tv.idx - tv.oix;
-        const float tny = ny[k] * tv.idy - tv.oiy, tfy = fy[k] * tv.idy - tv.oiy;
-        const float tnz = nz[k] * tv.idz - tv.oiz, tfz = fz[k] * tv.idz - tv.oiz;
-        const float tmin = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
-        const float tmax = fminf(fminf(tfx, tfy), min_raw(tfz, tv.best));
-        t[k] = (tmin <= tmax) ? tmin : INFINITY;   // an unused slot has an inverted box: never entered
-    }
-    wide_select<BLOCK>(t[0], t[1], t[2], t[3], __float_as_int(ch.x), __float_as_int(ch.y), __float_as_int(ch.z), __float_as_int(ch.w), tv, stk);
-}
-
-// the inner-node step of the while-while schedules: BVH2 (0), sign-ordered BVH2 in LDS (4), sign-ordered 4-wide in LDS (5), sign-ordered BVH2 in half precision (7)
-template <bool COUNT, int BLOCK, int LMODE, typename STK>
-TRG_DEV void trav_inner_step(const SceneView &sc, Trav &tv, STK stk, Counters &cnt) {
-    if (LMODE == 6) tv.node = kNodeDone;   // the octant-threaded layout is walked by traverse() only: the pool / wavefront / pair loops trace nothing in that (experimental) build
-    else if (LMODE == 5) trav_node4_step_lds<COUNT, BLOCK>(sc, tv, stk, cnt, (uint32_t)(uintptr_t)(const lds_v4f_t *)sc.nodes + 144u);
-    else trav_node_step<COUNT, BLOCK, LMODE>(sc, tv, stk, cnt);
-}
-
 // one unit of work per lane per iteration on the 4-wide tree: a quantised node (four 16-byte loads = 64 bytes)
 // or one triangle of the current leaf (the first three 16-byte rows of its 128-byte record)
 template <bool COUNT, int BLOCK, typename STK>
@@ -1097,22 +963,15 @@ TRG_DEV void trav_step_wide(const SceneView &sc, Trav &tv, bool any, STK stk, Co
     }
 }
 
-// traversal schedules.  LDS-resident scenes (TRG_TRAV_LDS): 0 = while-while on BVH2, 4 = while-while on sign-ordered BVH2 nodes
-// (default), 5 = sign-ordered 4-wide float nodes.  HBM-resident scenes (TRG_TRAV_HBM): 3 = the unified step on the quantised
-// 4-wide tree -- one unit of work per lane per iteration, a node or one triangle, off one group of loads (the only one left: the
-// unified step on BVH2 nodes of round 1 and a schedule with one block kind per iteration chosen by a lane-count vote measured
-// no better on C4 and 9 % worse on C2).
-#ifndef TRG_TRAV_LDS
-#define TRG_TRAV_LDS 4
-#endif
-#ifndef TRG_TRAV_HBM
-#define TRG_TRAV_HBM 3
-#endif
+// Traversal schedules.  LDS-resident scenes: while-while on the sign-ordered BVH2 nodes.  HBM-resident scenes (UNIFIED): the unified step on
+// the quantised 4-wide tree -- one unit of work per lane per iteration, a node or one triangle, off one group of loads.  (Measured and
+// dropped, NOTEBOOK.md: a plain BVH2, a sign-ordered 4-wide float tree, an octant-threaded stackless walk and half-precision nodes in LDS;
+// the unified step on BVH2 nodes and a block-kind vote per iteration in HBM.)
 
 // LDS address of the node array when the traversal reads sign-ordered LDS nodes (UNIFIED = false selects the LDS schedule)
 template <bool UNIFIED>
 TRG_DEV uint32_t lds_node_base(const SceneView &sc) {
-    return (!UNIFIED && (TRG_TRAV_LDS == 4 || TRG_TRAV_LDS == 5 || TRG_TRAV_LDS == 6 || TRG_TRAV_LDS == 7)) ? (uint32_t)(uintptr_t)(const lds_v4f_t *)sc.nodes : 0u;
+    return !UNIFIED ? (uint32_t)(uintptr_t)(const lds_v4f_t *)sc.nodes : 0u;
 }
 
 // Nearest-hit (ANY=false) or any-hit (ANY=true) query for one ray per lane.
@@ -1124,45 +983,12 @@ TRG_DEV bool traverse(const SceneView &sc, V3 o, V3 d, float tmax_ray, uint32_t 
     return !ANY;
 #endif
     Trav tv;
-    trav_begin(sc, tv, o, d, tmax_ray, rmask, stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED && TRG_TRAV_LDS == 5, !UNIFIED);
-    constexpr int mode = UNIFIED ? TRG_TRAV_HBM : TRG_TRAV_LDS;
-    if (mode == 3) {
+    trav_begin(sc, tv, o, d, tmax_ray, rmask, stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED);
+    if (UNIFIED) {
         while (tv.node != kNodeDone) trav_step_wide<COUNT, BLOCK>(sc, tv, ANY, stk, cnt);
-    } else if (mode == 6) {
-        // Octant-threaded walk (experiment; layout: trg_capi.cpp host_scene_build): position k of this ray's octant table names an entry
-        // (one child box) and a skip link; box entered -> k + 1 (its first child, or the next sibling after a leaf), missed -> the link.
-        const uint32_t nb = lds_node_base<UNIFIED>(sc), E = sc.thr_entries;
-        const uint32_t negx = __float_as_uint(tv.idx) >> 31, negy = __float_as_uint(tv.idy) >> 31, negz = __float_as_uint(tv.idz) >> 31;
-        const uint32_t ax = nb + negx * 8u, ay = nb + 16u + negy * 8u, az = nb + 32u + negz * 8u;
-        const uint32_t otab = nb + E * 64u + (negx | (negy << 1) | (negz << 2)) * (E + 1u) * 4u;
-        uint32_t k = 0u;
-        for (;;) {
-            int leaf = 0;
-            while (k < E) {
-                const uint32_t w = (uint32_t)*(const lds_int_t *)(uintptr_t)(otab + k * 4u);
-                const uint32_t e = w & 0xFFFFu;
-                typedef float v2f __attribute__((ext_vector_type(2)));
-                typedef __attribute__((address_space(3))) v2f lds_v2f_t;
-                const v2f X = *(const lds_v2f_t *)(uintptr_t)(e + ax);
-                const v2f Y = *(const lds_v2f_t *)(uintptr_t)(e + ay);
-                const v2f Z = *(const lds_v2f_t *)(uintptr_t)(e + az);
-                const int code = *(const lds_int_t *)(uintptr_t)(e + nb + 48u);
-                if (COUNT) { if (k & 1u) cnt.nodes++; if (mbcnt64(__ballot(1)) == 0) cnt.wnodes++; }
-                const float nx = X.x * tv.idx - tv.oix, fx = X.y * tv.idx - tv.oix;
-                const float ny = Y.x * tv.idy - tv.oiy, fy = Y.y * tv.idy - tv.oiy;
-                const float nz = Z.x * tv.idz - tv.oiz, fz = Z.y * tv.idz - tv.oiz;
-                const float tmin = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));
-                const float tmax = fminf(fminf(fx, fy), min_raw(fz, tv.best));
-                const bool in = tmin <= tmax;
-                k = in ? k + 1u : (w >> 16);
-                if (in && code < 0) { leaf = code; break; }
-            }
-            if (leaf == 0) break;
-            if (trav_leaf_test<COUNT>(sc, tv, leaf, ANY, cnt)) break;   // any-hit satisfied
-        }
     } else {
         for (;;) {
-            while (tv.node >= 0) trav_inner_step<COUNT, BLOCK, (mode >= 4 ? mode : 0)>(sc, tv, stk, cnt);
+            while (tv.node >= 0) trav_node_step_signed<COUNT, BLOCK>(sc, tv, stk, cnt);
             if (tv.node == kNodeDone) break;
             if (trav_leaf_step<COUNT, BLOCK>(sc, tv, ANY, stk, cnt)) break;   // any-hit satisfied
             if (tv.node == kNodeDone) break;
@@ -1184,127 +1010,26 @@ TRG_DEV void traverse_pair(const SceneView &sc, V3 org, bool has_shadow, V3 sdir
     nhit.t = -1.0f; nhit.prim = -1; nhit.u = 0.0f; nhit.v = 0.0f;
     int phase = has_shadow ? 0 : (has_next ? 1 : 2);
     Trav tv;
-    trav_begin(sc, tv, org, phase == 0 ? sdir : ndir, phase == 0 ? smax : INFINITY, phase == 0 ? 1u : nmask, stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED && TRG_TRAV_LDS == 5, !UNIFIED);
+    trav_begin(sc, tv, org, phase == 0 ? sdir : ndir, phase == 0 ? smax : INFINITY, phase == 0 ? 1u : nmask, stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED);
     if (phase == 2) tv.node = kNodeDone;
-    constexpr int mode = UNIFIED ? TRG_TRAV_HBM : TRG_TRAV_LDS;
     while (phase < 2) {
         const bool any = phase == 0;
-        if (mode == 3) {
+        if (UNIFIED) {
             trav_step_wide<COUNT, BLOCK>(sc, tv, any, stk, cnt);
         } else {
-            while (tv.node >= 0) trav_inner_step<COUNT, BLOCK, (mode >= 4 ? mode : 0)>(sc, tv, stk, cnt);
+            while (tv.node >= 0) trav_node_step_signed<COUNT, BLOCK>(sc, tv, stk, cnt);
             if (tv.node != kNodeDone && trav_leaf_step<COUNT, BLOCK>(sc, tv, any, stk, cnt)) tv.node = kNodeDone;
         }
         if (tv.node == kNodeDone) {
             if (phase == 0) {
                 occluded = tv.found;
                 phase = has_next ? 1 : 2;
-                if (phase == 1) trav_begin(sc, tv, org, ndir, INFINITY, nmask, stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED && TRG_TRAV_LDS == 5, !UNIFIED);
+                if (phase == 1) trav_begin(sc, tv, org, ndir, INFINITY, nmask, stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED);
             } else {
                 nhit = trav_hit(tv); nfound = tv.found;
                 phase = 2;
             }
         }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Queue-draining tracer for the path-pool megakernel (render_pool_kernel).
-//
-// A workgroup keeps a pool of path slots in LDS; a compacted list names the rays to trace this phase
-// (nearest-hit rays of the current bounce and any-hit shadow rays of the previous one, mixed).  Every
-// lane of every wavefront is a worker: when it has no ray it takes the next list entry (one LDS atomic
-// per wavefront per refill, slots handed out with a ballot / mbcnt prefix), traverses, writes the result
-// to the slot and comes back for more.  Lanes whose rays end early therefore do not idle until the
-// slowest lane of the wavefront is done -- the reason secondary rays ran at 23-46 % lane utilisation in
-// the one-ray-per-lane kernel.  A refill is attempted only when >= kRefillMin lanes are idle (or all are).
-//
-// Slot layout (float4 arrays in LDS, P = slots per workgroup):
-//   R0[s] = (origin.xyz, maxDistance)   R1[s] = (direction.xyz, bits mask)      nearest-hit ray
-//   SH[s] = (shadow direction.xyz, shadow maxDistance; set to -1 by the tracer when occluded);
-//           the shadow ray starts at R0[s].xyz (same origin as the next bounce ray); tracers never write R0/R1
-//   H[s]  = (t or -1, bits primitiveIndex, u, v)                                 nearest-hit result
-// List entry = slot | (kind << 15), kind 0 = nearest, 1 = shadow (any-hit, mask 1).
-// ---------------------------------------------------------------------------------------------
-#ifndef TRG_REFILL_MIN
-#define TRG_REFILL_MIN 16
-#endif
-constexpr int kRefillMin = TRG_REFILL_MIN;
-
-struct PoolView {
-    v4f *R0, *R1, *SH, *H;
-};
-
-template <bool COUNT, int BLOCK, bool UNIFIED = false, typename STK>
-TRG_DEV void trace_queue(const SceneView &sc, const PoolView pv, const unsigned short *list, uint32_t count,
-                         uint32_t *head, STK stk, Counters &cnt) {
-    const uint32_t lane = threadIdx.x & 63u;
-    bool busy = false, exhausted = false, any = false;
-    uint32_t slot = 0;
-    Trav tv;
-    trav_begin(sc, tv, mk(0.0f, 0.0f, 0.0f), mk(0.0f, 0.0f, 1.0f), 0.0f, 0u, stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED && TRG_TRAV_LDS == 5, !UNIFIED);
-    tv.node = kNodeDone;
-    for (;;) {
-        // ---- refill: idle lanes take the next list entries ----
-        const uint64_t idle = __ballot(!busy);
-        if (!exhausted && idle != 0ull) {
-            const uint32_t n_idle = (uint32_t)__popcll(idle);
-            const int leader = __ffsll((long long)idle) - 1;
-            uint32_t base = 0;
-            if ((int)lane == leader) base = atomicAdd(head, n_idle);
-            base = (uint32_t)__shfl((int)base, leader, 64);
-            if (base + n_idle >= count) exhausted = true;
-            const uint32_t my = base + mbcnt64(idle);
-            if (!busy && my < count) {
-                const uint32_t e = list[my];
-                slot = e & 0x7FFFu;
-                any = (e >> 15) != 0u;
-                const v4f r0 = pv.R0[slot];  // the shadow ray starts where the next ray starts
-                const v4f r1 = any ? pv.SH[slot] : pv.R1[slot];
-                trav_begin(sc, tv, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), any ? r1.w : r0.w,
-                           any ? 1u : (uint32_t)__float_as_int(r1.w), stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED && TRG_TRAV_LDS == 5, !UNIFIED);
-                busy = true;
-            }
-        }
-        if (__ballot(busy) == 0ull) break;
-        if (busy) {
-            constexpr int mode = UNIFIED ? TRG_TRAV_HBM : TRG_TRAV_LDS;
-            for (;;) {
-                if (mode == 3) {
-                    trav_step_wide<COUNT, BLOCK>(sc, tv, any, stk, cnt);
-                } else {
-                    while (tv.node >= 0) trav_inner_step<COUNT, BLOCK, (mode >= 4 ? mode : 0)>(sc, tv, stk, cnt);
-                    if (tv.node == kNodeDone) break;
-                    if (trav_leaf_step<COUNT, BLOCK>(sc, tv, any, stk, cnt)) tv.node = kNodeDone;
-                }
-                if (tv.node == kNodeDone) break;
-                // enough lanes of this wavefront have run dry: let them refill (state stays in registers)
-                if (!exhausted && __popcll(__ballot(1)) <= 64 - kRefillMin) break;
-            }
-            if (tv.node == kNodeDone) {
-                if (any) {
-                    if (tv.found) { v4f sh = pv.SH[slot]; sh.w = -1.0f; pv.SH[slot] = sh; }
-                } else {
-                    v4f h;
-                    h.x = tv.found ? tv.best : -1.0f; h.y = __int_as_float(tv.hit.prim); h.z = tv.hit.u; h.w = tv.hit.v;
-                    pv.H[slot] = h;
-                }
-                busy = false;
-            }
-        }
-    }
-}
-
-// wave-compacted append of `val` to an LDS list: one atomic per wavefront, slots by ballot prefix
-TRG_DEV void list_append(bool pred, unsigned short val, unsigned short *list, uint32_t *counter) {
-    const uint64_t m = __ballot(pred);
-    if (m != 0ull) {
-        const uint32_t lane = threadIdx.x & 63u;
-        const int leader = __ffsll((long long)m) - 1;
-        uint32_t base = 0;
-        if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
-        base = (uint32_t)__shfl((int)base, leader, 64);
-        if (pred) list[base + mbcnt64(m)] = val;
     }
 }
 

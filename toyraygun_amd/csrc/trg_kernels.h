@@ -7,6 +7,10 @@
 
 #include "../../include/trg.h"
 
+#ifndef TRG_EXPERIMENTS
+#define TRG_EXPERIMENTS 0   // 1: experiments/lib/libtoyraygun_hip_exp.so -- this library + the schedules kept in experiments/ (pool, wavefront)
+#endif
+
 namespace trg {
 
 #ifndef TRG_BLOCK
@@ -34,11 +38,6 @@ constexpr uint32_t kMaxLdsScene = TRG_MAX_LDS_SCENE_KB * 1024u;  // scenes up to
 #ifndef TRG_STACK_LDS_LEVELS
 #define TRG_STACK_LDS_LEVELS 12
 #endif
-#ifndef TRG_POOL_S
-#define TRG_POOL_S 2
-#endif
-constexpr int kPoolS = TRG_POOL_S;           // frames (path slots per thread) a pool workgroup keeps in flight
-constexpr uint32_t kPoolSlotBytes = 64u;      // R0, R1, SH, H: four float4 per slot
 
 // The scene lives in ONE device allocation.  A scene small enough for LDS starts with the part a workgroup stages:
 // [nodes | tris | normals | colors | mats | Halton tables], every section 16-byte aligned, so that it goes into LDS with a single
@@ -51,7 +50,6 @@ struct SceneDesc {
     uint32_t lds_stage_bytes;       // bytes a workgroup stages into LDS (everything before the 4-wide nodes)
     uint32_t off_htab;              // Halton group tables (kHtabFloats floats), inside the staged region
     uint32_t off_fat, n_fat;        // leaf records of the HBM traversal: geometry + attributes, 128 bytes each, 128-byte aligned, leaf order
-    uint32_t thr_entries;           // TRG_TRAV_LDS == 6 (experiment): entries of the octant-threaded tree in the LDS node section
     // LDS-resident scenes, shipped build (TRG_TRI_PLANES, round 4): the triangle test on three precomputed PLANES per triangle -- 48 bytes in
     // leaf order like the Moeller-Trumbore records (off_tris), kept outside the staged part and copied over them at staging time --
     // and, inside the staged part, one u16 per record: (original index << 2) | (material id & 3), the test's mask and the hit's primitive
@@ -89,8 +87,7 @@ struct RenderParams {
     uint32_t frame_begin, spp, bounces, row0, rows, tiles_x;
     uint32_t stack_off;            // byte offset of the traversal stacks in dynamic LDS
     uint32_t red_off;              // byte offset of the counter-reduction scratch in dynamic LDS
-    uint32_t pool_off;             // render_pool_kernel: byte offset of the path pool (slots, lists, counters);
-                                   // render_fp_kernel: byte offset of the parked per-frame radiances
+    uint32_t pool_off;             // render_fp_kernel: byte offset of the parked per-frame radiances (experiments: render_pool_kernel's path pool)
     TexDesc tex;
     uint32_t acc_off;              // render_kernel on an HBM-resident scene: byte offset of the parked running average (3 x kBlock floats)
     // tail compaction (trg_tail.inc.h): bounces >= tail_k of the frames of a chunk run in a second launch on compacted paths
@@ -194,28 +191,6 @@ TRG_HD inline bool tile_of_slot(uint32_t tiles_x, uint32_t tiles_y, uint32_t xcd
     return true;
 }
 
-// ---- wavefront schedule (TRG_KERNEL_WAVEFRONT, trg_wavefront.inc.h): path state and ray queues of one batch in HBM ----
-constexpr uint32_t kWfMaxPaths = 8u << 20;   // pixel-samples per batch (112 B of state each)
-constexpr uint32_t kWfMaxStages = TRG_MAX_BOUNCES + 2u;
-constexpr uint32_t kWfPathBytes = 7u * 16u;  // ray_o, ray_d, sh, hit, thr, rad, scol
-struct WfBuffers {
-    void *ray_o, *ray_d, *sh, *hit, *thr, *rad, *scol;   // float4[nb] each
-    uint32_t *list[2];                                   // 2 * nb entries each
-    uint32_t *ctr;                                       // 4 per stage: head, count, -, -
-};
-struct WfParams {
-    trg_uniforms u;
-    SceneDesc sc;
-    const uint32_t *offsets;
-    float *accum;
-    unsigned long long *counters;
-    WfBuffers b;
-    TexDesc tex;
-    uint32_t nb, npix, pix0, frame0, nframes, bounces, stage, bounce;
-    uint32_t stack_off;
-    StackDesc stack;
-};
-
 struct TraceParams {
     SceneDesc sc;
     const trg_ray *rays;
@@ -248,51 +223,22 @@ struct HtabSpec { uint32_t base, digits, radix, offset; };
 constexpr HtabSpec kHtab[5] = { { 3, 4, 81, 0 }, { 5, 3, 125, 81 }, { 7, 2, 49, 206 }, { 11, 2, 121, 255 }, { 13, 2, 169, 376 } };
 constexpr uint32_t kHtabFloats = 545, kHtabBytes = 2192;  // 545 * 4 rounded up to 16
 
-// which BVH flavour the HBM (non-LDS) kernels traverse; must match TRG_TRAV_HBM in trg_device.h (3 = quantised 4-wide: the only one)
-#ifndef TRG_TRAV_HBM
-#define TRG_TRAV_HBM 3
-#endif
-constexpr bool kWideHbm = (TRG_TRAV_HBM == 3);
-static_assert(kWideHbm, "scenes in HBM are traversed through the quantised 4-wide tree and 128-byte leaf records");
-// which node layout LDS-resident scenes are staged in; must match TRG_TRAV_LDS in trg_device.h
-#ifndef TRG_TRAV_LDS
-#define TRG_TRAV_LDS 4
-#endif
-constexpr bool kSignedLds = (TRG_TRAV_LDS == 4);
-constexpr bool kWideLds = (TRG_TRAV_LDS == 5);   // sign-ordered 4-wide float nodes in LDS (160 bytes)
-// 6 (round-3 experiment, measured slower: DESIGN section 6): the BVH2 as an OCTANT-THREADED list -- one 64-byte entry per child box (its
-// slab planes in both orders per axis + the leaf code), and for each of the 8 direction octants a table of the entries in depth-first
-// near-to-far order with a skip link each (next position when the box is missed): no stack, no near / far select.  Only traverse() walks it
-// (the direct, frame-parallel and tail kernels); the pool and wavefront schedules are not available in that build.
-constexpr bool kThreadedLds = (TRG_TRAV_LDS == 6);
-// 7 (round-4 experiment): the sign-ordered BVH2 node with its slab planes in HALF precision, relative to SceneDesc::center and rounded outward
-// (lo down, hi up: the boxes only grow): [X pair | Y pair] of 8 + 8 bytes per sign pair at 0 / 16 / 32 / 48, [Z pair | child0 child1] at 64 / 80,
-// 96 bytes + 16 of padding (a 28-dword stride spreads 16 nodes over all bank groups).  A node step reads 2 x 16 bytes instead of 56; the slab
-// products take the half straight from the register (v_fma_mix_f32).  MEASURED SLOWER (profiles/r04/ab_half_precision_nodes.txt: C2 1.62 -> 1.83 ms
-// per step, C3 13.5 -> 15.0): twelve v_fma_mix_f32 cost about twice twelve v_fma_f32, more than the 6 LDS-array cycles per step they save.  Parity is
-// green in that build (the boxes only grow); it stays as an experiment like 5 and 6.
-constexpr bool kHalfLds = (TRG_TRAV_LDS == 7);
-constexpr uint32_t kLdsNodeBytes = kWideLds ? 160u : (kSignedLds ? 208u : (kHalfLds ? 112u : 64u));   // (sign-ordered BVH2: 192 bytes used + 16 of padding, trg_device.h kSignedNodeBytes)
-static_assert(!(kSignedLds || kWideLds || kThreadedLds || kHalfLds) || kWideHbm, "the LDS node layouts replace the BVH2 array: the HBM kernels must use the 4-wide tree");
+// Node layouts.  Scenes traversed from HBM: the quantised 4-wide tree (q4node.h, 64 bytes per node) and 128-byte leaf records.  Scenes staged in
+// LDS: the SIGN-ORDERED BVH2 node (trg_device.h trav_node_step_signed): 192 bytes used + 16 of padding.  (A plain 64-byte BVH2 node, a
+// sign-ordered 4-wide float node, an octant-threaded stackless list and a half-precision node were built and measured slower: NOTEBOOK.md.)
+constexpr uint32_t kLdsNodeBytes = 208u;
 
 #define TRG_DECL_LAUNCHERS(SFX)                                                                                   \
     hipError_t launch_render_##SFX(const RenderParams &p, bool lds_scene, bool counters, uint32_t grid,          \
                                    size_t lds_bytes, hipStream_t s);                                             \
     hipError_t launch_render_regen_##SFX(const RenderParams &p, bool counters, uint32_t grid, size_t lds_bytes, hipStream_t s); \
     hipError_t launch_regen_accumulate_##SFX(const RenderParams &p, uint32_t grid, hipStream_t s);               \
-    hipError_t launch_render_pool_##SFX(const RenderParams &p, bool lds_scene, bool counters, uint32_t grid,     \
-                                        size_t lds_bytes, hipStream_t s);                                        \
     hipError_t launch_render_fp_##SFX(const RenderParams &p, bool lds_scene, bool counters, uint32_t grid,       \
                                       size_t lds_bytes, hipStream_t s);                                          \
     hipError_t launch_render_head_##SFX(const RenderParams &p, bool counters, uint32_t grid, size_t lds_bytes, hipStream_t s); \
     hipError_t launch_render_tail_##SFX(const RenderParams &p, bool counters, uint32_t grid, size_t lds_bytes, hipStream_t s); \
     hipError_t launch_tail_accumulate_##SFX(const RenderParams &p, hipStream_t s);                               \
     hipError_t launch_tail_sort_##SFX(const RenderParams &p, uint32_t grid, uint32_t mode, const float *lo3, const float *inv3, hipStream_t s); \
-    hipError_t launch_wf_raygen_##SFX(const WfParams &p, hipStream_t s);                                         \
-    hipError_t launch_wf_trace_##SFX(const WfParams &p, bool lds_scene, bool counters, uint32_t grid, size_t lds_bytes, \
-                                     hipStream_t s);                                                             \
-    hipError_t launch_wf_shade_##SFX(const WfParams &p, bool lds_scene, uint32_t grid, hipStream_t s);           \
-    hipError_t launch_wf_accumulate_##SFX(const WfParams &p, hipStream_t s);                                     \
     hipError_t launch_trace_##SFX(const TraceParams &p, bool lds_scene, bool any_hit, size_t lds_bytes,          \
                                   hipStream_t s);                                                                \
     hipError_t launch_halton_##SFX(const uint32_t *i, const uint32_t *d, uint32_t n, float *out, hipStream_t s); \
@@ -312,3 +258,7 @@ TRG_DECL_LAUNCHERS(fast)
 TRG_DECL_LAUNCHERS(strict)
 
 }  // namespace trg
+
+#if TRG_EXPERIMENTS
+#include "../../experiments/trg_exp.h"
+#endif

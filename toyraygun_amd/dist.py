@@ -57,19 +57,25 @@ def unpack_bands_reference(compact, height, world):
     return compact[src]
 
 
-def gather_bands(full, world, rank, group=None, root=None):
-    """All-gather the row bands of `full` ([h, w, 4] float32, this rank's band already filled) in place.
-    root = r: gather to rank r only (the other ranks keep just their own band) -- one eighth of the traffic when only
-    one rank presents or stores the frame; also selected by TRG_GATHER=root (rank 0)."""
+def gather_bands(full, world, rank, group=None, root=None, mode=None):
+    """Exchange the row bands of `full` ([h, w, 4] float32, this rank's band already filled) in place.
+    root = r: GATHER to rank r only (the other ranks keep just their own band) -- north_star's exchange: the root ingests world - 1 bands over
+    world - 1 independent xGMI links, one eighth of the all-gather's traffic at world = 8; also selected by TRG_GATHER=root (rank 0).
+    root = None: all-gather, every rank ends with the whole frame.  mode = "all" / "root" states the choice outright (the environment
+    variable is then not consulted)."""
     if world == 1 and not os.environ.get("TRG_FORCE_GATHER"):
         return full
-    if root is None and os.environ.get("TRG_GATHER") == "root":
+    if mode == "all":
+        root = None
+    elif mode == "root":
+        root = 0 if root is None else root
+    elif root is None and os.environ.get("TRG_GATHER") == "root":
         root = 0
     if full.is_cuda and dist.get_backend(group) == "gloo":
         # no RCCL in this process group (a machine without it, or the one-GPU rehearsal of bench.py's launched path, where the ranks share a
         # device and NCCL refuses a communicator): the bands go through host memory -- correct, slow, never what a scaling number is taken with
         host = full.cpu()   # (waits for the current stream, which is ordered behind the render)
-        gather_bands(host, world, rank, group, root)
+        gather_bands(host, world, rank, group, root, mode)
         full.copy_(host)
         return full
     if root is not None:
@@ -120,10 +126,15 @@ def gather_bands(full, world, rank, group=None, root=None):
 class DistributedRenderer:
     """Row-band sharded renderer over an initialised process group (one rank per GPU)."""
 
-    def __init__(self, width, height, device_index, group=None, pipelined=False, depth=None, interleaved=None):
+    def __init__(self, width, height, device_index, group=None, pipelined=False, depth=None, interleaved=None, gather_mode=None):
         from . import capi
         self.capi = capi
         self.group = group
+        # what render(gather=True) does: "root" = the gather to rank 0 north_star names (default; the other ranks keep their own band),
+        # "all" = the in-place all-gather (every rank ends with the frame).  TRG_GATHER=all|root overrides the default.
+        self.gather_mode = gather_mode or os.environ.get("TRG_GATHER") or "root"
+        if self.gather_mode not in ("root", "all"):
+            raise ValueError("gather mode must be 'root' or 'all' (TRG_GATHER), not %r" % (self.gather_mode,))
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.w, self.h = width, height
@@ -176,8 +187,12 @@ class DistributedRenderer:
             self.ctx.set_option(self.capi.OPT_TIMING, 0)
 
     def render(self, frame_begin, spp, bounces, gather=True):
-        """Render this rank's band; with gather=True every rank ends up with the whole frame.
+        """Render this rank's band and exchange: gather=True -> self.gather_mode ("root": rank 0 ends with the whole frame, the others with
+        their own band; "all": every rank with the whole frame), or "root" / "all" outright; False: no exchange.
         Returns the frame tensor the result lands in (valid after synchronize())."""
+        mode = self.gather_mode if gather is True else gather
+        if mode not in (False, None, "root", "all"):
+            raise ValueError("gather must be True, False, 'root' or 'all'")
         i = self._step % len(self.frames)
         self._step += 1
         frame = self.frames[i]
@@ -198,14 +213,14 @@ class DistributedRenderer:
             self._timed.append((e0, e1))
         else:
             self._launch(frame_begin, spp, bounces)
-        gathered = gather and self._needs_gather
+        gathered = bool(mode) and self._needs_gather
         if gathered:
             if self.comm_stream is not rs:
                 done = torch.cuda.Event()
                 done.record(rs)
                 self.comm_stream.wait_event(done)
             with torch.cuda.stream(self.comm_stream):
-                gather_bands(target, self.world, self.rank, self.group)   # (a compact frame always has equal bands: in place)
+                gather_bands(target, self.world, self.rank, self.group, mode=mode)   # (a compact frame always has equal bands: in place)
                 if self.interleaved:
                     self._unpack(target, frame, self.comm_stream, rs)
                 if len(self.frames) > 1:
