@@ -14,9 +14,13 @@ if ROOT not in sys.path:
 EXP_SO = os.path.join(HERE, "lib", "libtoyraygun_hip_exp.so")
 
 
+W8_SO = os.path.join(HERE, "lib", "libtoyraygun_hip_w8.so")   # -DTRG_WIDE8=1: compressed 8-wide nodes for scenes in HBM (trg_wide8.inc.h)
+
+
 def build(force=False, verbose=False):
     from toyraygun_amd import build as b
     b.build_hip_library(EXP_SO, obj_tag="exp_", defines=("-DTRG_EXPERIMENTS=1",), force=force, verbose=verbose)
+    b.build_hip_library(W8_SO, obj_tag="w8_", defines=("-DTRG_WIDE8=1",), force=force, verbose=verbose, regen_shared=False)
     return EXP_SO
 
 

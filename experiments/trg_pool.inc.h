@@ -66,7 +66,7 @@ TRG_DEV void trace_queue(const SceneView &sc, const PoolView pv, const unsigned 
         if (busy) {
             for (;;) {
                 if (UNIFIED) {
-                    trav_step_wide<COUNT, BLOCK>(sc, tv, any, stk, cnt);
+                    trav_step_hbm<COUNT, BLOCK>(sc, tv, any, stk, cnt);
                 } else {
                     while (tv.node >= 0) trav_node_step_signed<COUNT, BLOCK>(sc, tv, stk, cnt);
                     if (tv.node == kNodeDone) break;

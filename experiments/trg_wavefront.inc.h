@@ -168,7 +168,7 @@ __global__ __launch_bounds__(trg::kBlock, 8) void wf_trace_kernel(const trg::WfP
         if (busy) {
             for (;;) {
                 if (UNIFIED) {
-                    trav_step_wide<COUNT, trg::kBlock>(sc, tv, any, stk, cnt);
+                    trav_step_hbm<COUNT, trg::kBlock>(sc, tv, any, stk, cnt);
                 } else {
                     while (tv.node >= 0) trav_node_step_signed<COUNT, trg::kBlock>(sc, tv, stk, cnt);
                     if (tv.node == kNodeDone) break;

@@ -9,6 +9,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXP_SO = os.path.join(ROOT, "experiments", "lib", "libtoyraygun_hip_exp.so")
+W8_SO = os.path.join(ROOT, "experiments", "lib", "libtoyraygun_hip_w8.so")
 
 CHILD = r"""
 import sys
@@ -40,6 +41,47 @@ for force_global in (0, 1):          # the scene staged in LDS, and traversed fr
 c.close()
 print("ok", kernel)
 """
+
+
+CHILD_W8 = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+from oracle import pyoracle as O
+from toyraygun_amd import capi
+w, h, spp, bnc = 80, 48, 3, 3
+for name, scene in (("cornell box kept in HBM", O.OracleScene.cornell_box()), ("lattice of 2,628 triangles", O.OracleScene.cornell_lattice(6))):
+    b = scene.buffers()
+    off = O.pixel_offsets(w, h)
+    O.set_trig_mode(O.TRIG_PORTABLE)
+    ref, st = O.render(scene, w, h, spp, bnc, offsets=off)
+    c = capi.Context(w, h)
+    c.load_scene(b["positions"], b["normals"], b["colors"], b["indices"], b["material_ids"])
+    c.set_uniforms(O.uniforms_bytes(O.make_uniforms(w, h)))
+    c.set_pixel_offsets(off)
+    c.set_option(capi.OPT_STRICT, 1)
+    c.set_option(capi.OPT_FORCE_GLOBAL, 1)
+    for regen in (0, 1):             # lock step and path regeneration, both through trav_step_wide8
+        c.set_option(capi.OPT_REGEN, regen)
+        c.reset_stats()
+        c.render(0, spp, bnc)
+        img, gs = c.read_accum(), c.stats()
+        assert gs.scene_in_lds == 0 and gs.last_regen == regen
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), "8-wide traversal differs from the oracle: %%s, regen %%d" %% (name, regen)
+        assert gs.rays == st.rays, (gs.rays, st.rays)
+    c.close()
+print("ok w8")
+"""
+
+
+@pytest.mark.gpu
+def test_compressed_8wide_nodes_are_bit_exact():
+    """GPU: the compressed 8-wide tree (experiments/trg_wide8.inc.h; profiles/r05/c4_wide8_experiment.md: built, correct, slower) -- the Cornell
+    box kept in HBM and a 2,628-triangle lattice, strict build, lock step and path regeneration: the oracle's image and ray counts bit for bit."""
+    assert os.path.exists(W8_SO), "experiments/lib/libtoyraygun_hip_w8.so is missing: python experiments/build.py"
+    env = dict(os.environ, TRG_HIP_SO=W8_SO)
+    p = subprocess.run([sys.executable, "-c", CHILD_W8 % {"root": ROOT}], cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0 and "ok w8" in p.stdout, (p.stdout[-1500:], p.stderr[-1500:])
 
 
 def test_experimental_library_is_built_and_complete():

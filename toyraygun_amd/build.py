@@ -44,7 +44,7 @@ def _glob(d, exts):
     return sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith(exts)) if os.path.isdir(d) else []
 
 
-def build_hip_library(hip_so, obj_tag="", defines=(), force=False, verbose=False):
+def build_hip_library(hip_so, obj_tag="", defines=(), force=False, verbose=False, regen_shared=True):
     """Compile the HIP side (kernels in two builds x two translation units, the device builders, the C ABI, the host BVH builder, the device
     group) and link it into `hip_so`.  `defines` / `obj_tag`: a variant of the same sources (experiments/build.py: -DTRG_EXPERIMENTS=1)."""
     os.makedirs(os.path.dirname(hip_so), exist_ok=True)
@@ -79,7 +79,7 @@ def build_hip_library(hip_so, obj_tag="", defines=(), force=False, verbose=False
         ("trg_group.o", os.path.join(CSRC, "trg_group.cpp"), ["-x", "hip", "--offload-arch=" + ARCH, "-I/opt/rocm/include"]),
     ]
     # (the regeneration units do not contain the experimental schedules: the variant shares those objects with the product build)
-    shared_with_product = ("trg_kernels_fast_regen.o", "trg_kernels_strict_regen.o", "trg_build.o", "bvh_build.o", "trg_group.o")
+    shared_with_product = (("trg_kernels_fast_regen.o", "trg_kernels_strict_regen.o") if regen_shared else ()) + ("trg_build.o", "bvh_build.o", "trg_group.o")
     for name, src, extra in units:
         o = os.path.join(OBJ, name if (not obj_tag or name in shared_with_product) else obj_tag + name)
         if force or _newer(o, [src] + headers):

@@ -2,6 +2,7 @@
 // gfx950 traversal kernel reads with four 16-byte loads (see bvh_build.h).
 #include "bvh_build.h"
 #include "q4node.h"
+#include "q8node.h"
 
 #include <algorithm>
 #include <cmath>
@@ -177,7 +178,7 @@ uint32_t pair_quads(const float *pos, const uint32_t *idx, const uint32_t *masks
     return quads;
 }
 
-void build_bvh(const float *pos, const uint32_t *idx, const uint32_t *masks, uint32_t ntris, Bvh &out) {
+void build_bvh(const float *pos, const uint32_t *idx, const uint32_t *masks, uint32_t ntris, Bvh &out, bool want_wide8) {
     if (const char *e = getenv("TRG_BVH_MAXLEAF")) kMaxLeaf = (uint32_t)std::min(7, std::max(1, atoi(e)));
     if (const char *e = getenv("TRG_BVH_TRAVCOST")) kTravCost = (float)atof(e);
     kQuads = quads_enabled();   // (read per build: the tests switch it)
@@ -402,6 +403,134 @@ void build_bvh(const float *pos, const uint32_t *idx, const uint32_t *masks, uin
 
     out.nodes4q.assign((size_t)out.n_nodes4 * 16, 0u);
     for (size_t i = 0; i < wide.size(); ++i) quantize_node4(&out.nodes4[i * 8].x, &out.nodes4q[i * 16]);
+
+    // ---- 8-wide compressed collapse (q8node.h; TRG_WIDE8 builds) ----
+    out.nodes8.clear(); out.rec8.clear(); out.rec8_flags.clear(); out.n_nodes8 = 0; out.depth8 = 0; out.wide8_ok = false;
+    if (want_wide8) {
+        struct Item { int32_t bn; uint32_t first, count; Box box; bool leaf; };   // a child: an inner build node, or a leaf over prims [first, first + count)
+        auto item_of = [&](int32_t bn) { const BuildNode &n = B.nodes[bn]; return Item{ bn, n.first, n.count, n.box, n.leaf }; };
+        struct QNode { std::vector<Item> ch; uint32_t depth; };
+        std::vector<QNode> queue;   // breadth first: index = node index
+        bool ok = true;
+        {
+            QNode r; r.depth = 1;
+            if (synth_root) {
+                if (ntris == 0) {
+                    Box z; const float o[3] = { 0, 0, 0 }; z.grow(o);
+                    r.ch.push_back(Item{ -1, 0u, 0u, z, true });     // (count 0: the never-matching record)
+                } else {
+                    const uint32_t n0 = (n_prims + 1) / 2, n1 = n_prims - n0;
+                    r.ch.push_back(Item{ -1, 0u, n0, B.nodes[root].box, true });
+                    if (n1) r.ch.push_back(Item{ -1, n0, n1, B.nodes[root].box, true });
+                }
+            } else {
+                r.ch.push_back(item_of(B.nodes[root].child[0])); r.ch.push_back(item_of(B.nodes[root].child[1]));
+            }
+            queue.push_back(r);
+        }
+        for (size_t qi = 0; qi < queue.size() && ok; ++qi) {
+            // open the inner child with the largest surface area until there are eight children (or nothing left to open)
+            std::vector<Item> ch = queue[qi].ch;
+            while (ch.size() < 8) {
+                int best = -1; float best_area = -1.f;
+                for (size_t k = 0; k < ch.size(); ++k)
+                    if (!ch[k].leaf) { const float a = ch[k].box.half_area(); if (a > best_area) { best_area = a; best = (int)k; } }
+                if (best < 0) break;
+                const int32_t open = ch[best].bn;
+                ch[best] = item_of(B.nodes[open].child[0]);
+                ch.push_back(item_of(B.nodes[open].child[1]));
+            }
+            // slots: child c goes where dot(centre(c) - centre(node), (+-1, +-1, +-1)_slot) is largest, greedily over all (child, free slot) pairs
+            Box nb;
+            for (const Item &c : ch) nb.grow(c.box);
+            float cn[3];
+            for (int a = 0; a < 3; ++a) cn[a] = 0.5f * (nb.lo[a] + nb.hi[a]);
+            int slot_of[8], child_in[8];
+            for (int k = 0; k < 8; ++k) { slot_of[k] = -1; child_in[k] = -1; }
+            for (size_t round = 0; round < ch.size(); ++round) {
+                int bc = -1, bs = -1; float bv = -kInf;
+                for (size_t c = 0; c < ch.size(); ++c) {
+                    if (slot_of[c] >= 0) continue;
+                    for (int sl = 0; sl < 8; ++sl) {
+                        if (child_in[sl] >= 0) continue;
+                        float v = 0.f;
+                        for (int a = 0; a < 3; ++a) v += (0.5f * (ch[c].box.lo[a] + ch[c].box.hi[a]) - cn[a]) * (((sl >> a) & 1) ? 1.f : -1.f);
+                        if (v > bv) { bv = v; bc = (int)c; bs = sl; }
+                    }
+                }
+                slot_of[bc] = bs; child_in[bs] = bc;
+            }
+            // the node: inner children in slot order get consecutive indices, leaves in slot order consecutive record pairs
+            uint32_t w[kQ8NodeDwords] = { 0 };
+            uint32_t imask = 0, lmask = 0;
+            const uint32_t child_base = (uint32_t)queue.size(), rec_base = (uint32_t)out.rec8.size();
+            Box pb[8]; bool used[8];
+            for (int sl = 0; sl < 8; ++sl) {
+                used[sl] = child_in[sl] >= 0;
+                if (!used[sl]) continue;
+                const Item &c = ch[child_in[sl]];
+                pb[sl] = padded(c.box);
+                if (!c.leaf) {
+                    imask |= 1u << sl;
+                    QNode q; q.depth = queue[qi].depth + 1;
+                    q.ch.push_back(item_of(B.nodes[c.bn].child[0])); q.ch.push_back(item_of(B.nodes[c.bn].child[1]));
+                    queue.push_back(q);
+                } else {
+                    lmask |= 1u << sl;
+                    const uint32_t r0 = c.count ? rec_first[c.first] : 0u, nrec = c.count ? rec_first[c.first + c.count] - r0 : 1u;
+                    if (nrec > 2u) { ok = false; break; }            // (TRG_BVH_MAXLEAF > 2: this layout gives a leaf two record entries)
+                    const bool q = c.count == 1u && B.prims[c.first].id2 != ~0u;
+                    out.rec8.push_back(r0); out.rec8_flags.push_back((uint8_t)((nrec == 2u ? kRec8HasNext : 0u) | (q ? kRec8Quad : 0u)));
+                    out.rec8.push_back(nrec == 2u ? r0 + 1u : ~0u); out.rec8_flags.push_back(0);
+                }
+            }
+            if (!ok) break;
+            out.depth8 = std::max(out.depth8, queue[qi].depth);
+            // quantise against the union of the (padded) child boxes; per axis a power-of-two scale >= extent / 255
+            uint32_t qlo[3][2] = { { 0, 0 }, { 0, 0 }, { 0, 0 } }, qhi[3][2] = { { 0, 0 }, { 0, 0 }, { 0, 0 } };
+            float origin[3], scale[3];
+            for (int a = 0; a < 3; ++a) {
+                float mn = kInf, mx = -kInf;
+                for (int sl = 0; sl < 8; ++sl) if (used[sl]) { mn = std::min(mn, pb[sl].lo[a]); mx = std::max(mx, pb[sl].hi[a]); }
+                if (!(mn <= mx)) { mn = 0.f; mx = 0.f; }
+                const double ext = (double)mx - (double)mn;
+                int e = -100;
+                if (ext > 0.0) { (void)std::frexp(ext / 255.0, &e); if (e < -100) e = -100; }
+                for (;;) {
+                    const double sc = std::ldexp(1.0, e);
+                    bool fits = true;
+                    uint32_t pl[2] = { 0, 0 }, ph[2] = { 0, 0 };
+                    for (int sl = 0; sl < 8; ++sl) {
+                        uint32_t l = 255u, h = 0u;   // an empty slot: the inverted box, never entered
+                        if (used[sl]) {
+                            const double dl = std::floor(((double)pb[sl].lo[a] - (double)mn) / sc), dh = std::ceil(((double)pb[sl].hi[a] - (double)mn) / sc);
+                            if (dl < 0.0 || dh > 255.0 || !(dl <= 255.0) || !(dh >= 0.0)) { fits = false; break; }
+                            l = (uint32_t)dl; h = (uint32_t)dh;
+                        }
+                        pl[sl >> 2] |= l << (8 * (sl & 3)); ph[sl >> 2] |= h << (8 * (sl & 3));
+                    }
+                    if (fits || e >= 127) {
+                        if (!fits) for (int sl = 0; sl < 8; ++sl) { pl[sl >> 2] &= ~(255u << (8 * (sl & 3))); ph[sl >> 2] &= ~(255u << (8 * (sl & 3)));
+                                                                     pl[sl >> 2] |= (used[sl] ? 0u : 255u) << (8 * (sl & 3)); ph[sl >> 2] |= (used[sl] ? 255u : 0u) << (8 * (sl & 3)); }
+                        qlo[a][0] = pl[0]; qlo[a][1] = pl[1]; qhi[a][0] = ph[0]; qhi[a][1] = ph[1];
+                        origin[a] = mn; scale[a] = (float)sc;
+                        break;
+                    }
+                    ++e;
+                }
+            }
+            auto fbits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+            w[0] = fbits(origin[0]); w[1] = fbits(origin[1]); w[2] = fbits(origin[2]); w[3] = fbits(scale[0]);
+            w[4] = child_base; w[5] = rec_base; w[6] = imask | (lmask << 8);
+            w[7] = (fbits(scale[1]) >> 16) | (fbits(scale[2]) & 0xFFFF0000u);
+            w[8] = qlo[0][0]; w[9] = qlo[0][1]; w[10] = qlo[1][0]; w[11] = qlo[1][1];
+            w[12] = qlo[2][0]; w[13] = qlo[2][1]; w[14] = qhi[0][0]; w[15] = qhi[0][1];
+            w[16] = qhi[1][0]; w[17] = qhi[1][1]; w[18] = qhi[2][0]; w[19] = qhi[2][1];
+            out.nodes8.insert(out.nodes8.end(), w, w + kQ8NodeDwords);
+        }
+        if (ok) { out.n_nodes8 = (uint32_t)queue.size(); out.wide8_ok = true; }
+        else { out.nodes8.clear(); out.rec8.clear(); out.rec8_flags.clear(); out.depth8 = 0; }
+    }
 
     // SAH cost (reporting only)
     double cost = 0.0;

@@ -46,6 +46,13 @@ struct Bvh {
     uint32_t n_nodes = 0, n_leaves = 0, depth = 0, max_leaf = 0;
     uint32_t n_nodes4 = 0, depth4 = 0;
     double sah_cost = 0.0;
+    // ---- 8-wide compressed nodes (round-5 experiment, TRG_WIDE8 builds; q8node.h): the same BVH2 collapsed to up to eight children per node ----
+    std::vector<uint32_t> nodes8;   // 20 dwords (80 bytes) per node, breadth first: the inner children of a node have consecutive indices
+    std::vector<uint32_t> rec8;     // the leaf records in the order the 8-wide tree addresses them: rec8[i] = index into `tris` (record), or ~0u = a
+                                    // never-hit padding record.  Every leaf owns TWO consecutive entries (one or two triangles, or the X and Y of a quad).
+    std::vector<uint8_t> rec8_flags;  // per entry of rec8: bit 0 = this leaf's second entry holds a triangle to test too, bit 1 = the X of a quad
+    uint32_t n_nodes8 = 0, depth8 = 0;
+    bool wide8_ok = false;          // false: not built, or a leaf of more than two records (TRG_BVH_MAXLEAF > 2)
 };
 
 // the pairing rule by itself (the device builders use it too): are triangles k and k + 1 the two halves of a parallelogram?  x / y = which is X, which Y
@@ -56,6 +63,6 @@ uint32_t pair_quads(const float *positions3, const uint32_t *indices, const uint
 
 // positions3: nverts*3 floats; indices: ntris*3; masks: ntris (the reference's materialID buffer,
 // MetalRenderer.mm:276).  Deterministic for a given input.
-void build_bvh(const float *positions3, const uint32_t *indices, const uint32_t *masks, uint32_t ntris, Bvh &out);
+void build_bvh(const float *positions3, const uint32_t *indices, const uint32_t *masks, uint32_t ntris, Bvh &out, bool want_wide8 = false);
 
 }  // namespace trg

@@ -15,6 +15,7 @@
 #include "../../include/trg.h"
 #include "bvh_build.h"
 #include "q4node.h"
+#include "q8node.h"
 #include "trg_build.h"
 #include "trg_internal.h"
 #include "trg_kernels.h"
@@ -113,7 +114,7 @@ static bool plan_scene_layout(uint64_t n_nodes, uint32_t node_bytes, uint64_t nt
     const uint64_t off_htab = align16_64(off_meta + nt_rec * 2ull);
     const uint64_t stage_end = align16_64(off_htab + (with_htab ? kHtabBytes : 0u));
     const uint64_t off_nodes4 = (stage_end + 127ull) & ~127ull;  // 64-byte nodes, two per 128-byte line
-    const uint64_t off_fat = (off_nodes4 + n_nodes4 * kQ4NodeBytes + 127ull) & ~127ull;   // one record per 128-byte line
+    const uint64_t off_fat = (off_nodes4 + n_nodes4 * (TRG_WIDE8 ? kQ8NodeBytes : kQ4NodeBytes) + 127ull) & ~127ull;   // one record per 128-byte line
     const uint64_t off_fat_planes = off_fat + n_fat * kFatRecBytes;                        // the shipped build's leaf records (planes), one per line as well
     const uint64_t off_tris_alt = off_fat_planes + n_fat * kFatRecBytes;                   // the plane records of an LDS-sized scene (16-byte aligned)
     total = off_tris_alt + nt_rec * 48ull + 128ull;
@@ -224,7 +225,9 @@ static bool plan_lds_as(const trg_ctx *c, LdsPlan &p, bool lds_scene, bool pool,
         levels = c->bvh_depth + 2;
         p.klds = levels;
     } else {
-        levels = 3 * c->bvh_depth4 + 3;  // the sentinel at level 0; 4-wide: up to three pending entries per level
+        // the sentinel at level 0; 4-wide: up to three pending entries per level.  (TRG_WIDE8: one two-word node group per level of the 8-wide tree,
+        // behind two sentinel levels: LdsStackT::first)
+        levels = TRG_WIDE8 ? 2 * c->bvh_depth4 + 4 : 3 * c->bvh_depth4 + 3;
         p.klds = std::min(levels, (uint32_t)c->opt_stack_levels);
     }
     p.overflow_levels = levels - p.klds;
@@ -560,7 +563,8 @@ int host_scene_build(trg_ctx *c, const float *pos, const float *nrm, const float
     if (!hs) return fail(c, TRG_ERR_NOMEM, "trg_load_scene: out of host memory");
     const auto host_t0 = std::chrono::steady_clock::now();
     Bvh bvh;
-    build_bvh(pos, idx, mat, n_tris, bvh);
+    build_bvh(pos, idx, mat, n_tris, bvh, TRG_WIDE8 != 0);
+    if (TRG_WIDE8 && !bvh.wide8_ok) { delete hs; return fail(c, TRG_ERR_RANGE, "trg_load_scene: the 8-wide layout of this build needs leaves of at most two records (TRG_BVH_MAXLEAF <= 2)"); }
     hs->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
     if (n_tris) {
         for (int a = 0; a < 3; ++a) { hs->lo[a] = INFINITY; hs->hi[a] = -INFINITY; }
@@ -586,9 +590,10 @@ int host_scene_build(trg_ctx *c, const float *pos, const float *nrm, const float
     sc.n_tris_rec = lds_candidate ? nt_rec : 0u;
     for (int a = 0; a < 3; ++a) sc.center[a] = n_tris ? 0.5f * (hs->lo[a] + hs->hi[a]) : 0.0f;
     const uint32_t node_bytes = kLdsNodeBytes;
-    sc.n_nodes4 = bvh.n_nodes4;
+    sc.n_nodes4 = TRG_WIDE8 ? bvh.n_nodes8 : bvh.n_nodes4;
+    const uint32_t n_fat = TRG_WIDE8 ? (uint32_t)bvh.rec8.size() : nt_rec;   // (TRG_WIDE8: two entries per leaf, in the order the 8-wide tree addresses them)
     uint64_t total = 0;
-    if (!plan_scene_layout(sc.n_nodes, node_bytes, lds_candidate ? nt_rec : 0u, lds_candidate ? attr_tris : 0u, lds_candidate, sc.n_nodes4, nt_rec, sc, total)) {
+    if (!plan_scene_layout(sc.n_nodes, node_bytes, lds_candidate ? nt_rec : 0u, lds_candidate ? attr_tris : 0u, lds_candidate, sc.n_nodes4, n_fat, sc, total)) {
         delete hs;
         return fail(c, TRG_ERR_RANGE, "trg_load_scene: scene needs %llu B on the device (limit 4 GiB)", (unsigned long long)total);
     }
@@ -637,11 +642,32 @@ int host_scene_build(trg_ctx *c, const float *pos, const float *nrm, const float
             memcpy(&host[sc.off_mats], mat, (size_t)n_tris * 4);
         }
     }
+#if TRG_WIDE8
+    for (uint32_t e = 0; e < n_fat; ++e) {
+        const uint32_t i = bvh.rec8[e], flags = bvh.rec8_flags[e];
+        unsigned char *mt = &host[sc.off_fat + (size_t)e * kFatRecBytes], *pl = &host[sc.off_fat_planes + (size_t)e * kFatRecBytes];
+        if (i == ~0u) {   // padding behind a one-triangle leaf: mask 0 matches no ray (never addressed anyway: the leaf's flags say so)
+            const F4 none[3] = { F4{ 0.f, 0.f, 0.f, 0.f }, F4{ 1.f, 0.f, 0.f, 0.f }, F4{ 0.f, 1.f, 0.f, 0.f } };
+            fill_fat_record(mt, none, nrm, col, 0u);
+            fill_fat_record_planes(pl, none, nrm, col, 0u, sc.center, nullptr);
+            continue;
+        }
+        fill_fat_record(mt, &bvh.tris[(size_t)i * 3], nrm, col, n_tris);
+        fill_fat_record_planes(pl, &bvh.tris[(size_t)i * 3], nrm, col, n_tris, sc.center, (flags & kRec8Quad) ? &bvh.tris[(size_t)(i + 1) * 3] : nullptr);
+        // the leaf's flags: float 11 (row 2 .w, unused by Moeller-Trumbore) of the strict build's record; bits 28, 29 of the index word of the shipped one
+        memcpy(mt + 44, &flags, 4);
+        uint32_t iw;
+        memcpy(&iw, pl + 48, 4);
+        iw |= flags << 28;
+        memcpy(pl + 48, &iw, 4);
+    }
+#else
     for (uint32_t i = 0; i < nt_rec; ++i) {
         fill_fat_record(&host[sc.off_fat + (size_t)i * kFatRecBytes], &bvh.tris[(size_t)i * 3], nrm, col, n_tris);
         fill_fat_record_planes(&host[sc.off_fat_planes + (size_t)i * kFatRecBytes], &bvh.tris[(size_t)i * 3], nrm, col, n_tris, sc.center,
                                (i < bvh.quad.size() && bvh.quad[i]) ? &bvh.tris[(size_t)(i + 1) * 3] : nullptr);
     }
+#endif
     if (lds_candidate) {  // Halton group tables (trg_kernels.h kHtab)
         float *T = reinterpret_cast<float *>(&host[sc.off_htab]);
         for (const HtabSpec &h : kHtab)
@@ -652,11 +678,15 @@ int host_scene_build(trg_ctx *c, const float *pos, const float *nrm, const float
                 T[h.offset + r] = (float)v;
             }
     }
+#if TRG_WIDE8
+    if (sc.n_nodes4) memcpy(&host[sc.off_nodes4], bvh.nodes8.data(), (size_t)sc.n_nodes4 * kQ8NodeBytes);
+#else
     if (sc.n_nodes4) memcpy(&host[sc.off_nodes4], bvh.nodes4q.data(), (size_t)sc.n_nodes4 * kQ4NodeBytes);
+#endif
 
     hs->sc = sc;
     hs->bvh_nodes = bvh.n_nodes; hs->bvh_depth = bvh.depth; hs->bvh_leaves = bvh.n_leaves;
-    hs->bvh_nodes4 = bvh.n_nodes4; hs->bvh_depth4 = bvh.depth4;
+    hs->bvh_nodes4 = TRG_WIDE8 ? bvh.n_nodes8 : bvh.n_nodes4; hs->bvh_depth4 = TRG_WIDE8 ? bvh.depth8 : bvh.depth4;
     *out = hs;
     return TRG_OK;
 }
@@ -689,7 +719,7 @@ extern "C" {
 int trg_load_scene(trg_ctx *c, const float *pos, const float *nrm, const float *col, const uint32_t *idx,
                    const uint32_t *mat, uint32_t n_verts, uint32_t n_tris) {
     if (!c) return TRG_ERR_INVALID;
-    if (c->opt_gpu_build && n_tris >= 2) {
+    if (c->opt_gpu_build && n_tris >= 2 && !TRG_WIDE8) {   // (a TRG_WIDE8 build has the host builder's 8-wide layout only)
         if (int rc = check_scene_args(c, pos, nrm, col, idx, mat, n_verts, n_tris)) return rc;
         HIPCHK(c, hipSetDevice(c->device));
         if (c->tex_mem) {   // textures belong to the scene they were loaded for

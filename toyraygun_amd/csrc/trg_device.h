@@ -576,7 +576,8 @@ constexpr bool kTriPlanes = !TRG_STRICT && TRG_TRI_PLANES;
 constexpr bool kRecPlanes = !TRG_STRICT && TRG_TRI_PLANES_HBM;
 
 constexpr bool kRecMetaFirst = kRecPlanes && TRG_REC_META_FIRST;   // plane records: index / mask = floats 12, 13 (else 30, 31)
-TRG_DEV int fat_prim(const v4f *recs, uint32_t r) { return __float_as_int(kRecMetaFirst ? recs[(size_t)r * kRecV4 + 3].x : kRecPlanes ? recs[(size_t)r * kRecV4 + 7].z : recs[(size_t)r * kRecV4].w); }
+// (TRG_WIDE8: the index word of a record carries two flag bits, 28 and 29 -- trav_step_wide8)
+TRG_DEV int fat_prim(const v4f *recs, uint32_t r) { return (TRG_WIDE8 ? 0x0FFFFFFF : -1) & __float_as_int(kRecMetaFirst ? recs[(size_t)r * kRecV4 + 3].x : kRecPlanes ? recs[(size_t)r * kRecV4 + 7].z : recs[(size_t)r * kRecV4].w); }
 TRG_DEV uint32_t fat_mask(const v4f *recs, uint32_t r) { return (uint32_t)__float_as_int(kRecMetaFirst ? recs[(size_t)r * kRecV4 + 3].y : kRecPlanes ? recs[(size_t)r * kRecV4 + 7].w : recs[(size_t)r * kRecV4 + 1].w); }
 
 // Per-lane traversal stack, laid out [level][thread] so lane i always hits LDS bank i%32 (no conflicts).
@@ -608,7 +609,9 @@ struct LdsStackT {
         overflow = ovf; gcol = blockIdx.x * BLOCK + threadIdx.x; gstride = gridDim.x * BLOCK; lim = col0 + klds_ * (uint32_t)(BLOCK * 4);
         *(lds_int_t *)(uintptr_t)lds = kNodeDone;   // the sentinel at level 0
     }
-    TRG_DEV int first() const { return (int)lds + BLOCK * 4; }
+    // (TRG_WIDE8: the stack of an HBM traversal holds PAIRS of words -- a node group -- so the empty stack stands two levels up and the pop
+    //  that would underflow reads the sentinel at level 0 and whatever is at level 1)
+    TRG_DEV int first() const { return (int)lds + BLOCK * 4 * ((TRG_WIDE8 && OVERFLOW) ? 2 : 1); }
     TRG_DEV void push(int sp, int v) {
         if (!OVERFLOW || (uint32_t)sp < lim) *(lds_int_t *)(uintptr_t)(uint32_t)sp = v;
         else overflow[(size_t)(((uint32_t)sp - lim) / (uint32_t)(BLOCK * 4) * gstride + gcol)] = v;
@@ -635,6 +638,13 @@ struct Trav {
     Hit hit;           // prim, u, v of the accepted hit; hit.t is filled in by trav_hit() only (it is `best`)
     bool found;
     int node, sp;
+#if TRG_WIDE8
+    // compressed 8-wide tree (q8node.h): the node GROUP in hand -- the inner children of one node that were hit and are still to be entered:
+    // g_base = index of that node's first inner child, g_bits = hit mask in PRIORITY order (bit p <-> slot p ^ octinv; the highest goes first) |
+    // the node's inner-slot mask << 8 -- and its leaf group: t_base = first leaf record of the node, t_bits = hit leaf slots | leaf-slot mask << 8 |
+    // (bit 16: the SECOND record of the lowest pending leaf is next)
+    uint32_t g_base, g_bits, t_base, t_bits;
+#endif
     int sx, sz;      // sign-ordered LDS nodes: LDS address of this ray's [X | Y] block and of its Z block in node 0 (added to a node's byte offset)
 };
 
@@ -663,6 +673,12 @@ TRG_DEV void trav_begin(const SceneView &sc, Trav &tv, V3 o, V3 d, float tmax, u
     tv.hit.t = -1.0f; tv.hit.prim = -1; tv.hit.u = 0.0f; tv.hit.v = 0.0f;
     tv.found = false;
     tv.node = 0; tv.sp = sp0;  // sp0 = stk.first(): the empty stack
+#if TRG_WIDE8
+    if (!rel) {   // (HBM traversal) the root as the one inner child, in slot 0, of a virtual parent: popped by the first step
+        const uint32_t octinv = ((__float_as_uint(dx) >> 31) | ((__float_as_uint(dy) >> 31) << 1) | ((__float_as_uint(dz) >> 31) << 2)) ^ 7u;
+        tv.g_base = 0u; tv.g_bits = (1u << octinv) | (1u << 8); tv.t_base = 0u; tv.t_bits = 0u;
+    }
+#endif
     // sign-ordered LDS nodes: LDS address of the slab copy to read per axis, for node 0 (node_base = LDS address of the node array; layout:
     // trav_node_step_signed): the [X | Y] block of the sign pair at +0 / +32 / +64 / +96, Z+ Z- at +128 / +160
     tv.sx = (int)(node_base + (((__float_as_uint(dx) >> 31) | ((__float_as_uint(dy) >> 31) << 1)) << 5));
@@ -963,6 +979,20 @@ TRG_DEV void trav_step_wide(const SceneView &sc, Trav &tv, bool any, STK stk, Co
     }
 }
 
+#if TRG_WIDE8
+#include "../../experiments/trg_wide8.inc.h"   // trav_step_wide8: the compressed 8-wide tree (measured slower: profiles/r05/c4_wide8_experiment.md)
+#endif  // TRG_WIDE8
+// the unit of work of an HBM traversal in this build
+template <bool COUNT, int BLOCK, typename STK>
+TRG_DEV void trav_step_hbm(const SceneView &sc, Trav &tv, bool any, STK stk, Counters &cnt) {
+#if TRG_WIDE8
+    static_assert(!kRecPlanes || kRecMetaFirst, "TRG_WIDE8 reads a plane record's index word and mask from floats 12, 13");
+    trav_step_wide8<COUNT, BLOCK>(sc, tv, any, stk, cnt);
+#else
+    trav_step_wide<COUNT, BLOCK>(sc, tv, any, stk, cnt);
+#endif
+}
+
 // Traversal schedules.  LDS-resident scenes: while-while on the sign-ordered BVH2 nodes.  HBM-resident scenes (UNIFIED): the unified step on
 // the quantised 4-wide tree -- one unit of work per lane per iteration, a node or one triangle, off one group of loads.  (Measured and
 // dropped, NOTEBOOK.md: a plain BVH2, a sign-ordered 4-wide float tree, an octant-threaded stackless walk and half-precision nodes in LDS;
@@ -985,7 +1015,7 @@ TRG_DEV bool traverse(const SceneView &sc, V3 o, V3 d, float tmax_ray, uint32_t 
     Trav tv;
     trav_begin(sc, tv, o, d, tmax_ray, rmask, stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED);
     if (UNIFIED) {
-        while (tv.node != kNodeDone) trav_step_wide<COUNT, BLOCK>(sc, tv, ANY, stk, cnt);
+        while (tv.node != kNodeDone) trav_step_hbm<COUNT, BLOCK>(sc, tv, ANY, stk, cnt);
     } else {
         for (;;) {
             while (tv.node >= 0) trav_node_step_signed<COUNT, BLOCK>(sc, tv, stk, cnt);
@@ -1015,7 +1045,7 @@ TRG_DEV void traverse_pair(const SceneView &sc, V3 org, bool has_shadow, V3 sdir
     while (phase < 2) {
         const bool any = phase == 0;
         if (UNIFIED) {
-            trav_step_wide<COUNT, BLOCK>(sc, tv, any, stk, cnt);
+            trav_step_hbm<COUNT, BLOCK>(sc, tv, any, stk, cnt);
         } else {
             while (tv.node >= 0) trav_node_step_signed<COUNT, BLOCK>(sc, tv, stk, cnt);
             if (tv.node != kNodeDone && trav_leaf_step<COUNT, BLOCK>(sc, tv, any, stk, cnt)) tv.node = kNodeDone;

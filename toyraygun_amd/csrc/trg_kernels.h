@@ -7,6 +7,10 @@
 
 #include "../../include/trg.h"
 
+#ifndef TRG_WIDE8
+#define TRG_WIDE8 0   // 1 (round-5 experiment; scripts/exp_build.sh <name> -DTRG_WIDE8=1): scenes in HBM are traversed through the 80-byte COMPRESSED 8-WIDE
+                      // nodes of q8node.h (host builder only) instead of the quantised 4-wide nodes
+#endif
 #ifndef TRG_EXPERIMENTS
 #define TRG_EXPERIMENTS 0   // 1: experiments/lib/libtoyraygun_hip_exp.so -- this library + the schedules kept in experiments/ (pool, wavefront)
 #endif

@@ -285,7 +285,7 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
         }
         if (in_shadow || in_next) {
             tv.rmask = (in_next && primary_ray) ? 3u : 1u;   // re-formed every step from the lane masks: not a register across the loop
-            trav_step_wide<COUNT, trg::kBlock>(sc, tv, in_shadow, stk, cnt);
+            trav_step_hbm<COUNT, trg::kBlock>(sc, tv, in_shadow, stk, cnt);
             if (tv.node == kNodeDone) {
                 if (in_shadow) {
                     occluded = tv.found;
