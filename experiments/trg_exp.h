@@ -36,6 +36,7 @@ struct WfParams {
 #define TRG_DECL_EXP_LAUNCHERS(SFX)                                                                               \
     hipError_t launch_render_pool_##SFX(const RenderParams &p, bool lds_scene, bool counters, uint32_t grid,     \
                                         size_t lds_bytes, hipStream_t s);                                        \
+    hipError_t launch_render_rtail_##SFX(const RenderParams &p, bool counters, uint32_t grid, size_t lds_bytes, hipStream_t s); \
     hipError_t launch_wf_raygen_##SFX(const WfParams &p, hipStream_t s);                                         \
     hipError_t launch_wf_trace_##SFX(const WfParams &p, bool lds_scene, bool counters, uint32_t grid, size_t lds_bytes, \
                                      hipStream_t s);                                                             \

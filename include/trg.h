@@ -126,6 +126,11 @@ enum trg_option {
     TRG_OPT_TAIL_SORT = 14,   /* tail compaction: before a tail launch reads them, the queued paths of a tile are sorted by the octant of their direction
                                  (1), or by octant + the cell of their origin in a 2^3 (2) / 4^3 (3) grid over the scene box, so that the 64 lanes of a
                                  tail wavefront start alike; 0 (default) = queue order.  Same image bit for bit (a path's arithmetic is its own) */
+    TRG_OPT_TAIL_REFILL = 15, /* tail compaction (round 5): 1 = the tail launches run ONE bounce each and their wavefronts REFILL -- a lane whose rays of
+                                 this bounce are done takes the next queue entry instead of waiting for the slowest lane of its group of 64, lanes
+                                 whose nearest-hit ray is done share a shading event -- ; 0 = lock-step groups of 64 entries, two bounces per launch.
+                                 Same image bit for bit.  EXPERIMENT (experiments/lib/libtoyraygun_hip_exp.so only; the product library refuses 1):
+                                 lanes per VALU instruction 24 -> 27 of 64, 24 % more time on C3 (profiles/r05/c3_tail_refill_experiment.md) */
     TRG_OPT_FRAME_SPLIT = 7   /* TRG_KERNEL_DIRECT only: frame lanes per workgroup. 1: a pixel's frames run one after the other in one
                                  lane; 2 or 4: that many wavefronts share a pixel's frames (same result bit for bit; fills the chip
                                  when the pixel grid alone does not -- small windows, row bands of a multi-GPU job);

@@ -1923,6 +1923,24 @@ def test_tail_compaction_is_bit_exact(capi, O, cornell, k, bounces, spp):
         with pytest.raises(capi.TrgError):
             c.set_option(capi.OPT_TAIL_SORT, 4)
         c.set_option(capi.OPT_TAIL_SORT, 0)
+        # TRG_OPT_TAIL_REFILL (round 5): one bounce per tail launch, the lanes of a wavefront take queue entries at their own pace (render_rtail_kernel):
+        # the same per-path arithmetic -- whole frame, continued average, row bands, ray counts
+        if not capi.has_experiments():    # (the refilling tail lost to the lock-step one and lives in the experiments library: the product refuses it)
+            with pytest.raises(capi.TrgError, match="experiment"):
+                c.set_option(capi.OPT_TAIL_REFILL, 1)
+        for refill in ((1, 0) if capi.has_experiments() else (0,)):
+            c.set_option(capi.OPT_TAIL_REFILL, refill)
+            c.reset_stats()
+            c.render(0, spp, bounces)
+            st = c.stats()
+            assert np.array_equal(_bits(c.read_accum()), _bits(ref)) and st.rays == rst.rays and st.shaded_hits == rst.shaded_hits, ("refill", refill)
+            c.render(0, a, bounces)
+            for r0, n in ((0, 50), (50, 63), (113, 37)):
+                c.render(a, spp - a, bounces, r0, n)
+            assert np.array_equal(_bits(c.read_accum()), _bits(ref)), ("refill bands", refill)
+        with pytest.raises(capi.TrgError):
+            c.set_option(capi.OPT_TAIL_REFILL, 2)
+        c.set_option(capi.OPT_TAIL_REFILL, -1)
         # off = the plain kernel; auto picks it for deep paths only
         c.set_option(capi.OPT_TAIL_BOUNCE, 0)
         c.render(0, spp, bounces)

@@ -16,7 +16,7 @@ HIP_SO = os.environ.get("TRG_HIP_SO") or os.path.join(LIB_DIR, "libtoyraygun_hip
 OK = 0
 ERR_INVALID, ERR_NOMEM, ERR_DEVICE, ERR_NODEV, ERR_RANGE = -22, -12, -5, -19, -34
 OPT_STRICT, OPT_COUNTERS, OPT_FORCE_GLOBAL, OPT_TIMING, OPT_KERNEL, OPT_GPU_BUILD, OPT_FRAME_SPLIT, OPT_LAUNCHES_IN_FLIGHT = 1, 2, 3, 4, 5, 6, 7, 8
-OPT_TAIL_BOUNCE, OPT_TAIL_LEVELS, OPT_REGEN, OPT_TILE_ORDER, OPT_STACK_LDS_LEVELS, OPT_TAIL_SORT = 9, 10, 11, 12, 13, 14
+OPT_TAIL_BOUNCE, OPT_TAIL_LEVELS, OPT_REGEN, OPT_TILE_ORDER, OPT_STACK_LDS_LEVELS, OPT_TAIL_SORT, OPT_TAIL_REFILL = 9, 10, 11, 12, 13, 14, 15
 KERNEL_DIRECT, KERNEL_POOL, KERNEL_WAVEFRONT, KERNEL_AUTO = 0, 1, 2, -1
 MATERIAL_DEFAULT, MATERIAL_EMISSIVE = 1, 2
 MAX_BOUNCES = 15

@@ -64,6 +64,7 @@ struct trg_ctx {
     int opt_in_flight = 1;  // launches of this context the caller keeps in flight (TRG_OPT_LAUNCHES_IN_FLIGHT)
     int opt_stack_levels = (int)TRG_STACK_LDS_LEVELS;   // TRG_OPT_STACK_LDS_LEVELS
     int opt_tail_sort = 0;     // TRG_OPT_TAIL_SORT: 0 off, 1 direction octant, 2 / 3 octant + origin cell of a 2^3 / 4^3 grid
+    int opt_tail_refill = -1;  // TRG_OPT_TAIL_REFILL: 1 = the tail launches run ONE bounce each with in-wave refill (render_rtail_kernel); -1 = the library's choice
     float scene_lo[3] = { 0.f, 0.f, 0.f }, scene_hi[3] = { 1.f, 1.f, 1.f };   // bounds of the loaded scene (tail sort: the origin grid)
     int opt_tile_order = -1;   // TRG_OPT_TILE_ORDER: -1 auto, 0 image columns centre-out, 1 / 2 / 4 / 8 XCD regions with that many column strips
     uint32_t last_xcd_cols = 0;
@@ -199,6 +200,9 @@ static void fill_fat_record_planes(unsigned char *dst, const F4 *rec48, const fl
 }
 
 constexpr uint32_t kStackLdsLevels = TRG_STACK_LDS_LEVELS;
+#ifndef TRG_TAIL_REFILL_AUTO
+#define TRG_TAIL_REFILL_AUTO 0   // what TRG_OPT_TAIL_REFILL -1 means (set once the refill tail has been measured)
+#endif
 #ifndef TRG_TAIL_AUTO_MIN_BOUNCES
 #define TRG_TAIL_AUTO_MIN_BOUNCES 4
 #endif
@@ -932,9 +936,11 @@ static int render_impl(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t 
         const uint64_t n_waves = (uint64_t)grid * kWaves, cap = 64ull * fc, band_pixels = (uint64_t)c->w * rows;
         const size_t q_bytes = (size_t)(n_waves * cap * 48u), cnt_bytes = (size_t)((n_waves * 4u + 255u) & ~255ull), rad_bytes = (size_t)(band_pixels * fc * 16u);
         // compaction levels: K, K + 2, K + 4 ... while at least two bounces are left (each level halves the live lanes again)
-        uint32_t levels[8]; int n_levels = 0;
-        for (uint32_t k = tail_k; k < bounces && n_levels < 8; k += kTailLevelStep) { levels[n_levels++] = k; if (c->opt_tail_levels == 1) break; }
-        const bool sorted = c->opt_tail_sort > 0 && cap * kWaves <= 4096u;   // the sort kernel holds a tile's keys in LDS
+        // (TRG_OPT_TAIL_REFILL: one level per bounce -- every path of a launch is at the same bounce, its lanes refill from the queue)
+        const bool refill = TRG_EXPERIMENTS && (c->opt_tail_refill > 0 || (c->opt_tail_refill < 0 && TRG_TAIL_REFILL_AUTO));
+        uint32_t levels[TRG_MAX_BOUNCES + 1]; int n_levels = 0;
+        for (uint32_t k = tail_k; k < bounces && n_levels < (int)TRG_MAX_BOUNCES; k += refill ? 1u : kTailLevelStep) { levels[n_levels++] = k; if (c->opt_tail_levels == 1 && !refill) break; }
+        const bool sorted = !refill && c->opt_tail_sort > 0 && cap * kWaves <= 4096u;   // the sort kernel holds a tile's keys in LDS
         const bool two_queues = n_levels > 1 || sorted;
         const size_t need = q_bytes * (two_queues ? 2u : 1u) + cnt_bytes * 2u + rad_bytes;
         if (need > c->wf_bytes[slot]) {
@@ -969,6 +975,10 @@ static int render_impl(trg_ctx *c, uint32_t frame_begin, uint32_t spp, uint32_t 
                 } else {
                     p.tail_queue = q[l & 1]; p.tail_count = qc[l & 1]; p.tail_queue_out = q[(l + 1) & 1]; p.tail_count_out = qc[(l + 1) & 1];
                 }
+#if TRG_EXPERIMENTS
+                if (refill) te = c->opt_strict ? launch_render_rtail_strict(p, c->opt_counters, grid, plan.total, c->stream) : launch_render_rtail_fast(p, c->opt_counters, grid, plan.total, c->stream);
+                else
+#endif
                 te = c->opt_strict ? launch_render_tail_strict(p, c->opt_counters, grid, plan.total, c->stream) : launch_render_tail_fast(p, c->opt_counters, grid, plan.total, c->stream);
             }
             if (te == hipSuccess) te = c->opt_strict ? launch_tail_accumulate_strict(p, c->stream) : launch_tail_accumulate_fast(p, c->stream);
@@ -1140,6 +1150,12 @@ int trg_set_option(trg_ctx *c, int option, int64_t value) {
     case TRG_OPT_TAIL_SORT:
         if (value < 0 || value > 3) return fail(c, TRG_ERR_INVALID, "trg_set_option: tail sort must be 0 (off), 1 (octant), 2 or 3 (octant + origin cell)");
         c->opt_tail_sort = (int)value;
+        break;
+    case TRG_OPT_TAIL_REFILL:
+        if (value < -1 || value > 1) return fail(c, TRG_ERR_INVALID, "trg_set_option: tail refill must be -1 (auto), 0 (off) or 1 (on)");
+        if (!TRG_EXPERIMENTS && value == 1) return fail(c, TRG_ERR_INVALID, "trg_set_option: the refilling tail kernel is an experiment that lost to the lock-step one and is not in this library: "
+                                                                           "experiments/lib/libtoyraygun_hip_exp.so has it (profiles/r05/c3_tail_refill_experiment.md)");
+        c->opt_tail_refill = (int)value;
         break;
     case TRG_OPT_TILE_ORDER:
         if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 17 && value != 18 && value != 20 && value != 24 && value != 32 && value != 65 && value != 66 && value != 68 && value != 72)

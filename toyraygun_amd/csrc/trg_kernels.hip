@@ -680,6 +680,13 @@ hipError_t SFX(launch_render_tail)(const RenderParams &p, bool counters, uint32_
     else hipLaunchKernelGGL((render_tail_kernel<false>), dim3(grid), dim3(kBlock), lds_bytes, s, p);
     return hipGetLastError();
 }
+#if TRG_EXPERIMENTS
+hipError_t SFX(launch_render_rtail)(const RenderParams &p, bool counters, uint32_t grid, size_t lds_bytes, hipStream_t s) {
+    if (counters) hipLaunchKernelGGL((render_rtail_kernel<true>), dim3(grid), dim3(kBlock), lds_bytes, s, p);
+    else hipLaunchKernelGGL((render_rtail_kernel<false>), dim3(grid), dim3(kBlock), lds_bytes, s, p);
+    return hipGetLastError();
+}
+#endif
 hipError_t SFX(launch_tail_sort)(const RenderParams &p, uint32_t grid, uint32_t mode, const float *lo3, const float *inv3, hipStream_t s) {
     hipLaunchKernelGGL(tail_sort_kernel, dim3(grid), dim3(256), 0, s, p, mode, lo3[0], lo3[1], lo3[2], inv3[0], inv3[1], inv3[2]);
     return hipGetLastError();

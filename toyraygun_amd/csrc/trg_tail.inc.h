@@ -202,6 +202,10 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES) void render_tail_kernel
     flush_counters(p, smem, wave, lane_id_opaque(), pc, cnt, COUNT);
 }
 
+#if TRG_EXPERIMENTS
+#include "../../experiments/trg_rtail.inc.h"   // render_rtail_kernel: tail launches with in-wave refill (TRG_OPT_TAIL_REFILL; measured slower: profiles/r05/c3_tail_refill_experiment.md)
+#endif
+
 // ---- sort a tile's queued paths by a coherence key (TRG_OPT_TAIL_SORT; round 4, DESIGN section 6: the verdict's "direction-octant sub-queues") ----
 // A tail wavefront takes 64 CONSECUTIVE entries of its segment: paths of neighbouring pixels at bounce K, whose rays point anywhere.  This
 // kernel re-orders the entries of a workgroup's four segments (one tile's paths of the chunk) by key -- the octant of the direction
