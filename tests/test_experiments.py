@@ -84,6 +84,66 @@ def test_compressed_8wide_nodes_are_bit_exact():
     assert p.returncode == 0 and "ok w8" in p.stdout, (p.stdout[-1500:], p.stderr[-1500:])
 
 
+CHILD_TAIL_FLAT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+from oracle import pyoracle as O
+from toyraygun_amd import capi
+from tests.util import image_metrics, TOL_RMSE, TOL_FRAC
+what = sys.argv[1]
+assert capi.has_experiments()
+scene = O.OracleScene.cornell_box()
+b = scene.buffers()
+w, h, spp, bnc = 120, 80, 5, 6
+off = O.pixel_offsets(w, h)
+c = capi.Context(w, h)
+c.load_scene(b["positions"], b["normals"], b["colors"], b["indices"], b["material_ids"])
+c.set_uniforms(O.uniforms_bytes(O.make_uniforms(w, h)))
+c.set_pixel_offsets(off)
+if what == "rtail":      # the refilling tail kernel: strict build, bit for bit, ray counts included
+    O.set_trig_mode(O.TRIG_PORTABLE)
+    ref, st = O.render(scene, w, h, spp, bnc, offsets=off)
+    c.set_option(capi.OPT_STRICT, 1)
+    c.set_option(capi.OPT_TAIL_BOUNCE, 2)
+    c.set_option(capi.OPT_TAIL_REFILL, 1)
+    c.reset_stats()
+    c.render(0, spp, bnc)
+    gs = c.stats()
+    assert gs.last_tail_bounce == 2
+    assert np.array_equal(c.read_accum().view(np.uint32), ref.view(np.uint32)) and gs.rays == st.rays
+else:                    # the flat primitive list (TRG_FLAT_PRIMS=1 in the environment): shipped build, the stated tolerance
+    ref, st = O.render(scene, w, h, spp, bnc, offsets=off)
+    c.render(0, spp, bnc)
+    rmse, frac_ok, _ = image_metrics(c.read_accum(), ref)
+    assert rmse <= TOL_RMSE and frac_ok >= TOL_FRAC, (rmse, frac_ok)
+    rng = np.random.default_rng(9)
+    rays = np.zeros(20000, O.RAY_DTYPE)
+    rays["origin"] = rng.uniform((-0.95, 0.05, -0.95), (0.95, 1.9, 3.0), (20000, 3)).astype(np.float32)
+    d = rng.normal(size=(20000, 3))
+    rays["direction"] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    rays["mask"] = rng.choice([1, 2, 3], 20000).astype(np.uint32)
+    rays["maxDistance"] = np.where(rng.random(20000) < 0.25, rng.uniform(0.05, 3.0, 20000), np.inf).astype(np.float32)
+    got, want = c.trace(rays), O.intersect_nearest(scene, rays)
+    assert (got["primitiveIndex"] != want["primitiveIndex"]).mean() < 3e-3
+    assert ((c.trace(rays, any_hit=True) >= 0) != (O.intersect_any(scene, rays) >= 0)).mean() < 2e-3
+c.close()
+print("ok", what)
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("what", ["rtail", "flat"])
+def test_round5_experiments(what):
+    """GPU: the tail kernel with in-wave refill (bit-exact, slower: profiles/r05/c3_tail_refill_experiment.md) and the flat primitive list for tiny
+    scenes (in tolerance; C2 slower, C3 faster: profiles/r05/c2_flat_list_experiment.md), both in the experiments library only."""
+    env = dict(os.environ, TRG_HIP_SO=EXP_SO)
+    if what == "flat":
+        env["TRG_FLAT_PRIMS"] = "1"
+    p = subprocess.run([sys.executable, "-c", CHILD_TAIL_FLAT % {"root": ROOT}, what], cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0 and ("ok " + what) in p.stdout, (what, p.stdout[-1500:], p.stderr[-1500:])
+
+
 def test_experimental_library_is_built_and_complete():
     """CPU: the experimental build exists next to the product library and exports every symbol of include/trg.h (no compute call)."""
     import ctypes

@@ -118,7 +118,9 @@ static bool plan_scene_layout(uint64_t n_nodes, uint32_t node_bytes, uint64_t nt
     const uint64_t off_fat = (off_nodes4 + n_nodes4 * (TRG_WIDE8 ? kQ8NodeBytes : kQ4NodeBytes) + 127ull) & ~127ull;   // one record per 128-byte line
     const uint64_t off_fat_planes = off_fat + n_fat * kFatRecBytes;                        // the shipped build's leaf records (planes), one per line as well
     const uint64_t off_tris_alt = off_fat_planes + n_fat * kFatRecBytes;                   // the plane records of an LDS-sized scene (16-byte aligned)
-    total = off_tris_alt + nt_rec * 48ull + 128ull;
+    const uint64_t off_flat = (off_tris_alt + nt_rec * 48ull + 63ull) & ~63ull;            // the flat primitive list of a tiny scene (sc.n_flat set by the caller)
+    total = off_flat + (uint64_t)sc.n_flat * kFlatPrimBytes + 128ull;
+    sc.off_flat = (uint32_t)off_flat;
     if (total > kBlobLimit) return false;
     sc.off_meta = (uint32_t)off_meta; sc.off_tris_alt = (uint32_t)off_tris_alt;
     sc.off_nodes = (uint32_t)off_nodes; sc.off_tris = (uint32_t)off_tris; sc.off_normals = (uint32_t)off_normals;
@@ -594,6 +596,14 @@ int host_scene_build(trg_ctx *c, const float *pos, const float *nrm, const float
     sc.n_tris_rec = lds_candidate ? nt_rec : 0u;
     for (int a = 0; a < 3; ++a) sc.center[a] = n_tris ? 0.5f * (hs->lo[a] + hs->hi[a]) : 0.0f;
     const uint32_t node_bytes = kLdsNodeBytes;
+    // a TINY scene (at most kFlatMaxPrims primitives once the quads are paired) also gets the flat list the shipped build tests instead of walking the tree
+    uint32_t n_flat = 0;
+    if (TRG_EXPERIMENTS && lds_candidate && kFlatMaxPrims && getenv("TRG_FLAT_PRIMS") && atoi(getenv("TRG_FLAT_PRIMS")) != 0) {   // (experiments library, opt-in)
+        uint32_t prims = 0;
+        for (uint32_t i = 0; i < nt_rec; ++i) { ++prims; if (i < bvh.quad.size() && bvh.quad[i]) ++i; }
+        if (n_tris && prims <= kFlatMaxPrims) n_flat = prims;
+    }
+    sc.n_flat = n_flat;
     sc.n_nodes4 = TRG_WIDE8 ? bvh.n_nodes8 : bvh.n_nodes4;
     const uint32_t n_fat = TRG_WIDE8 ? (uint32_t)bvh.rec8.size() : nt_rec;   // (TRG_WIDE8: two entries per leaf, in the order the 8-wide tree addresses them)
     uint64_t total = 0;
@@ -640,6 +650,31 @@ int host_scene_build(trg_ctx *c, const float *pos, const float *nrm, const float
         for (uint32_t i = 0; i < nt_rec; ++i)
             fill_plane_record(&host[sc.off_tris_alt + (size_t)i * 48u], reinterpret_cast<uint16_t *>(&host[sc.off_meta]) + i, &bvh.tris[(size_t)i * 3], sc.center,
                               (i < bvh.quad.size() && bvh.quad[i]) ? &bvh.tris[(size_t)(i + 1) * 3] : nullptr);
+        if (sc.n_flat) {   // the flat list: the same plane records, one entry per primitive, + who it is -- in ASCENDING order of original index (traverse_flat's tie rule)
+            struct FP { uint32_t key, rec; bool quad; };
+            std::vector<FP> fl;
+            for (uint32_t i = 0; i < nt_rec; ++i) {
+                const bool q = i < bvh.quad.size() && bvh.quad[i];
+                uint32_t px, py = ~0u;
+                memcpy(&px, &bvh.tris[(size_t)i * 3].w, 4);
+                if (q) memcpy(&py, &bvh.tris[(size_t)(i + 1) * 3].w, 4);
+                fl.push_back(FP{ std::min(px, py), i, q });
+                if (q) ++i;
+            }
+            std::sort(fl.begin(), fl.end(), [](const FP &x, const FP &y) { return x.key < y.key; });
+            for (uint32_t k = 0; k < sc.n_flat && k < fl.size(); ++k) {
+                const uint32_t i = fl[k].rec;
+                const bool q = fl[k].quad;
+                unsigned char *dst = &host[sc.off_flat + (size_t)k * kFlatPrimBytes];
+                uint16_t meta;
+                fill_plane_record(dst, &meta, &bvh.tris[(size_t)i * 3], sc.center, q ? &bvh.tris[(size_t)(i + 1) * 3] : nullptr);
+                uint32_t row3[4] = { 0u, ~0u, 0u, q ? 1u : 0u };
+                memcpy(&row3[0], &bvh.tris[(size_t)i * 3].w, 4);
+                memcpy(&row3[2], &bvh.tris[(size_t)i * 3 + 1].w, 4);
+                if (q) memcpy(&row3[1], &bvh.tris[(size_t)(i + 1) * 3].w, 4);
+                memcpy(dst + 48, row3, 16);
+            }
+        }
         if (n_tris) {
             memcpy(&host[sc.off_normals], nrm, (size_t)n_tris * 36);
             memcpy(&host[sc.off_colors], col, (size_t)n_tris * 36);

@@ -518,6 +518,8 @@ struct SceneView {
     const unsigned short *meta;   // LDS scene: per record (original index << 2) | (material id & 3) (the plane test of the shipped build)
     V3 center;              // shipped build: the point the plane records are relative to (SceneDesc::center); Trav::o is relative to it too
     uint32_t rec_delta;     // HBM scene: byte distance from `nodes` to `tris` (the records follow the nodes in the blob)
+    const v4f *flat;        // shipped build, tiny LDS-resident scene: the flat primitive list in global memory (trg_kernels.h SceneDesc::off_flat), wave-uniform
+    uint32_t n_flat;        // its entries; 0: walk the tree
 };
 // original index / material id of leaf record r of an HBM-resident scene: the .w of rows 0 / 1 (Moeller-Trumbore records), or the last two
 // words of the record (plane records, whose rows 0..2 are full)
@@ -1004,6 +1006,10 @@ TRG_DEV uint32_t lds_node_base(const SceneView &sc) {
     return !UNIFIED ? (uint32_t)(uintptr_t)(const lds_v4f_t *)sc.nodes : 0u;
 }
 
+#if TRG_EXPERIMENTS
+#include "../../experiments/trg_flat.inc.h"   // traverse_flat: tiny scenes without a tree (measured: C2 +7 % time, C3 -5 %: profiles/r05/c2_flat_list_experiment.md)
+#endif
+
 // Nearest-hit (ANY=false) or any-hit (ANY=true) query for one ray per lane.
 template <bool ANY, bool COUNT, int BLOCK, bool UNIFIED = false, typename STK>
 TRG_DEV bool traverse(const SceneView &sc, V3 o, V3 d, float tmax_ray, uint32_t rmask, Hit &hit, STK stk,
@@ -1011,6 +1017,9 @@ TRG_DEV bool traverse(const SceneView &sc, V3 o, V3 d, float tmax_ray, uint32_t 
 #ifdef TRG_EXP_NOTRAVERSE  // timing-only ablation: a made-up hit, no traversal
     hit.t = 0.5f + 0.001f * (float)(threadIdx.x & 15); hit.prim = ANY ? -1 : (int)((threadIdx.x * 7u + (uint32_t)(o.x * 64.0f)) % 34u); hit.u = 0.3f; hit.v = 0.3f;
     return !ANY;
+#endif
+#if TRG_EXPERIMENTS
+    if (!UNIFIED && kTriPlanes && sc.n_flat != 0u) return traverse_flat<ANY, COUNT>(sc, o, d, tmax_ray, rmask, hit, cnt);   // (wave-uniform: a property of the scene)
 #endif
     Trav tv;
     trav_begin(sc, tv, o, d, tmax_ray, rmask, stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED);

@@ -61,11 +61,20 @@ struct SceneDesc {
     // scenes traversed from HBM, shipped build (TRG_TRI_PLANES_HBM): a second set of 128-byte leaf records whose rows 0..2 are the triangle's
     // three planes, then the original index and the material id (floats 12, 13: TRG_REC_META_FIRST), then the attributes (floats 14..31)
     uint32_t off_fat_planes;
+    // FLAT primitive list (round-5 EXPERIMENT, experiments library with TRG_FLAT_PRIMS=1 only; scenes of at most kFlatMaxPrims primitives after the quads are paired -- the Cornell box has 18):
+    // n_flat x 64 bytes in the blob, outside the staged part -- rows 0..2 the plane record of the triangle or of the quad's parallelogram (as
+    // off_tris_alt), row 3 = (original index of the triangle / of the quad's X, original index of the quad's Y or ~0, material id = mask, 1 = quad).
+    // Such a scene is not walked through its tree at all: every ray tests every primitive in record order (trg_device.h traverse_flat).
+    uint32_t off_flat, n_flat;
     // the planes are stored relative to this point (the centre of the scene's bounding box) and a ray's origin is shifted by it when its
     // traversal begins: n . o - d0 then cancels numbers of the size of the scene instead of its distance from the coordinate origin
     float center[3];
 };
 constexpr uint32_t kFatRecBytes = 128u;
+#ifndef TRG_FLAT_MAX_PRIMS
+#define TRG_FLAT_MAX_PRIMS 32
+#endif
+constexpr uint32_t kFlatMaxPrims = TRG_FLAT_MAX_PRIMS, kFlatPrimBytes = 64u;   // 0: never a flat list
 
 // albedo textures (trg_load_textures): per-corner texture coordinates, per-triangle texture id (0 = none), a table of
 // (first texel, width, height, -) per texture and the RGBA8 texels of all textures back to back.  uv == nullptr: no textures.

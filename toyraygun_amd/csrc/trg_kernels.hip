@@ -70,6 +70,8 @@ TRG_DEV SceneView scene_view(const trg::SceneDesc &sc, unsigned char *smem) {
         v.normals = nullptr; v.colors = nullptr; v.mats = nullptr; v.meta = nullptr;
         v.htab = nullptr;
     }
+    v.flat = reinterpret_cast<const v4f *>(sc.blob + sc.off_flat);
+    v.n_flat = (LDS_SCENE && kTriPlanes) ? sc.n_flat : 0u;
     v.center = mk(sc.center[0], sc.center[1], sc.center[2]);
     v.tex.uv = nullptr; v.tex.ids = nullptr; v.tex.table = nullptr; v.tex.texels = nullptr;
     v.rec_delta = LDS_SCENE ? 0u : (kRecPlanes ? sc.off_fat_planes : sc.off_fat) - sc.off_nodes4;
