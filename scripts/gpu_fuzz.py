@@ -7,6 +7,8 @@ os.environ.setdefault("TRG_GROUP_EXCHANGE", "copy")   # device groups of several
 import numpy as np
 from toyraygun_amd import capi
 from oracle import pyoracle as O
+sys.path.insert(0, "tests")
+from util import edge_flip_allowance
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -117,10 +119,11 @@ for case in range(cases):
             #  radiance 10^4 -- 1/distance^2 -- whose 1e-4 relative error would otherwise be the whole RMSE of a 2,000-pixel image: seed 302, case 1998)
             rel = d / np.maximum(1.0, nr)
             rmse = float(np.sqrt(np.mean((rel * rel)[inl]))) if inl.any() else 0.0
-            # (and never fewer than 4 pixels: 0.1 % of these images is 1-6 pixels, and a soup with duplicated triangles flips 3 now and then)
-            ok = rmse <= 1e-3 and int((~inl).sum()) <= max(4, int(0.001 * w * h))
+            # the outliers: 0.1 % of the pixels + the Poisson bound of the measured edge flips per ray (tests/util.py edge_flip_allowance; round 5:
+            # no "small-image rule" any more)
+            ok = rmse <= 1e-3 and int((~inl).sum()) <= edge_flip_allowance(w * h, rst.rays)
             if not ok:
-                print("  rmse %.3g frac_ok %.5f (%d of %d pixels off)" % (rmse, frac, int((d > 1e-4 * np.maximum(1.0, nr)).sum()), w * h))
+                print("  rmse %.3g frac_ok %.5f (%d of %d pixels off, allowed %d for %d rays)" % (rmse, frac, int((d > 1e-4 * np.maximum(1.0, nr)).sum()), w * h, edge_flip_allowance(w * h, rst.rays), rst.rays))
         else:
             ok = np.array_equal(img.view(np.uint32), ref.view(np.uint32)) and st.rays == rst.rays
     finally:

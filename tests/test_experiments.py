@@ -105,6 +105,7 @@ if what == "rtail":      # the refilling tail kernel: strict build, bit for bit,
     O.set_trig_mode(O.TRIG_PORTABLE)
     ref, st = O.render(scene, w, h, spp, bnc, offsets=off)
     c.set_option(capi.OPT_STRICT, 1)
+    c.set_option(capi.OPT_FRAME_SPLIT, 1)     # (a small image would take frame lanes, which have no tail)
     c.set_option(capi.OPT_TAIL_BOUNCE, 2)
     c.set_option(capi.OPT_TAIL_REFILL, 1)
     c.reset_stats()

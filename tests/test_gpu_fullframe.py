@@ -1,19 +1,22 @@
 """WHOLE-frame parity of the full-size configurations against the oracle -- what scripts/gpu_fullframe.py prints, as a test (VERDICT r03,
 item 2): every pixel of C2, C3 (2.97 G rays), C4 (1,022,244 triangles) and C5 (3840x2160), the strict build bit for bit including the
-three ray counts, the shipped build within the stated tolerance.  About seven minutes of oracle time on the GPU box's host threads, so it
-is opt-in:  python -m pytest tests -m "gpu and slow"   (the one-minute `-m gpu` suite compares sampled rows of C3 / C4 / C5 and the
-whole frame of C2)."""
+three ray counts, the shipped build within the stated tolerance.  About seven minutes of oracle time on the GPU box's host threads for all four:
+C4 runs in every `-m gpu` suite (round 5), the others are opt-in:  python -m pytest tests -m "gpu and slow"   (the plain suite compares
+sampled rows of C3 / C5 and the whole frame of C2)."""
 import numpy as np
 import pytest
 
 from tests.util import TOL_FRAC, TOL_FRAC_C4, TOL_RMSE, image_metrics
 
-pytestmark = [pytest.mark.gpu, pytest.mark.slow]
+pytestmark = [pytest.mark.gpu]
 
 CONFIGS = {"c2": (1920, 1080, 16, 3, "box"), "c3": (1920, 1080, 256, 8, "box"), "c4": (1920, 1080, 16, 3, "lattice"), "c5": (3840, 2160, 64, 3, "box")}
 
 
-@pytest.mark.parametrize("name", ["c2", "c3", "c4", "c5"])
+# C4 -- the configuration with the loosened pixel-share bar (tests/util.py TOL_FRAC_C4) -- is compared as a WHOLE frame in every `-m gpu` run
+# (round-4 verdict, item 6c: about 90 s of oracle time on the box's 16 host threads); C2 (also covered whole by test_full_size_c2_properties),
+# C3 and C5 stay opt-in: `-m "gpu and slow"`.
+@pytest.mark.parametrize("name", [pytest.param("c2", marks=pytest.mark.slow), pytest.param("c3", marks=pytest.mark.slow), "c4", pytest.param("c5", marks=pytest.mark.slow)])
 def test_whole_frame_parity(built, O, name):
     from toyraygun_amd import capi
     w, h, spp, bnc, kind = CONFIGS[name]

@@ -24,6 +24,23 @@ TOL_FRAC = 0.999
 TOL_FRAC_C4 = 0.997
 
 
+# Edge flips per RAY (round 5; scripts/gpu_edge_flips.py, profiles/r05/edge_flips.txt).  An outlier pixel of the metric above is a path that resolved to the
+# other face of an edge it passed within ~1e-7 of; how many there are is a matter of how many rays are traced and how much edge they meet, not of
+# how many pixels the picture has.  Measured on the shipped build in the fuzz's regime (images up to 90 x 70, 1 - 40 spp, 1 - 6 bounces): 0.4 outlier
+# pixels per MILLION rays on the bare Cornell box, 1 - 1.5 with 100 - 2,000 extra triangles, 2.7 - 3.1 with 4,000 - 9,000; worst single image 13.
+# (The cube lattice of C4 -- a million silhouette edges a few pixels long -- is another regime: TOL_FRAC_C4.)  A random soup's picture may therefore
+# hold 0.1 % of its pixels PLUS what a Poisson count with mean q x rays, q = 1e-5 (three times the largest measured rate), reaches
+# with probability 1 - 1e-7: for a 60 x 50 image at 20 spp and 5 bounces (0.5 M rays) that is 3 + 20 pixels, for the 2-megapixel C2 frame it would be
+# 0.1 % + 0.06 % -- the full-size tests do not use it, they keep the flat 99.9 %.
+EDGE_FLIPS_PER_RAY = 1e-5
+
+
+def edge_flip_allowance(pixels, rays, q=EDGE_FLIPS_PER_RAY):
+    """Outlier pixels a random-soup picture of `pixels` pixels rendered with `rays` rays may hold (see above)."""
+    from scipy.stats import poisson
+    return int(0.001 * pixels) + int(poisson.ppf(1.0 - 1e-7, q * max(float(rays), 1.0)))
+
+
 def make_ctx(O, scene, w, h, offsets=None, uniforms=None):
     from toyraygun_amd import capi
     c = capi.Context(w, h)
