@@ -622,7 +622,9 @@ def main(argv=None):
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d, or plainly (no launcher) for the single-process group" % (args.gpus, world, args.gpus))
 
     import torch
-    distributed = world > 1
+    # (a LAUNCHED run of one rank with TRG_FORCE_GATHER=1 takes every N > 1 branch -- communicator, barrier, reductions, the exchange per
+    # frame -- through RCCL with a one-rank communicator: what a one-GPU box can run of the path the driver's scaling run takes)
+    distributed = world > 1 or (launched and bool(os.environ.get("TRG_FORCE_GATHER")))
     dist = None
     # TRG_BENCH_BACKEND=gloo + TRG_BENCH_DEVICES="0,0": the launched multi-rank path rehearsed on a one-GPU box -- the ranks share device 0
     # (NCCL refuses such a communicator) and exchange their bands through host memory; never a scaling number

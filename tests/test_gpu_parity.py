@@ -1486,6 +1486,86 @@ def test_bench_launched_multi_rank_path_rehearsed_on_one_device(capi, tmp_path):
     assert out["roofline"]["derived"] and len(lines[0]) < 4096
 
 
+_RCCL_ONE_RANK = r"""
+import os, sys
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+from toyraygun_amd import capi, host
+from toyraygun_amd.dist import DistributedRenderer
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+w, h, spp, bnc = 200, 93, 3, 3
+b = host.Scene.cornell_box().buffers()
+u = host.uniforms(w, h)[0]
+ref = capi.Context(w, h)
+ref.load_scene(b["positions"], b["normals"], b["colors"], b["indices"], b["material_ids"]); ref.set_uniforms(u); ref.set_pixel_offsets_seed()
+ref.render(0, spp, bnc)
+want = ref.read_accum(); ref.close()
+for interleaved in (False, True):
+    for pipelined in (False, True):
+        r = DistributedRenderer(w, h, 0, pipelined=pipelined, interleaved=interleaved)
+        r.load_scene(b); r.ctx.set_uniforms(u); r.ctx.set_pixel_offsets_seed()
+        for mode in ("root", "all", "root", "all", "root"):      # (five steps: the four slots of a pipelined renderer wrap)
+            f = r.render(0, spp, bnc, gather=mode)
+            r.synchronize(); torch.cuda.synchronize()
+            got = f.cpu().numpy().reshape(h, w, 4)
+            assert np.array_equal(got, want), (interleaved, pipelined, mode, float(np.abs(got - want).max()))
+        r.close()
+t = torch.tensor([1.5, 2.5], dtype=torch.float64, device="cuda:0")
+dist.all_reduce(t, op=dist.ReduceOp.MAX); dist.barrier(); torch.cuda.synchronize()
+assert t.tolist() == [1.5, 2.5]
+dist.destroy_process_group()
+print("RCCL_ONE_RANK_OK", torch.cuda.nccl.version())
+"""
+
+
+def _launched_env(port):
+    import os
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TRG_FORCE_GATHER="1")
+    for k in ("TRG_BENCH_BACKEND", "TRG_BENCH_DEVICES", "TRG_GATHER", "TRG_BANDS"):
+        env.pop(k, None)
+    return env
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def test_torch_distributed_exchange_through_rccl_with_one_rank(capi):
+    """toyraygun_amd/dist.py on a REAL RCCL communicator (backend "nccl"), one rank -- all a one-GPU box can give it: the in-place dist.gather
+    to rank 0 whose receive list ARE the row bands of the frame, the in-place all_gather_into_tensor (sendbuff = recvbuff + rank * count),
+    both on the communication stream behind the render, contiguous and interleaved bands (unpack behind the exchange), plain and pipelined
+    with the slots wrapping: every step's frame equals the plain context's bit for bit.  (The gloo rehearsals never touch ProcessGroupNCCL;
+    the driver's scaling run does.)  A child process: the process group is global state."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK], cwd=root, env=_launched_env(_free_port()), capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0 and "RCCL_ONE_RANK_OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
+
+
+def test_bench_launched_path_through_rccl_with_one_rank(capi):
+    """bench.py as the driver's scaling run starts it (rank environment, backend nccl), one rank, TRG_FORCE_GATHER=1: init_process_group on the
+    device, the barriers, the float64 MAX / SUM reductions and the all_gather of the per-rank figures on the GPU, the root gather timed per
+    frame and the all-gather beside it -- every N > 1 branch, through RCCL."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-secondary"],
+                       cwd=root, env=_launched_env(_free_port()), capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    cfgo = out["config"]
+    assert out["n_gpus"] == 1 and out["value"] > 1000 and 100e6 < cfgo["rays_per_step"] < 120e6
+    assert "RCCL" in cfgo["sharding"] and cfgo["exchange"] == "root gather" and cfgo["rccl_ranks"] == 1 and cfgo["rccl_version"]
+    assert cfgo["gather_root_ms_per_step"] >= 0 and cfgo["gather_all_ms_per_step"] >= 0 and len(lines[0]) < 4096
+
+
 def test_bench_single_process_group_path_rehearsed_on_one_device(capi, monkeypatch, capsys):
     """`python bench.py --gpus N` invoked plainly (what a driver without a launcher does) takes the single-process trg_group path.  Rehearsed
     here end to end on ONE device: TRG_BENCH_DEVICES names device 0 N times and TRG_GROUP_EXCHANGE=copy lets the contexts share it.  The JSON
