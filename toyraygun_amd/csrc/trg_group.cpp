@@ -631,7 +631,14 @@ int trg_group_fence_record(trg_group *g, int slot) {
     for (int r = 0; r < g->n; ++r) {
         hipError_t e = hipSetDevice(g->devices[r]);
         if (e == hipSuccess && !g->fence[slot][r]) e = hipEventCreateWithFlags(&g->fence[slot][r], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventRecord(g->fence[slot][r], g->last_on_xstream ? g->xstream[r] : g->rstream[r][g->cur_slot]);
+        // the last frame's device work: its render stream, and -- behind an exchange -- the exchange stream too (a rank that is no destination
+        // of a gather to one root unpacks its own micro-bands on the render stream AFTER the `rendered` event the exchange stream waits for):
+        // the mark goes behind both
+        if (e == hipSuccess) e = hipEventRecord(g->fence[slot][r], g->rstream[r][g->cur_slot]);
+        if (e == hipSuccess && g->last_on_xstream) {
+            e = hipStreamWaitEvent(g->xstream[r], g->fence[slot][r], 0);
+            if (e == hipSuccess) e = hipEventRecord(g->fence[slot][r], g->xstream[r]);
+        }
         if (e != hipSuccess) return gfail(g, TRG_ERR_DEVICE, "trg_group_fence_record: rank %d: %s", r, hipGetErrorString(e));
     }
     g->fence_set[slot] = true;
