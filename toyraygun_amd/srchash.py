@@ -16,8 +16,11 @@ def kernel_source_files():
     """The kernels' own sources (trg_kernels.hip and everything it includes from csrc/), the ABI header they include
     (include/trg.h: the uniforms block, material and mask constants), and -- ADVICE r03 -- the host side that decides WHICH kernel
     runs with which parameters (trg_capi.cpp: kernel choice, frame split, regeneration lanes, tile order, LDS plan, scene layout):
-    a changed schedule changes the per-launch instruction counts as surely as a changed kernel."""
+    a changed schedule changes the per-launch instruction counts as surely as a changed kernel.  Since round 5 the BVH builders too."""
     names = ["trg_kernels.hip", "trg_kernels.h", "trg_device.h", "q4node.h"] + sorted(f for f in os.listdir(CSRC) if f.endswith(".inc.h")) + ["trg_capi.cpp"]
+    # ... and the builders (round 5): the TREE a scene gets -- split rule, leaf sizes, quad pairing, the 4-wide collapse, on the host and on the
+    # device (bench.py's c4xl leg builds on the device) -- sets the node steps per ray as surely as the traversal code does
+    names += ["bvh_build.cpp", "bvh_build.h", "trg_build.hip"]
     return [os.path.join(CSRC, f) for f in names if os.path.exists(os.path.join(CSRC, f))] + [os.path.join(ROOT, "include", "trg.h")]
 
 
