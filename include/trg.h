@@ -332,6 +332,14 @@ TRG_API int trg_debug_build_bvh(const float *positions3, const uint32_t *indices
 TRG_API int trg_debug_build_bvh4(const float *positions3, const uint32_t *indices, const uint32_t *material_ids, uint32_t n_verts,
                                  uint32_t n_tris, float *nodes4_out, uint32_t nodes4_cap, uint32_t *n_nodes4, uint32_t *depth4);
 
+/* host-only: the BOX leaves the builder finds (scenes staged in LDS: twelve consecutive triangles that are six quads bounding a parallelepiped
+ * -- Scene::addCube, src/engine/Scene.cpp:24-58 -- become one leaf: twelve triangle tests in the strict build, one slab test in the box's own
+ * frame in the shipped one).  20 floats per box: node of the subtree's root and first record (in the tree trg_debug_build_bvh returns when
+ * TRG_DEBUG_BVH_BOXES=1 is set), centre (3), the rows a_k of the frame (9: l_k = a_k . (P - centre), inside <=> |l_k| <= 1), and per face
+ * f = 2 k + (l_k > 0) the offset of its quad's first record (6).  Pass NULL to query the count. */
+TRG_API int trg_debug_boxes(const float *positions3, const uint32_t *indices, const uint32_t *material_ids, uint32_t n_verts, uint32_t n_tris,
+                            float *boxes20_out, uint32_t boxes_cap, uint32_t *n_boxes);
+
 /* host-only: the same 4-wide nodes in the 64-byte quantised form the HBM kernels actually load (16 dwords per node:
  * origin.xyz scale.x | qlo.x qhi.x qlo.y qhi.y | qlo.z qhi.z scale.y scale.z | child[4]; one byte per child in each
  * q dword; plane = origin + q * scale).  Node i of this array is node i of trg_debug_build_bvh4. */

@@ -129,6 +129,7 @@ _SYMBOLS = [
     ("trg_debug_leaf_records", C.c_int, [_P, _P, _P, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
     ("trg_debug_tile_of_slot", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("trg_debug_build_bvh4q", C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
+    ("trg_debug_boxes", C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
 ]
 SYMBOL_NAMES = [s[0] for s in _SYMBOLS]
 
@@ -537,6 +538,24 @@ def debug_build_bvh(positions, indices, material_ids):
     if rc != OK:
         raise TrgError(rc, "trg_debug_build_bvh")
     return nodes, tris, dp.value
+
+
+def debug_boxes(positions, indices, material_ids):
+    """Host-only: the box leaves of the scene, [n, 20] float32 (include/trg.h trg_debug_boxes)."""
+    L = load()
+    pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+    idx = np.ascontiguousarray(indices, np.uint32).reshape(-1)
+    mat = np.ascontiguousarray(material_ids, np.uint32).reshape(-1)
+    n = C.c_uint32()
+    rc = L.trg_debug_boxes(_ptr(pos), _ptr(idx), _ptr(mat), pos.shape[0], mat.shape[0], None, 0, C.byref(n))
+    if rc != OK:
+        raise TrgError(rc, "trg_debug_boxes")
+    out = np.zeros((n.value, 20), np.float32)
+    if n.value:
+        rc = L.trg_debug_boxes(_ptr(pos), _ptr(idx), _ptr(mat), pos.shape[0], mat.shape[0], _ptr(out), n.value, C.byref(n))
+        if rc != OK:
+            raise TrgError(rc, "trg_debug_boxes")
+    return out
 
 
 def debug_build_bvh4(positions, indices, material_ids):

@@ -5,6 +5,7 @@
 #include "q8node.h"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -16,7 +17,7 @@ namespace trg {
 namespace {
 
 constexpr int kBins = 16;
-uint32_t kMaxLeaf = 2;               // leaf encoding allows 7 (tunable: TRG_BVH_MAXLEAF)
+uint32_t kMaxLeaf = 2;               // leaf encoding allows 6 (count field 6 = a BOX leaf, 7 = a QUAD leaf; tunable: TRG_BVH_MAXLEAF)
 bool kQuads = true;                  // pair the two triangles of a parallelogram into one primitive with a leaf of its own (TRG_BVH_QUADS=0: off)
 float kTravCost = 1.2f;               // SAH cost of one node visit relative to one triangle test (TRG_BVH_TRAVCOST)
 constexpr uint32_t kSahDepthCap = 24; // below this depth switch to balanced median splits
@@ -33,13 +34,15 @@ struct Box {
     }
 };
 
-struct Prim { Box b; float c[3]; uint32_t id; uint32_t id2; };   // id2 != ~0u: a quad -- triangle id is its X, id2 its Y (bvh_build.h)
+struct Prim { Box b; float c[3]; uint32_t id; uint32_t id2; uint32_t box; };   // id2 != ~0u: a quad -- triangle id is its X, id2 its Y (bvh_build.h); box != ~0u: the twelve triangles from id on are a parallelepiped (kLeafBox)
 
 struct BuildNode {
     Box box;
     int32_t child[2] = { -1, -1 };  // build-node indices, or -1
     uint32_t first = 0, count = 0;  // leaf range in prims[]
     bool leaf = false;
+    uint32_t d = 0;                 // leaf: its depth
+    uint32_t boxprim = ~0u;         // leaf inside the subtree of a box: the box's index in prims[]; `first` is then the quad's place (0..5) among the box's six
 };
 
 // A subtree handed to a worker thread: its triangle range, its depth, and the child slot of the top tree it hangs from.
@@ -53,7 +56,7 @@ struct Builder {
     std::vector<Task> *tasks = nullptr;
 
     int32_t make_leaf(const Box &box, uint32_t first, uint32_t count, uint32_t d) {
-        BuildNode n; n.box = box; n.first = first; n.count = count; n.leaf = true;
+        BuildNode n; n.box = box; n.first = first; n.count = count; n.leaf = true; n.d = d;
         nodes.push_back(n);
         depth = std::max(depth, d); ++leaves; max_leaf = std::max(max_leaf, count);
         return (int32_t)nodes.size() - 1;
@@ -63,9 +66,9 @@ struct Builder {
         Box box, cbox;
         for (uint32_t i = 0; i < count; ++i) { box.grow(prims[first + i].b); cbox.grow(prims[first + i].c); }
         if (count <= 1) return make_leaf(box, first, count, d);
-        // a quad is a leaf of its own: a range that holds one is split until it is alone
+        // a quad (and a box) is a leaf of its own: a range that holds one is split until it is alone
         bool has_quad = false;
-        for (uint32_t i = 0; i < count && !has_quad; ++i) has_quad = prims[first + i].id2 != ~0u;
+        for (uint32_t i = 0; i < count && !has_quad; ++i) has_quad = prims[first + i].id2 != ~0u || prims[first + i].box != ~0u;
 
         int axis = 0;
         float ext[3] = { cbox.hi[0] - cbox.lo[0], cbox.hi[1] - cbox.lo[1], cbox.hi[2] - cbox.lo[2] };
@@ -178,8 +181,85 @@ uint32_t pair_quads(const float *pos, const uint32_t *idx, const uint32_t *masks
     return quads;
 }
 
-void build_bvh(const float *pos, const uint32_t *idx, const uint32_t *masks, uint32_t ntris, Bvh &out, bool want_wide8) {
-    if (const char *e = getenv("TRG_BVH_MAXLEAF")) kMaxLeaf = (uint32_t)std::min(7, std::max(1, atoi(e)));
+bool boxes_enabled() { const char *e = getenv("TRG_BVH_BOXES"); return !e || atoi(e) != 0; }
+
+namespace {
+// Are triangles k .. k + 11 six quads that bound a parallelepiped (addCube, Scene.cpp:24-58)?  Geometry in double from the fp32 corners:
+// centre C = mean of the six face centres, half axes h_k = half the difference of two opposite face centres, A = [h_0 h_1 h_2]^-1, and
+// every corner of every face must sit at local coordinates (+-1, +-1, +-1) to 1e-5 with the face's own sign on its axis.
+struct BoxGeom { double c[3], a[3][3]; uint32_t face_quad[6]; };   // face f = 2 k + (l_k > 0): which of the six quads (in index order) it is
+bool box_group(const float *pos, const uint32_t *idx, const uint32_t *masks, uint32_t ntris, uint32_t k, BoxGeom &g) {
+    if (k + 12u > ntris) return false;
+    auto vtx = [&](uint32_t t, int j) { return &pos[(size_t)idx[t * 3 + j] * 3]; };
+    double corner[6][4][3], fc[6][3], C[3] = { 0, 0, 0 };
+    for (uint32_t q = 0; q < 6; ++q) {
+        uint32_t x = 0, y = 0;
+        if (masks[k + 2 * q] != masks[k] || !quad_pair(pos, idx, masks, ntris, k + 2 * q, x, y)) return false;
+        const float *p[4] = { vtx(x, 0), vtx(x, 1), vtx(x, 2), vtx(y, 2) };   // a, p1, the diagonal corner, p3 (quad_pair)
+        for (int a = 0; a < 3; ++a) {
+            fc[q][a] = 0;
+            for (int j = 0; j < 4; ++j) { corner[q][j][a] = p[j][a]; fc[q][a] += 0.25 * p[j][a]; }
+            C[a] += fc[q][a] / 6.0;
+        }
+    }
+    // opposite faces: fc_q + fc_q' = 2 C
+    int opp[6] = { -1, -1, -1, -1, -1, -1 };
+    double scale = 0;
+    for (int q = 0; q < 6; ++q) for (int a = 0; a < 3; ++a) scale = std::max(scale, std::fabs(fc[q][a] - C[a]));
+    if (!(scale > 0) || !std::isfinite(scale)) return false;
+    for (int q = 0; q < 6; ++q) {
+        double best = 1e300; int bq = -1;
+        for (int r = 0; r < 6; ++r) {
+            if (r == q) continue;
+            double e = 0;
+            for (int a = 0; a < 3; ++a) e = std::max(e, std::fabs(fc[q][a] + fc[r][a] - 2 * C[a]));
+            if (e < best) { best = e; bq = r; }
+        }
+        if (bq < 0 || best > 1e-5 * scale) return false;
+        opp[q] = bq;
+    }
+    double h[3][3];
+    int axis_of[6], nax = 0;
+    for (int q = 0; q < 6; ++q) axis_of[q] = -1;
+    for (int q = 0; q < 6; ++q) {
+        if (opp[opp[q]] != q) return false;
+        if (axis_of[q] >= 0) continue;
+        if (nax == 3) return false;
+        for (int a = 0; a < 3; ++a) h[nax][a] = 0.5 * (fc[q][a] - fc[opp[q]][a]);
+        axis_of[q] = axis_of[opp[q]] = nax;
+        g.face_quad[2 * nax + 1] = (uint32_t)q; g.face_quad[2 * nax] = (uint32_t)opp[q];   // + side: the face at C + h_k
+        ++nax;
+    }
+    if (nax != 3) return false;
+    // A = H^-1 (rows a_k: a_k . h_j = delta_kj), H's columns the half axes
+    auto cross = [](const double *u, const double *v, double *o) { o[0] = u[1] * v[2] - u[2] * v[1]; o[1] = u[2] * v[0] - u[0] * v[2]; o[2] = u[0] * v[1] - u[1] * v[0]; };
+    double c12[3], c20[3], c01[3];
+    cross(h[1], h[2], c12); cross(h[2], h[0], c20); cross(h[0], h[1], c01);
+    const double det = h[0][0] * c12[0] + h[0][1] * c12[1] + h[0][2] * c12[2];
+    if (!(std::fabs(det) > 1e-12 * scale * scale * scale) || !std::isfinite(det)) return false;
+    for (int a = 0; a < 3; ++a) { g.a[0][a] = c12[a] / det; g.a[1][a] = c20[a] / det; g.a[2][a] = c01[a] / det; g.c[a] = C[a]; }
+    for (int q = 0; q < 6; ++q) {
+        const int kx = axis_of[q];
+        const double side = g.face_quad[2 * kx + 1] == (uint32_t)q ? 1.0 : -1.0;
+        double sum[3] = { 0, 0, 0 };
+        for (int j = 0; j < 4; ++j) {
+            for (int ax = 0; ax < 3; ++ax) {
+                double l = 0;
+                for (int a = 0; a < 3; ++a) l += g.a[ax][a] * (corner[q][j][a] - C[a]);
+                if (!(std::fabs(std::fabs(l) - 1.0) <= 1e-5)) return false;       // (also false for NaN)
+                if (ax == kx && l * side < 0) return false;
+                sum[ax] += l;
+            }
+        }
+        for (int ax = 0; ax < 3; ++ax)
+            if (ax != kx && std::fabs(sum[ax]) > 1e-3) return false;             // the four corners are the four sign pairs of the other two axes
+    }
+    return true;
+}
+}  // namespace
+
+void build_bvh(const float *pos, const uint32_t *idx, const uint32_t *masks, uint32_t ntris, Bvh &out, bool want_wide8, bool want_boxes) {
+    if (const char *e = getenv("TRG_BVH_MAXLEAF")) kMaxLeaf = (uint32_t)std::min(6, std::max(1, atoi(e)));
     if (const char *e = getenv("TRG_BVH_TRAVCOST")) kTravCost = (float)atof(e);
     kQuads = quads_enabled();   // (read per build: the tests switch it)
     Builder B;
@@ -189,10 +269,23 @@ void build_bvh(const float *pos, const uint32_t *idx, const uint32_t *masks, uin
     auto vtx = [&](uint32_t k, int j) { return &pos[(size_t)idx[k * 3 + j] * 3]; };
     auto quad_of = [&](uint32_t k, uint32_t &x, uint32_t &y) { return kQuads && quad_pair(pos, idx, masks, ntris, k, x, y); };
     uint32_t n_prims = 0;
+    std::vector<BoxGeom> box_geom;
+    const bool boxes = want_boxes && kQuads && boxes_enabled();
     for (uint32_t k = 0; k < ntris; ++k) {
         Prim &p = B.prims[n_prims++];
         p = Prim();
-        p.id = k; p.id2 = ~0u;
+        p.id = k; p.id2 = ~0u; p.box = ~0u;
+        BoxGeom bg;
+        if (boxes && box_group(pos, idx, masks, ntris, k, bg)) {   // twelve triangles, one primitive
+            p.box = (uint32_t)box_geom.size();
+            box_geom.push_back(bg);
+            for (uint32_t t = k; t < k + 12u; ++t)
+                for (int j = 0; j < 3; ++j) p.b.grow(vtx(t, j));
+            for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * (p.b.lo[a] + p.b.hi[a]);
+            scene.grow(p.b);
+            k += 11u;
+            continue;
+        }
         uint32_t x = 0, y = 0;
         const bool q = quad_of(k, x, y);
         if (q) { p.id = x; p.id2 = y; }
@@ -243,6 +336,44 @@ void build_bvh(const float *pos, const uint32_t *idx, const uint32_t *masks, uin
         }
     }
 
+    // ---- boxes: the leaf of a box primitive becomes the root of a subtree over its six quads (built by the same rule).  The quads keep
+    //      the order that build leaves them in: box_quads[b][j] = (X, Y) of the j-th, records first + 2 j and first + 2 j + 1 ----
+    struct QuadIds { uint32_t x, y, q; };
+    std::vector<std::array<QuadIds, 6>> box_quads(box_geom.size());
+    std::vector<int32_t> box_root_node(box_geom.size(), -1);   // build-node index of the subtree's root
+    if (!box_geom.empty()) {
+        const size_t n_before = B.nodes.size();
+        for (size_t n = 0; n < n_before; ++n) {
+            if (!B.nodes[n].leaf || B.nodes[n].count != 1u || B.prims[B.nodes[n].first].box == ~0u) continue;
+            const uint32_t bp = B.nodes[n].first, b = B.prims[bp].box, k0 = B.prims[bp].id;
+            Prim lp[6];
+            for (uint32_t q = 0; q < 6; ++q) {
+                Prim &p = lp[q];
+                p = Prim();
+                uint32_t x = 0, y = 0;
+                (void)quad_pair(pos, idx, masks, ntris, k0 + 2 * q, x, y);   // (box_group has checked it)
+                p.id = x; p.id2 = y; p.box = ~0u;
+                for (uint32_t t = k0 + 2 * q; t <= k0 + 2 * q + 1; ++t)
+                    for (int j = 0; j < 3; ++j) p.b.grow(vtx(t, j));
+                for (int a = 0; a < 3; ++a) p.c[a] = 0.5f * (p.b.lo[a] + p.b.hi[a]);
+            }
+            Builder sub;
+            sub.prims = lp;
+            const int32_t sr = sub.build(0, 6, B.nodes[n].d);
+            for (uint32_t j = 0; j < 6; ++j) box_quads[b][j] = QuadIds{ lp[j].id, lp[j].id2, (std::min(lp[j].id, lp[j].id2) - k0) / 2u };
+            const int32_t off = (int32_t)B.nodes.size();
+            for (BuildNode sn : sub.nodes) {
+                for (int c = 0; c < 2; ++c)
+                    if (sn.child[c] >= 0) sn.child[c] += off;
+                if (sn.leaf) sn.boxprim = bp;      // (first = the quad's place among the six)
+                B.nodes.push_back(sn);
+            }
+            B.nodes[n] = B.nodes[(size_t)(off + sr)];   // the box's leaf becomes the subtree's root: whoever pointed at it still does
+            box_root_node[b] = (int32_t)n;
+            B.depth = std::max(B.depth, sub.depth); B.leaves += sub.leaves - 1u; B.max_leaf = std::max(B.max_leaf, sub.max_leaf);
+        }
+    }
+
     // Conservative padding: the slab test and the triangle test round differently; every box is
     // widened by far more than that so a triangle the Moeller-Trumbore test accepts is always reached.
     float diag = 0.f;
@@ -275,7 +406,7 @@ void build_bvh(const float *pos, const uint32_t *idx, const uint32_t *masks, uin
 
     // triangle records in leaf (prims[]) order; a quad contributes its X record, then its Y record
     std::vector<uint32_t> rec_first((size_t)n_prims + 1, 0u);   // first record of prim i
-    for (uint32_t i = 0; i < n_prims; ++i) rec_first[i + 1] = rec_first[i] + (B.prims[i].id2 != ~0u ? 2u : 1u);
+    for (uint32_t i = 0; i < n_prims; ++i) rec_first[i + 1] = rec_first[i] + (B.prims[i].box != ~0u ? 12u : B.prims[i].id2 != ~0u ? 2u : 1u);
     out.quad.assign(ntris, 0);
     out.n_quads = 0;
     auto put_rec = [&](uint32_t r, uint32_t k) {
@@ -285,6 +416,14 @@ void build_bvh(const float *pos, const uint32_t *idx, const uint32_t *masks, uin
         out.tris[(size_t)r * 3 + 2] = F4{ c[0] - a[0], c[1] - a[1], c[2] - a[2], 0.f };
     };
     for (uint32_t i = 0; i < n_prims; ++i) {
+        if (B.prims[i].box != ~0u) {   // six quads, in the order their subtree left them
+            for (uint32_t j = 0; j < 6; ++j) {
+                const QuadIds &qi = box_quads[B.prims[i].box][j];
+                put_rec(rec_first[i] + 2 * j, qi.x); put_rec(rec_first[i] + 2 * j + 1u, qi.y);
+                out.quad[rec_first[i] + 2 * j] = 1; ++out.n_quads;
+            }
+            continue;
+        }
         put_rec(rec_first[i], B.prims[i].id);
         if (B.prims[i].id2 != ~0u) { put_rec(rec_first[i] + 1u, B.prims[i].id2); out.quad[rec_first[i]] = 1; ++out.n_quads; }
     }
@@ -296,6 +435,11 @@ void build_bvh(const float *pos, const uint32_t *idx, const uint32_t *masks, uin
         const bool q = count == 1u && B.prims[first].id2 != ~0u;
         return ~(int32_t)((r0 << 3) | (q ? kLeafQuad : nrec - 1u));
     };
+    // ... and the leaf code of a leaf build node: a quad of a box's subtree addresses its pair of the box's twelve records
+    auto leaf_of = [&](const BuildNode &n) {
+        if (n.boxprim != ~0u) return ~(int32_t)(((rec_first[n.boxprim] + 2u * n.first) << 3) | kLeafQuad);
+        return leaf_ref(n.first, n.count);
+    };
     auto put = [&](uint32_t di, const Box &b0, int32_t r0, const Box &b1, int32_t r1) {
         F4 *n = &out.nodes[(size_t)di * 4];
         n[0] = F4{ b0.lo[0], b0.hi[0], b0.lo[1], b0.hi[1] };
@@ -306,7 +450,7 @@ void build_bvh(const float *pos, const uint32_t *idx, const uint32_t *masks, uin
     auto child_ref = [&](int32_t ch, Box &box) -> int32_t {
         const BuildNode &n = B.nodes[ch];
         box = padded(n.box);
-        return n.leaf ? leaf_ref(n.first, n.count) : dev_index[ch];
+        return n.leaf ? leaf_of(n) : dev_index[ch];
     };
     if (synth_root) {
         // The kernel always starts at an inner node.  A scene that is a single leaf gets a root whose
@@ -328,6 +472,22 @@ void build_bvh(const float *pos, const uint32_t *idx, const uint32_t *masks, uin
             const int32_t r0 = child_ref(B.nodes[n].child[0], b0), r1 = child_ref(B.nodes[n].child[1], b1);
             put((uint32_t)dev_index[n], b0, r0, b1, r1);
         }
+    }
+
+    out.boxes.clear();
+    for (uint32_t i = 0; i < n_prims && !synth_root; ++i) {
+        const uint32_t b = B.prims[i].box;
+        if (b == ~0u || box_root_node[b] < 0 || dev_index[(size_t)box_root_node[b]] < 0) continue;
+        BoxLeaf bl;
+        bl.node = (uint32_t)dev_index[(size_t)box_root_node[b]];
+        bl.first_rec = rec_first[i];
+        for (int a = 0; a < 3; ++a) { bl.center[a] = (float)box_geom[b].c[a]; for (int k = 0; k < 3; ++k) bl.axis[k][a] = (float)box_geom[b].a[k][a]; }
+        for (int f = 0; f < 6; ++f) {
+            bl.face_rec[f] = 0;
+            for (uint32_t j = 0; j < 6; ++j)
+                if (box_quads[b][j].q == box_geom[b].face_quad[f]) bl.face_rec[f] = (uint8_t)(2u * j);
+        }
+        out.boxes.push_back(bl);
     }
 
     // ---- 4-wide collapse (used for scenes that stay in HBM): each BVH2 inner node pulls up grandchildren,
@@ -375,7 +535,7 @@ void build_bvh(const float *pos, const uint32_t *idx, const uint32_t *masks, uin
                 const BuildNode &c = B.nodes[ch[k]];
                 w.box[k] = padded(c.box);
                 if (c.leaf) {
-                    w.child[k] = leaf_ref(c.first, c.count);
+                    w.child[k] = leaf_of(c);
                 } else {
                     w.child[k] = (int32_t)wide.size();
                     wide.emplace_back();

@@ -35,6 +35,20 @@ struct F4 { float x, y, z, w; };
 // without knowing) tests the two triangles one after the other: kLeafQuad = a count of 2.
 constexpr uint32_t kLeafQuad = 7u;
 inline uint32_t leaf_count(uint32_t code) { return (code & 7u) == kLeafQuad ? 2u : (code & 7u) + 1u; }
+// BOX leaves (round 5; scenes staged in LDS only).  addCube's twelve triangles (Scene.cpp:24-58) are six quads that bound a parallelepiped.  With
+// `want_boxes` the builder treats such a group as ONE primitive while it splits -- it gets a subtree of its own, six quad leaves whose records are
+// consecutive -- and reports the subtree's root (BoxLeaf): whoever lays the nodes out for LDS may replace the reference to that root by the leaf
+// code ~((first_rec << 3) | kLeafBox), a leaf of TWELVE records.  The strict build tests the twelve triangles; the shipped build does one slab
+// test in the box's own frame and reads (triangle, barycentrics) off the face it enters by.  The tree every other consumer sees (the BVH2 node
+// array, its 4-wide collapse) just holds the subtree.  A plain leaf therefore holds at most six triangles (count field 0..5).
+constexpr uint32_t kLeafBox = 6u;
+struct BoxLeaf {
+    uint32_t node;          // index (BVH2 node array) of the root of the box's subtree
+    uint32_t first_rec;     // its twelve records: six quads, X then Y each
+    float center[3];        // the parallelepiped: local coordinate l_k = axis[k] . (P - center), inside <=> |l_k| <= 1 for k = 0, 1, 2
+    float axis[3][3];
+    uint8_t face_rec[6];    // face f = 2 k + (l_k > 0 ? 1 : 0): offset (0, 2, .. 10) of its quad's X record from first_rec
+};
 
 struct Bvh {
     std::vector<uint8_t> quad;   // per triangle record: 1 = record X of a quad leaf (the next record is its Y)
@@ -45,6 +59,7 @@ struct Bvh {
     std::vector<F4> tris;    // 3 per triangle
     uint32_t n_nodes = 0, n_leaves = 0, depth = 0, max_leaf = 0;
     uint32_t n_nodes4 = 0, depth4 = 0;
+    std::vector<BoxLeaf> boxes;   // want_boxes: the parallelepipeds found (see kLeafBox)
     double sah_cost = 0.0;
     // ---- 8-wide compressed nodes (round-5 experiment, TRG_WIDE8 builds; q8node.h): the same BVH2 collapsed to up to eight children per node ----
     std::vector<uint32_t> nodes8;   // 20 dwords (80 bytes) per node, breadth first: the inner children of a node have consecutive indices
@@ -63,6 +78,7 @@ uint32_t pair_quads(const float *positions3, const uint32_t *indices, const uint
 
 // positions3: nverts*3 floats; indices: ntris*3; masks: ntris (the reference's materialID buffer,
 // MetalRenderer.mm:276).  Deterministic for a given input.
-void build_bvh(const float *positions3, const uint32_t *indices, const uint32_t *masks, uint32_t ntris, Bvh &out, bool want_wide8 = false);
+void build_bvh(const float *positions3, const uint32_t *indices, const uint32_t *masks, uint32_t ntris, Bvh &out, bool want_wide8 = false, bool want_boxes = false);
+bool boxes_enabled();   // TRG_BVH_BOXES != 0 (default on), read at every call: the switch for A/B runs and tests
 
 }  // namespace trg

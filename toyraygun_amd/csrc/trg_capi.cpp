@@ -21,6 +21,8 @@
 #include "trg_kernels.h"
 
 using namespace trg;
+// the host-only debug entry points build WITHOUT box leaves unless TRG_DEBUG_BVH_BOXES is set (tests: the builder's soundness checks run both ways)
+static bool debug_want_boxes() { const char *e = getenv("TRG_DEBUG_BVH_BOXES"); return e && atoi(e) != 0; }
 
 struct trg_ctx {
     int device = 0;
@@ -569,7 +571,8 @@ int host_scene_build(trg_ctx *c, const float *pos, const float *nrm, const float
     if (!hs) return fail(c, TRG_ERR_NOMEM, "trg_load_scene: out of host memory");
     const auto host_t0 = std::chrono::steady_clock::now();
     Bvh bvh;
-    build_bvh(pos, idx, mat, n_tris, bvh, TRG_WIDE8 != 0);
+    // (boxes: only a scene that may be staged in LDS can use them -- 170 triangles at most; the switch is wider so that the answer does not hinge on it)
+    build_bvh(pos, idx, mat, n_tris, bvh, TRG_WIDE8 != 0, TRG_BOX_LEAVES && !TRG_WIDE8 && n_tris <= 1024u);
     if (TRG_WIDE8 && !bvh.wide8_ok) { delete hs; return fail(c, TRG_ERR_RANGE, "trg_load_scene: the 8-wide layout of this build needs leaves of at most two records (TRG_BVH_MAXLEAF <= 2)"); }
     hs->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
     if (n_tris) {
@@ -624,6 +627,9 @@ int host_scene_build(trg_ctx *c, const float *pos, const float *nrm, const float
             int32_t ch[2];
             memcpy(ch, &n[3].x, 8);
             for (int k = 0; k < 2; ++k) {
+                // the root of a box's subtree: ONE leaf of twelve records here (bvh_build.h kLeafBox; its subtree's nodes stay in the array, unreferenced)
+                for (const BoxLeaf &bl : bvh.boxes)
+                    if (ch[k] >= 0 && (uint32_t)ch[k] == bl.node) ch[k] = ~(int32_t)((bl.first_rec << 3) | kLeafBox);
                 if (ch[k] >= 0) ch[k] *= (int32_t)kLdsNodeBytes;   // inner child: byte offset of its node
                 // (a leaf child keeps its code ~((record << 3) | (count - 1)): the leaf step turns the record into an address with ONE
                 //  v_mad_u32_u24, and the same number indexes the u16 per record of the plane test)
@@ -650,6 +656,20 @@ int host_scene_build(trg_ctx *c, const float *pos, const float *nrm, const float
         for (uint32_t i = 0; i < nt_rec; ++i)
             fill_plane_record(&host[sc.off_tris_alt + (size_t)i * 48u], reinterpret_cast<uint16_t *>(&host[sc.off_meta]) + i, &bvh.tris[(size_t)i * 3], sc.center,
                               (i < bvh.quad.size() && bvh.quad[i]) ? &bvh.tris[(size_t)(i + 1) * 3] : nullptr);
+        // a box leaf's twelve plane records hold six quads X, Y, X, Y ...: a quad's test reads its X record only, so the Y slots are free -- the first
+        // takes the box itself, rows (a_k, d_k): l_k = a_k . (P - scene centre) + d_k, the second the X-record offset of each of its six faces
+        for (const BoxLeaf &bl : bvh.boxes) {
+            float rec[12];
+            for (int k = 0; k < 3; ++k) {
+                double dk = 0.0;
+                for (int a = 0; a < 3; ++a) { rec[k * 4 + a] = bl.axis[k][a]; dk -= (double)bl.axis[k][a] * ((double)bl.center[a] - (double)sc.center[a]); }
+                rec[k * 4 + 3] = (float)dk;
+            }
+            memcpy(&host[sc.off_tris_alt + (size_t)(bl.first_rec + 1u) * 48u], rec, 48);
+            uint32_t faces[12] = { 0 };
+            for (int f = 0; f < 6; ++f) faces[f] = ((uint32_t)bl.face_rec[f] << 16) | ((uint32_t)bl.face_rec[f] * 48u);
+            memcpy(&host[sc.off_tris_alt + (size_t)(bl.first_rec + 3u) * 48u], faces, 48);
+        }
         if (sc.n_flat) {   // the flat list: the same plane records, one entry per primitive, + who it is -- in ASCENDING order of original index (traverse_flat's tie rule)
             struct FP { uint32_t key, rec; bool quad; };
             std::vector<FP> fl;
@@ -1276,7 +1296,7 @@ int trg_debug_build_bvh(const float *positions3, const uint32_t *indices, const 
     for (size_t i = 0; i < (size_t)n_tris * 3; ++i)
         if (indices[i] >= n_verts) return TRG_ERR_INVALID;
     Bvh bvh;
-    build_bvh(positions3, indices, material_ids, n_tris, bvh);
+    build_bvh(positions3, indices, material_ids, n_tris, bvh, false, debug_want_boxes());
     const uint32_t nrec = (uint32_t)(bvh.tris.size() / 3);
     if (n_nodes) *n_nodes = bvh.n_nodes;
     if (n_tri_records) *n_tri_records = nrec;
@@ -1298,12 +1318,33 @@ int trg_debug_build_bvh4(const float *positions3, const uint32_t *indices, const
     for (size_t i = 0; i < (size_t)n_tris * 3; ++i)
         if (indices[i] >= n_verts) return TRG_ERR_INVALID;
     Bvh bvh;
-    build_bvh(positions3, indices, material_ids, n_tris, bvh);
+    build_bvh(positions3, indices, material_ids, n_tris, bvh, false, debug_want_boxes());
     if (n_nodes4) *n_nodes4 = bvh.n_nodes4;
     if (depth4) *depth4 = bvh.depth4;
     if (nodes4_out) {
         if (nodes4_cap < bvh.n_nodes4) return TRG_ERR_RANGE;
         memcpy(nodes4_out, bvh.nodes4.data(), (size_t)bvh.n_nodes4 * 128);
+    }
+    return TRG_OK;
+}
+
+int trg_debug_boxes(const float *positions3, const uint32_t *indices, const uint32_t *material_ids, uint32_t n_verts, uint32_t n_tris,
+                    float *boxes20_out, uint32_t boxes_cap, uint32_t *n_boxes) {
+    if (n_tris && (!positions3 || !indices || !material_ids)) return TRG_ERR_INVALID;
+    for (size_t i = 0; i < (size_t)n_tris * 3; ++i)
+        if (indices[i] >= n_verts) return TRG_ERR_INVALID;
+    Bvh bvh;
+    build_bvh(positions3, indices, material_ids, n_tris, bvh, false, true);
+    if (n_boxes) *n_boxes = (uint32_t)bvh.boxes.size();
+    if (boxes20_out) {
+        if (boxes_cap < bvh.boxes.size()) return TRG_ERR_RANGE;
+        for (size_t b = 0; b < bvh.boxes.size(); ++b) {
+            const BoxLeaf &bl = bvh.boxes[b];
+            float *o = boxes20_out + b * 20;
+            o[0] = (float)bl.node; o[1] = (float)bl.first_rec;
+            for (int a = 0; a < 3; ++a) { o[2 + a] = bl.center[a]; for (int k = 0; k < 3; ++k) o[5 + k * 3 + a] = bl.axis[k][a]; }
+            for (int f = 0; f < 6; ++f) o[14 + f] = (float)bl.face_rec[f];
+        }
     }
     return TRG_OK;
 }
@@ -1314,7 +1355,7 @@ int trg_debug_build_bvh4q(const float *positions3, const uint32_t *indices, cons
     for (size_t i = 0; i < (size_t)n_tris * 3; ++i)
         if (indices[i] >= n_verts) return TRG_ERR_INVALID;
     Bvh bvh;
-    build_bvh(positions3, indices, material_ids, n_tris, bvh);
+    build_bvh(positions3, indices, material_ids, n_tris, bvh, false, debug_want_boxes());
     if (n_nodes4) *n_nodes4 = bvh.n_nodes4;
     if (nodes4q_out) {
         if (nodes4_cap < bvh.n_nodes4) return TRG_ERR_RANGE;
@@ -1329,7 +1370,7 @@ int trg_debug_leaf_records(const float *positions3, const float *normals3, const
     for (size_t i = 0; i < (size_t)n_tris * 3; ++i)
         if (indices[i] >= n_verts) return TRG_ERR_INVALID;
     Bvh bvh;
-    build_bvh(positions3, indices, material_ids, n_tris, bvh);
+    build_bvh(positions3, indices, material_ids, n_tris, bvh, false, debug_want_boxes());
     const uint32_t nrec = (uint32_t)(bvh.tris.size() / 3);
     if (n_records) *n_records = nrec;
     if (records32_out) {
@@ -1346,7 +1387,7 @@ int trg_debug_plane_records(const float *positions3, const uint32_t *indices, co
     for (size_t i = 0; i < (size_t)n_tris * 3; ++i)
         if (indices[i] >= n_verts) return TRG_ERR_INVALID;
     Bvh bvh;
-    build_bvh(positions3, indices, material_ids, n_tris, bvh);
+    build_bvh(positions3, indices, material_ids, n_tris, bvh, false, debug_want_boxes());
     const uint32_t nrec = (uint32_t)(bvh.tris.size() / 3);
     if (n_records) *n_records = nrec;
     float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY }, ctr[3];

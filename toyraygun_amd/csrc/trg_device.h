@@ -572,6 +572,7 @@ TRG_DEV bool tri_test_planes_quad(const v4f a, const v4f b, const v4f c, V3 o, V
     return in && (t >= 0.0f) && (t <= tmax_ray);
 }
 constexpr uint32_t kLeafQuad = 7u;   // bvh_build.h: the count field of a QUAD leaf (two triangles of a parallelogram, X then Y)
+constexpr uint32_t kLeafBox = 6u;    // ... of a BOX leaf (LDS-resident scenes): twelve records, six quads that bound a parallelepiped
 // the build's triangle test on an LDS-resident scene: planes + the u16 per record (shipped), or the Moeller-Trumbore rows (strict)
 constexpr bool kTriPlanes = !TRG_STRICT && TRG_TRI_PLANES;
 // ... and on a scene traversed from HBM: the leaf records of SceneDesc::off_fat_planes (rows 0..2 planes, words 30 / 31 index and mask)
@@ -806,6 +807,51 @@ TRG_DEV bool trav_quad_planes(const SceneView &sc, const v4f *tr, uint32_t rec, 
     tv.hit.v = take ? v : tv.hit.v;
     return any && ok;
 }
+// a BOX leaf of an LDS-resident scene (shipped build; bvh_build.h kLeafBox, trg_capi.cpp): `tr` = its twelve plane records -- six quads, X then Y
+// each.  A quad's test reads its X record only, so the Y slots are free: record 1 holds the box, rows (a_k, d_k) with l_k = a_k . o + d_k the
+// ray origin in the box's own frame (inside <=> |l_k| <= 1), record 3 one word per face f = 2 k + (l_k > 0): (X-record offset << 16) | its byte
+// offset.  One slab test in that frame; the face the ray enters by (leaves by, from inside: the triangles are two-sided) names the quad, and that
+// quad's own rows 1, 2 give (s, t) at the hit point exactly as its quad test would -- hence the triangle and the weights the reference's buffers know.
+template <bool COUNT>
+TRG_DEV bool trav_box_planes(const SceneView &sc, const v4f *tr, uint32_t first, Trav &tv, bool any, Counters &cnt) {
+    const uint32_t meta0 = sc.meta[first];
+    const bool masked_in = (meta0 & tv.rmask) != 0u;   // (one material for the twelve: bvh_build.cpp box_group)
+    if (COUNT) { if (masked_in) cnt.tris++; if (mbcnt64(__ballot(1)) == 0) cnt.wtris++; }
+    const v4f b0 = tr[3], b1 = tr[4], b2 = tr[5];
+    const V3 o = tv.o, d = tv.d;
+    const float lox = b0.x * o.x + (b0.y * o.y + (b0.z * o.z + b0.w)), ldx = b0.x * d.x + (b0.y * d.y + b0.z * d.z);
+    const float loy = b1.x * o.x + (b1.y * o.y + (b1.z * o.z + b1.w)), ldy = b1.x * d.x + (b1.y * d.y + b1.z * d.z);
+    const float loz = b2.x * o.x + (b2.y * o.y + (b2.z * o.z + b2.w)), ldz = b2.x * d.x + (b2.y * d.y + b2.z * d.z);
+    const float ix = rcp_fast(ldx), iy = rcp_fast(ldy), iz = rcp_fast(ldz);
+    const float mx = -lox * ix, my = -loy * iy, mz = -loz * iz;              // the ray meets the planes l_k = -1, +1 at m_k -+ |1 / ld_k|
+    const float ax = fabsf(ix), ay = fabsf(iy), az = fabsf(iz);
+    const float nx = mx - ax, ny = my - ay, nz = mz - az, fx = mx + ax, fy = my + ay, fz = mz + az;
+    const float tnear = fmaxf(fmaxf(nx, ny), nz), tfar = fminf(fminf(fx, fy), fz);
+    const bool inside = tnear < 0.0f;
+    const float t = inside ? tfar : tnear;
+    const bool ok = (tnear <= tfar) && (t >= 0.0f) && (t <= tv.best) && masked_in;
+    // the face: the axis whose plane gives t, the side the hit point lies on
+    const float cx = inside ? fx : nx, cy = inside ? fy : ny;
+    const bool isx = cx == t, isy = cy == t;
+    const float lk = isx ? lox + t * ldx : isy ? loy + t * ldy : loz + t * ldz;
+    const uint32_t f = (isx ? 0u : isy ? 2u : 4u) + (lk > 0.0f ? 1u : 0u);
+    const uint32_t fw = reinterpret_cast<const uint32_t *>(tr + 9)[f];
+    const v4f *q = reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(tr) + (fw & 0xFFFFu));
+    const v4f q1 = q[1], q2 = q[2];
+    const V3 P = mk(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);
+    const float s0 = q1.x * P.x + (q1.y * P.y + (q1.z * P.z + q1.w));
+    const float t0 = q2.x * P.x + (q2.y * P.y + (q2.z * P.z + q2.w));
+    const bool second = s0 < t0;
+    const float u = second ? s0 : s0 - t0, v = second ? t0 - s0 : t0;
+    const int prim = (int)((uint32_t)sc.meta[first + (fw >> 16) + (second ? 1u : 0u)] >> 2);
+    const bool take = ok && (any || !tv.found || t < tv.best || (t == tv.best && prim < tv.hit.prim));
+    tv.found = tv.found || ok;
+    tv.best = take ? t : tv.best;
+    tv.hit.prim = take ? prim : tv.hit.prim;
+    tv.hit.u = take ? u : tv.hit.u;
+    tv.hit.v = take ? v : tv.hit.v;
+    return any && ok;
+}
 // ... and on a leaf RECORD of an HBM-resident scene (the hit keeps the record index; ties go to the lower original index, read back from the
 // held record only then): mask and prim are floats 13 and 12 of the record (TRG_REC_META_FIRST; its last two words before)
 template <bool COUNT>
@@ -849,11 +895,14 @@ template <bool COUNT, int BLOCK, typename STK>
 TRG_DEV bool trav_leaf_step(const SceneView &sc, Trav &tv, bool any, STK stk, Counters &cnt) {
     const uint32_t code = (uint32_t)~tv.node;
     const bool quad = (code & 7u) == kLeafQuad;   // the two triangles of a parallelogram (bvh_build.h): ONE plane test in the shipped build
-    const uint32_t first = code >> 3, count = quad ? 2u : (code & 7u) + 1u;
+    const bool box = TRG_BOX_LEAVES && (code & 7u) == kLeafBox;   // the twelve of a parallelepiped: ONE slab test in the shipped build
+    const uint32_t first = code >> 3, count = quad ? 2u : box ? 12u : (code & 7u) + 1u;
     bool stop = false;
     {   // leaves of the host builder hold a quad, or one or two triangles: those without a loop (-2 %); more only from other builders
         const v4f *tr = lds_records(sc, first);
-        if (kTriPlanes && quad) {
+        if (kTriPlanes && TRG_BOX_LEAVES && box) {
+            stop = trav_box_planes<COUNT>(sc, tr, first, tv, any, cnt);
+        } else if (kTriPlanes && quad) {
             stop = trav_quad_planes<COUNT>(sc, tr, first, tv, any, cnt);
         } else {
             stop = trav_tri_lds<COUNT>(sc, tr, first, tv, any, cnt);

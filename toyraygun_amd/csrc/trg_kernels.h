@@ -229,6 +229,10 @@ struct TraceParams {
 #ifndef TRG_TRI_PLANES_HBM
 #define TRG_TRI_PLANES_HBM 1   // the same for scenes traversed from HBM (their own set of leaf records, SceneDesc::off_fat_planes)
 #endif
+#ifndef TRG_BOX_LEAVES
+#define TRG_BOX_LEAVES 1       // scenes staged in LDS: addCube's twelve triangles become ONE leaf (bvh_build.h kLeafBox): twelve triangle tests in the strict
+                               // build, one slab test in the parallelepiped's own frame in the shipped one (trg_device.h trav_box_planes)
+#endif
 #ifndef TRG_HALTON_TABLES
 #define TRG_HALTON_TABLES 1
 #endif
