@@ -15,6 +15,8 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 FAST = len(sys.argv) > 3 and sys.argv[3] == "fast"
 ONLY = set(int(x) for x in os.environ.get("FUZZ_ONLY", "").split(",") if x.strip())
 eye = np.eye(4, dtype=np.float32)
+_unit = O.OracleScene(); _unit.add("cube", (1.0, 1.0, 1.0), eye)
+CUBE = _unit.buffers()["positions"].reshape(-1, 3).copy()      # addCube's 36 vertices in its own order (Scene.cpp:24-58)
 bad = 0
 t_start = time.time()
 for case in range(cases):
@@ -40,6 +42,17 @@ for case in range(cases):
                     s.add_geometry(p4, [0, 2, 3, 0, 1, 2], eye, rng.uniform(0.2, 0.9, 3), int(mats[k]))      # (a, c, d)(a, b, c): the second is X
             else:
                 s.add_geometry(tri[k], [0, 1, 2], eye, rng.uniform(0.2, 0.9, 3), int(mats[k]))
+    # round 5: parallelepipeds (addCube's twelve triangles under a random rotation, anisotropic scale with random signs, sometimes a shear) of
+    # every material -> BOX leaves where the scene is staged in LDS, six quads per cube everywhere else
+    for k in range(int(rng.integers(1, 6)) if rng.random() < 0.5 else 0):
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        sh = np.eye(3)
+        if rng.random() < 0.3:
+            sh[0, 1] = rng.uniform(-0.8, 0.8)
+        m = np.eye(4)
+        m[:3, :3] = q @ sh @ np.diag(rng.uniform(0.03, 0.3, 3) * rng.choice([-1.0, 1.0], 3))
+        m[:3, 3] = rng.uniform([-0.8, 0.1, -0.8], [0.8, 1.8, 0.8])
+        s.add_geometry(CUBE, np.arange(36, dtype=np.uint32), m.T.astype(np.float32), rng.uniform(0.2, 0.9, 3), int(rng.choice([1, 1, 1, 2, 3])))
     w, h = int(rng.integers(1, 90)), int(rng.integers(1, 70))
     if FAST:
         w, h = max(w, 32), max(h, 32)

@@ -12,7 +12,7 @@ import os
 import numpy as np
 import pytest
 
-from tests.util import TOL_FRAC, TOL_FRAC_C4, TOL_RMSE, image_metrics, make_ctx
+from tests.util import TOL_FRAC, TOL_FRAC_C4, TOL_RMSE, edge_flip_allowance, image_metrics, make_ctx
 
 pytestmark = pytest.mark.gpu
 
@@ -455,6 +455,99 @@ def test_lds_resident_soup_parity(capi, O, n, seed):
                     assert st.rays == rst.rays and st.scene_in_lds == (0 if force_global else 1)
         finally:
             c.close()
+
+
+def _box_rays(O, scene, boxes, seed):
+    """Random rays in the room, rays that START INSIDE every box (the triangles are two-sided: they meet the far face from within), and rays from
+    the eye and from random points aimed at every box's corners, edge midpoints and face centres."""
+    rng = np.random.default_rng(seed)
+    parts = [_rays(O, 30000, seed, hi=(0.95, 1.9, 1.5))]
+    eye = np.array(O.EYE, np.float32)
+    for row in boxes:
+        c, A = row[2:5].astype(np.float64), row[5:14].reshape(3, 3).astype(np.float64)
+        H = np.linalg.inv(A)                                            # columns: the half axes
+        inside = _rays(O, 600, seed + 1)
+        inside["origin"] = (c + (H @ rng.uniform(-0.95, 0.95, (3, 600))).T).astype(np.float32)
+        grid = np.array([[x, y, z] for x in (-1, 0, 1) for y in (-1, 0, 1) for z in (-1, 0, 1) if (x, y, z) != (0, 0, 0)], np.float64)
+        targets = (c + (H @ grid.T).T).astype(np.float32)               # 8 corners, 12 edge midpoints, 6 face centres
+        aimed = np.zeros(2 * len(targets), O.RAY_DTYPE)
+        org = np.concatenate([np.tile(eye, (len(targets), 1)), rng.uniform((-0.9, 0.1, -0.9), (0.9, 1.9, 2.5), (len(targets), 3)).astype(np.float32)])
+        d = np.concatenate([targets, targets]) - org
+        aimed["origin"], aimed["direction"] = org, (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+        aimed["mask"], aimed["maxDistance"] = 3, np.inf
+        parts += [inside, aimed]
+    return np.concatenate(parts)
+
+
+def test_box_leaves(capi, O, monkeypatch):
+    """Round 5: addCube's twelve triangles as ONE leaf of a scene staged in LDS (bvh_build.h kLeafBox; tests/util.py box_zoo: rotated, sheared,
+    mirrored, nested, emissive, material-3 cubes and an almost-cube).  The strict build tests the twelve triangles of such a leaf and stays
+    bit-identical to the oracle -- records, any-hit answers, the image with its ray counts --; the shipped build does one slab test in the
+    box's own frame and may differ from the oracle only where double precision says fp32 cannot decide (rays that graze an edge or meet
+    two coincident faces), hit distances and weights to 3e-6 / 2e-5 elsewhere, the image within the stated tolerance.  Switched off
+    (TRG_BVH_BOXES=0) the same scene gives the same strict bits and clearly more primitive tests per ray: the leaves are really in use."""
+    from tests.util import box_zoo
+    scene, n_boxes = box_zoo(O)
+    b = scene.buffers()
+    boxes = capi.debug_boxes(b["positions"], b["indices"], b["material_ids"])
+    assert boxes.shape[0] == n_boxes
+    rays = _box_rays(O, scene, boxes, 55)
+    ref = O.intersect_nearest(scene, rays, brute=True)
+    ref_any = O.intersect_any(scene, rays) >= 0
+    _, _, margin = O.nearest_f64(scene, rays)
+    undecidable = margin < 1e-5
+    assert undecidable.mean() < 0.05 and (ref["primitiveIndex"] >= 36).mean() > 0.05       # the extra boxes are hit by thousands of these rays, and decidably
+    w, h, spp, bnc = 64, 48, 6, 4
+    off = O.pixel_offsets(w, h)
+    O.set_trig_mode(O.TRIG_PORTABLE)
+    try:
+        img_ref, rst = O.render(scene, w, h, spp, bnc, offsets=off)
+    finally:
+        O.set_trig_mode(O.TRIG_LIBM)
+    img_libm, _ = O.render(scene, w, h, spp, bnc, offsets=off)
+    tests = {}
+    for switch in ("1", "0"):
+        monkeypatch.setenv("TRG_BVH_BOXES", switch)
+        c = capi.Context(w, h)
+        try:
+            c.load_scene(b["positions"], b["normals"], b["colors"], b["indices"], b["material_ids"])
+            c.set_uniforms(O.uniforms_bytes(O.make_uniforms(w, h)))
+            c.set_pixel_offsets(off)
+            assert c.stats().scene_in_lds == 1
+            c.set_option(capi.OPT_STRICT, 1)
+            assert np.array_equal(c.trace(rays).view(np.uint8), ref.view(np.uint8)), "strict nearest-hit differs from the oracle (boxes %s)" % switch
+            assert np.array_equal(c.trace(rays, any_hit=True) >= 0, ref_any)
+            c.reset_stats()
+            c.render(0, spp, bnc)
+            assert np.array_equal(_bits(c.read_accum()), _bits(img_ref)) and c.stats().rays == rst.rays
+            c.set_option(capi.OPT_STRICT, 0)
+            fast = c.trace(rays)
+            diff = fast["primitiveIndex"] != ref["primitiveIndex"]
+            assert not (diff & ~undecidable).any(), "boxes %s: %d decidable rays picked another primitive" % (switch, int((diff & ~undecidable).sum()))
+            same = ~diff & (ref["primitiveIndex"] >= 0)
+            np.testing.assert_allclose(fast["distance"][same], ref["distance"][same], rtol=3e-6, atol=3e-6)
+            # the weights say WHERE on the triangle the hit lies: the point they name must be the oracle's to 1e-5 of the room's size, and the
+            # weights themselves to 2e-5 on a triangle of the room's size -- 1e-5 / (shortest edge) on the zoo's 10 cm cubes, where the same
+            # few ulps of position are a larger share of the triangle
+            T = b["positions"].reshape(-1, 3, 3)[ref["primitiveIndex"][same]].astype(np.float64)
+            uvf, uvr = fast["coordinates"][same].astype(np.float64), ref["coordinates"][same].astype(np.float64)
+            point = lambda uv: T[:, 0] + uv[:, :1] * (T[:, 1] - T[:, 0]) + uv[:, 1:] * (T[:, 2] - T[:, 0])
+            assert np.abs(point(uvf) - point(uvr)).max() < 1e-5
+            edge = np.minimum(np.linalg.norm(T[:, 1] - T[:, 0], axis=1), np.linalg.norm(T[:, 2] - T[:, 0], axis=1))
+            assert (np.abs(uvf - uvr).max(1) <= np.maximum(2e-5, 1e-5 / edge)).all()
+            fast_any = c.trace(rays, any_hit=True) >= 0
+            assert (fast_any != ref_any).mean() < 2e-3
+            c.set_option(capi.OPT_COUNTERS, 1)
+            c.reset_stats()
+            c.render(0, spp, bnc)
+            st = c.stats()
+            tests[switch] = (st.tri_tests / st.rays, st.node_fetches / st.rays)
+            rmse, frac_ok, _ = image_metrics(c.read_accum(), img_libm)
+            assert rmse <= TOL_RMSE and frac_ok >= 1.0 - edge_flip_allowance(w * h, st.rays) / (w * h), (switch, rmse, frac_ok)
+        finally:
+            c.close()
+    # the box leaves are in use: fewer primitive tests per ray (one per box where a cube took one or two quads) and fewer node steps (no subtree)
+    assert tests["1"][0] < tests["0"][0] and tests["1"][1] < 0.97 * tests["0"][1], tests
 
 
 @pytest.mark.parametrize("n,seed,gpu_build", [(300, 1, 0), (300, 2, 1), (3000, 3, 0), (3000, 4, 1), (3000, 5, 2), (3000, 6, 3), (2, 7, 1), (5, 8, 1)])

@@ -321,6 +321,68 @@ def test_builder_pairs_parallelograms_into_quad_leaves(built, O):
         assert len(_quad_leaves(capi.debug_build_bvh(bf["positions"], bf["indices"], bf["material_ids"])[0])) == scene.ntris // 2
 
 
+def test_builder_finds_parallelepipeds_and_keeps_the_tree_sound(built, O):
+    """Round 5, BOX leaves (bvh_build.h kLeafBox): twelve consecutive triangles that are six quads bounding a parallelepiped -- Scene::addCube --
+    are ONE primitive of the split rule and end up as one subtree of six quad leaves over twelve consecutive records; the builder reports
+    the subtree's root, the parallelepiped's frame and which quad is which face.  tests/util.py box_zoo: rotated, sheared, mirrored, nested,
+    emissive cubes are found, an almost-cube is not; with the boxes the BVH2 and its 4-wide collapse still reach every triangle exactly once."""
+    from toyraygun_amd import capi
+    from tests.util import box_zoo
+    scene, n_boxes = box_zoo(O)
+    b = scene.buffers()
+    boxes = capi.debug_boxes(b["positions"], b["indices"], b["material_ids"])
+    assert boxes.shape == (n_boxes, 20)
+    os.environ["TRG_DEBUG_BVH_BOXES"] = "1"
+    try:
+        nodes, tris, depth = capi.debug_build_bvh(b["positions"], b["indices"], b["material_ids"])
+        nodes4, depth4 = capi.debug_build_bvh4(b["positions"], b["indices"], b["material_ids"])
+        assert (_walk(nodes, tris, scene.ntris)[0] == 1).all()
+        lat = O.OracleScene.cornell_lattice(4).buffers()
+        ln, lt, _ = capi.debug_build_bvh(lat["positions"], lat["indices"], lat["material_ids"])
+        assert (_walk(ln, lt, len(lat["material_ids"]))[0] == 1).all()
+        assert capi.debug_boxes(lat["positions"], lat["indices"], lat["material_ids"]).shape[0] == 4 ** 3 + 2
+    finally:
+        del os.environ["TRG_DEBUG_BVH_BOXES"]
+    prim_of = tris[:, 3:4].copy().view(np.int32)[:, 0]
+    firsts = set()
+    for row in boxes:
+        node, first = int(row[0]), int(row[1])
+        c, A = row[2:5].astype(np.float64), row[5:14].reshape(3, 3).astype(np.float64)
+        prims = np.sort(prim_of[first:first + 12])
+        assert np.array_equal(prims, np.arange(prims[0], prims[0] + 12)) and prims[0] % 2 == 0      # twelve consecutive triangles
+        firsts.add(int(prims[0]))
+        for r in range(first, first + 12):                       # every corner of the twelve sits at (+-1, +-1, +-1) of the frame
+            v0, e1, e2 = tris[r, 0:3].astype(np.float64), tris[r, 4:7].astype(np.float64), tris[r, 8:11].astype(np.float64)
+            for P in (v0, v0 + e1, v0 + e2):
+                assert np.allclose(np.abs(A @ (P - c)), 1.0, atol=2e-5)
+        for f in range(6):                                       # ... and face f = 2 k + (l_k > 0) names the quad that lies on that side
+            k, side = f // 2, (1.0 if f % 2 else -1.0)
+            off = int(row[14 + f])
+            assert off % 2 == 0 and 0 <= off <= 10
+            for r in (first + off, first + off + 1):
+                v0, e1, e2 = tris[r, 0:3].astype(np.float64), tris[r, 4:7].astype(np.float64), tris[r, 8:11].astype(np.float64)
+                for P in (v0, v0 + e1, v0 + e2):
+                    assert abs((A @ (P - c))[k] - side) < 2e-5
+        assert sorted(int(row[14 + f]) for f in range(6)) == [0, 2, 4, 6, 8, 10]
+        # the subtree under `node` holds exactly the six quad leaves of these records
+        leaves, st = [], [node]
+        while st:
+            for ref in nodes[st.pop(), 12:14].copy().view(np.int32):
+                if ref >= 0:
+                    st.append(int(ref))
+                else:
+                    leaves.append((~int(ref)) >> 3)
+                    assert ((~int(ref)) & 7) == 7
+        assert sorted(leaves) == [first + 2 * j for j in range(6)]
+    assert firsts == {0, 12} | {36 + 12 * j for j in range(6)}    # the Cornell box's two cubes (triangles 0-11, 12-23: addCube comes first) and the zoo's six
+    for name in ("TRG_BVH_BOXES", "TRG_BVH_QUADS"):               # both switches off the feature (a box is made of quads)
+        os.environ[name] = "0"
+        try:
+            assert capi.debug_boxes(b["positions"], b["indices"], b["material_ids"]).shape[0] == 0
+        finally:
+            del os.environ[name]
+
+
 def test_wide_bvh_is_sound(built, O):
     """The 4-wide collapse reaches every triangle exactly once, boxes enclose their subtrees, and the stack
     bound the kernel sizes its scratch from (3 * depth + 2) holds."""

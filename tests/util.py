@@ -52,3 +52,36 @@ def make_ctx(O, scene, w, h, offsets=None, uniforms=None):
     else:
         c.set_pixel_offsets(offsets)
     return c
+
+
+def box_zoo(O):
+    """A scene that fits in LDS and exercises the BOX leaves (bvh_build.h kLeafBox): the Cornell box (two cubes standing on the floor) plus cubes that
+    are rotated, sheared (a parallelepiped), mirrored (negative scale: the vertex order flips), nested in another, emissive (material 2: seen by
+    primary rays only) and of material 3 -- seven parallelepipeds -- and one ALMOST-cube with a corner moved by 1e-3, which must stay six quads'
+    worth of triangles.  Returns (scene, number of boxes the builder must find)."""
+    unit = O.OracleScene()
+    unit.add("cube", (1.0, 1.0, 1.0), np.eye(4, dtype=np.float32))
+    verts = unit.buffers()["positions"].reshape(-1, 3).copy()          # addCube's 36 vertices in its own order (Scene.cpp:24-58)
+    idx = np.arange(36, dtype=np.uint32)
+
+    def mtx(scale, rot_y, pos, shear=0.0):
+        c, s_ = np.cos(rot_y), np.sin(rot_y)
+        r = np.array([[c, 0, s_], [0, 1, 0], [-s_, 0, c]], np.float64)
+        sh = np.eye(3); sh[0, 1] = shear                                  # x += shear * y
+        m = np.eye(4)
+        m[:3, :3] = r @ sh @ np.diag(scale)
+        m[:3, 3] = pos
+        return m.T.astype(np.float32)                                     # row-vector convention of bx (mtx[12..14] = translation)
+
+    s = O.OracleScene.cornell_box()
+    s.add_geometry(verts, idx, mtx((0.12, 0.12, 0.12), 0.7, (-0.6, 1.5, 0.5)), (0.3, 0.8, 0.4), 1)                 # rotated, floating
+    s.add_geometry(verts, idx, mtx((0.15, 0.1, 0.08), -0.3, (0.55, 1.3, -0.4), shear=0.6), (0.8, 0.5, 0.2), 1)      # sheared
+    s.add_geometry(verts, idx, mtx((-0.1, 0.14, 0.1), 1.1, (0.1, 1.6, 0.6)), (0.2, 0.4, 0.9), 1)                    # mirrored
+    s.add_geometry(verts, idx, mtx((0.05, 0.05, 0.05), 0.2, (-0.6, 1.5, 0.5)), (0.9, 0.9, 0.1), 1)                  # inside the first
+    s.add_geometry(verts, idx, mtx((0.08, 0.04, 0.08), 0.0, (-0.2, 1.85, 0.2)), (1.0, 1.0, 1.0), 2)                 # emissive
+    s.add_geometry(verts, idx, mtx((0.1, 0.1, 0.1), 0.5, (0.6, 0.1, 0.9)), (0.6, 0.6, 0.6), 3)                      # material 3, on the floor
+    almost = verts.copy()
+    corner = almost[0].copy()
+    almost[(almost == corner).all(1)] += np.float32(1e-2)                 # one corner of the unit cube off by 1e-2 (1e-3 once scaled)
+    s.add_geometry(almost, idx, mtx((0.1, 0.1, 0.1), 0.9, (-0.1, 0.9, 1.2)), (0.5, 0.2, 0.7), 1)
+    return s, 2 + 6

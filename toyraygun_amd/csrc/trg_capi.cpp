@@ -572,7 +572,9 @@ int host_scene_build(trg_ctx *c, const float *pos, const float *nrm, const float
     const auto host_t0 = std::chrono::steady_clock::now();
     Bvh bvh;
     // (boxes: only a scene that may be staged in LDS can use them -- 170 triangles at most; the switch is wider so that the answer does not hinge on it)
-    build_bvh(pos, idx, mat, n_tris, bvh, TRG_WIDE8 != 0, TRG_BOX_LEAVES && !TRG_WIDE8 && n_tris <= 1024u);
+    uint32_t box_max_tris = 1024u;
+    if (const char *e = getenv("TRG_BVH_BOXES_MAX_TRIS")) box_max_tris = (uint32_t)strtoul(e, nullptr, 10);   // (measurements: boxes as units of the split rule in larger scenes too)
+    build_bvh(pos, idx, mat, n_tris, bvh, TRG_WIDE8 != 0, TRG_BOX_LEAVES && !TRG_WIDE8 && n_tris <= box_max_tris);
     if (TRG_WIDE8 && !bvh.wide8_ok) { delete hs; return fail(c, TRG_ERR_RANGE, "trg_load_scene: the 8-wide layout of this build needs leaves of at most two records (TRG_BVH_MAXLEAF <= 2)"); }
     hs->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
     if (n_tris) {
