@@ -445,7 +445,9 @@ def run_torch(config_name, steps, warmup, env, use_imported=True, gpu_build=None
                   "sharding": ("none" if not distributed else "%s bands, 1 process/GPU, %s gather to rank 0 per frame" % ("interleaved 8-row" if r.interleaved else "contiguous row", "gloo (host memory: rehearsal)" if env.get("backend") == "gloo" else "RCCL")),
                   "pipeline": "%d frames in flight on alternating streams" % len(r.render_streams) if getattr(r, "_overlap", False) else "serial launches",
                   "kernel": kernel_name(st, in_lds), "triangles": int(len(buffers["material_ids"])), "scene_bytes": int(cst.scene_bytes),
-                  "builder": builder, "build_ms": sig(cst.last_build_ms), "load_scene_s": sig(load_s), "bvh_depth4": int(cst.bvh_depth4), "nodes4": int(cst.bvh_nodes4)}
+                  "builder": builder, "build_ms": sig(cst.last_build_ms), "load_scene_s": sig(load_s), "bvh_depth4": int(cst.bvh_depth4), "nodes4": int(cst.bvh_nodes4),
+                  # geometry-specific leaves, said next to the number: parallelogram pairs tested as one quad, addCube groups that are one box leaf (LDS scenes)
+                  "quads": int(cst.bvh_quads), "box_leaves": int(cst.bvh_boxes)}
         if gather:
             config.update({"exchange": "root gather" if r.gather_mode == "root" else "all-gather",
                            "gather_root_ms_per_step": sig(max(0.0, (dt - dt_none) / steps * 1e3)), "gather_all_ms_per_step": sig(max(0.0, (dt_all - dt_none) / steps * 1e3)),

@@ -45,6 +45,7 @@ class Stats(C.Structure):
         ("last_build_ms", C.c_double),
         ("gpu_built", C.c_uint32), ("bvh_nodes4", C.c_uint32), ("bvh_depth4", C.c_uint32), ("last_frame_split", C.c_uint32),
         ("last_tail_bounce", C.c_uint32), ("last_kernel", C.c_uint32), ("last_regen", C.c_uint32), ("last_tile_order", C.c_uint32),
+        ("bvh_quads", C.c_uint32), ("bvh_boxes", C.c_uint32),
     ]
 
     @property

@@ -72,7 +72,7 @@ struct trg_ctx {
     uint32_t last_xcd_cols = 0;
     double last_build_ms = 0.0;
     bool gpu_built = false;
-    uint32_t bvh_nodes = 0, bvh_depth = 0, bvh_leaves = 0;
+    uint32_t bvh_nodes = 0, bvh_depth = 0, bvh_leaves = 0, bvh_quads = 0, bvh_boxes = 0;
     double last_ms = 0.0, total_ms = 0.0;
     uint32_t renders = 0;
     uint32_t last_fsplit = 1;
@@ -446,7 +446,7 @@ static int load_scene_gpu_build(trg_ctx *c, const float *pos, const float *nrm, 
     HIPCHK(c, hipStreamSynchronize(c->stream));
     sc.blob = c->blob;
     c->sc = sc;
-    c->bvh_nodes = 0; c->bvh_depth = 2 * depth4; c->bvh_leaves = n_tris;
+    c->bvh_nodes = 0; c->bvh_depth = 2 * depth4; c->bvh_leaves = n_tris; c->bvh_quads = 0; c->bvh_boxes = 0;   // (device builds: the quads are paired on the device, not counted)
     c->bvh_nodes4 = n4; c->bvh_depth4 = depth4;
     c->scene_loaded = true;
     LdsPlan plan;
@@ -461,7 +461,7 @@ namespace trg {
 struct HostScene {
     std::vector<unsigned char> blob;   // the image of the device allocation (plan_scene_layout)
     SceneDesc sc{};                    // offsets; sc.blob is filled in per context
-    uint32_t bvh_nodes = 0, bvh_depth = 0, bvh_leaves = 0, bvh_nodes4 = 0, bvh_depth4 = 0;
+    uint32_t bvh_nodes = 0, bvh_depth = 0, bvh_leaves = 0, bvh_nodes4 = 0, bvh_depth4 = 0, bvh_quads = 0, bvh_boxes = 0;
     double build_ms = 0.0;
     float lo[3] = { 0.f, 0.f, 0.f }, hi[3] = { 1.f, 1.f, 1.f };   // bounds of the triangles
 };
@@ -747,6 +747,7 @@ int host_scene_build(trg_ctx *c, const float *pos, const float *nrm, const float
 
     hs->sc = sc;
     hs->bvh_nodes = bvh.n_nodes; hs->bvh_depth = bvh.depth; hs->bvh_leaves = bvh.n_leaves;
+    hs->bvh_quads = bvh.n_quads; hs->bvh_boxes = lds_candidate ? (uint32_t)bvh.boxes.size() : 0u;
     hs->bvh_nodes4 = TRG_WIDE8 ? bvh.n_nodes8 : bvh.n_nodes4; hs->bvh_depth4 = TRG_WIDE8 ? bvh.depth8 : bvh.depth4;
     *out = hs;
     return TRG_OK;
@@ -768,6 +769,7 @@ int host_scene_upload(trg_ctx *c, const HostScene *hs) {
     for (int a = 0; a < 3; ++a) { c->scene_lo[a] = hs->lo[a]; c->scene_hi[a] = hs->hi[a]; }
     c->gpu_built = false;
     c->bvh_nodes = hs->bvh_nodes; c->bvh_depth = hs->bvh_depth; c->bvh_leaves = hs->bvh_leaves;
+    c->bvh_quads = hs->bvh_quads; c->bvh_boxes = hs->bvh_boxes;
     c->bvh_nodes4 = hs->bvh_nodes4; c->bvh_depth4 = hs->bvh_depth4;
     c->scene_loaded = true;
     LdsPlan plan;
@@ -1150,6 +1152,7 @@ int trg_get_stats(trg_ctx *c, trg_stats *out) {
     out->wave_node_iters = sum[6]; out->wave_tri_iters = sum[7];
     out->last_render_ms = c->last_ms; out->total_render_ms = c->total_ms; out->renders = c->renders;
     out->bvh_nodes = c->bvh_nodes; out->bvh_depth = c->bvh_depth; out->bvh_leaves = c->bvh_leaves;
+    out->bvh_quads = c->bvh_quads; out->bvh_boxes = c->bvh_boxes;
     out->scene_bytes = c->sc.blob_bytes;
     out->last_build_ms = c->last_build_ms; out->gpu_built = c->gpu_built ? 1u : 0u;
     out->bvh_nodes4 = c->bvh_nodes4; out->bvh_depth4 = c->bvh_depth4;
