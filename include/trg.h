@@ -83,8 +83,8 @@ typedef struct trg_stats {
     uint32_t last_regen;       /* 1: the last trg_render ran the path-regeneration megakernel (TRG_OPT_REGEN) */
     uint32_t last_tile_order;  /* the workgroup -> tile order of the last trg_render: 0 = image columns, 1/2/4/8 = XCD regions (TRG_OPT_TILE_ORDER) */
     uint32_t bvh_quads;        /* host build: pairs of triangles the builder found to be parallelograms (one test each in the shipped build) */
-    uint32_t bvh_boxes;        /* ... and groups of six such quads that bound a parallelepiped and are ONE leaf of the LDS node array (0 for a scene
-                                  that is not staged in LDS: there the six quads stay a subtree) */
+    uint32_t bvh_boxes;        /* ... and groups of six such quads that bound a parallelepiped and are ONE leaf of the tree the shipped build walks: twelve
+                                  triangle tests in the strict build (LDS node array; the strict HBM tree keeps the subtree), one slab test in the shipped one */
 } trg_stats;
 
 enum trg_option {

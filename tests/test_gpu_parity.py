@@ -513,41 +513,49 @@ def test_box_leaves(capi, O, monkeypatch):
             c.load_scene(b["positions"], b["normals"], b["colors"], b["indices"], b["material_ids"])
             c.set_uniforms(O.uniforms_bytes(O.make_uniforms(w, h)))
             c.set_pixel_offsets(off)
-            assert c.stats().scene_in_lds == 1
-            c.set_option(capi.OPT_STRICT, 1)
-            assert np.array_equal(c.trace(rays).view(np.uint8), ref.view(np.uint8)), "strict nearest-hit differs from the oracle (boxes %s)" % switch
-            assert np.array_equal(c.trace(rays, any_hit=True) >= 0, ref_any)
-            c.reset_stats()
-            c.render(0, spp, bnc)
-            assert np.array_equal(_bits(c.read_accum()), _bits(img_ref)) and c.stats().rays == rst.rays
-            c.set_option(capi.OPT_STRICT, 0)
-            fast = c.trace(rays)
-            diff = fast["primitiveIndex"] != ref["primitiveIndex"]
-            assert not (diff & ~undecidable).any(), "boxes %s: %d decidable rays picked another primitive" % (switch, int((diff & ~undecidable).sum()))
-            same = ~diff & (ref["primitiveIndex"] >= 0)
-            np.testing.assert_allclose(fast["distance"][same], ref["distance"][same], rtol=3e-6, atol=3e-6)
-            # the weights say WHERE on the triangle the hit lies: the point they name must be the oracle's to 1e-5 of the room's size, and the
-            # weights themselves to 2e-5 on a triangle of the room's size -- 1e-5 / (shortest edge) on the zoo's 10 cm cubes, where the same
-            # few ulps of position are a larger share of the triangle
-            T = b["positions"].reshape(-1, 3, 3)[ref["primitiveIndex"][same]].astype(np.float64)
-            uvf, uvr = fast["coordinates"][same].astype(np.float64), ref["coordinates"][same].astype(np.float64)
-            point = lambda uv: T[:, 0] + uv[:, :1] * (T[:, 1] - T[:, 0]) + uv[:, 1:] * (T[:, 2] - T[:, 0])
-            assert np.abs(point(uvf) - point(uvr)).max() < 1e-5
-            edge = np.minimum(np.linalg.norm(T[:, 1] - T[:, 0], axis=1), np.linalg.norm(T[:, 2] - T[:, 0], axis=1))
-            assert (np.abs(uvf - uvr).max(1) <= np.maximum(2e-5, 1e-5 / edge)).all()
-            fast_any = c.trace(rays, any_hit=True) >= 0
-            assert (fast_any != ref_any).mean() < 2e-3
-            c.set_option(capi.OPT_COUNTERS, 1)
-            c.reset_stats()
-            c.render(0, spp, bnc)
-            st = c.stats()
-            tests[switch] = (st.tri_tests / st.rays, st.node_fetches / st.rays)
-            rmse, frac_ok, _ = image_metrics(c.read_accum(), img_libm)
-            assert rmse <= TOL_RMSE and frac_ok >= 1.0 - edge_flip_allowance(w * h, st.rays) / (w * h), (switch, rmse, frac_ok)
+            assert c.stats().scene_in_lds == 1 and c.stats().bvh_boxes == (n_boxes if switch == "1" else 0)
+            for force_global in (0, 1):      # the tree staged in LDS, and the same scene traversed from HBM (the shipped build has box leaves in both)
+                c.set_option(capi.OPT_FORCE_GLOBAL, force_global)
+                tag = (switch, force_global)
+                c.set_option(capi.OPT_STRICT, 1)
+                assert np.array_equal(c.trace(rays).view(np.uint8), ref.view(np.uint8)), "strict nearest-hit differs from the oracle %s" % (tag,)
+                assert np.array_equal(c.trace(rays, any_hit=True) >= 0, ref_any)
+                c.reset_stats()
+                c.render(0, spp, bnc)
+                assert np.array_equal(_bits(c.read_accum()), _bits(img_ref)) and c.stats().rays == rst.rays
+                c.set_option(capi.OPT_STRICT, 0)
+                fast = c.trace(rays)
+                diff = fast["primitiveIndex"] != ref["primitiveIndex"]
+                assert not (diff & ~undecidable).any(), "%s: %d decidable rays picked another primitive" % (tag, int((diff & ~undecidable).sum()))
+                same = ~diff & (ref["primitiveIndex"] >= 0)
+                np.testing.assert_allclose(fast["distance"][same], ref["distance"][same], rtol=3e-6, atol=3e-6)
+                # the weights say WHERE on the triangle the hit lies: the point they name must be the oracle's to 1e-5 of the room's size, and the
+                # weights themselves to 2e-5 on a triangle of the room's size -- 1e-5 / (shortest edge) on the zoo's 10 cm cubes, where the same
+                # few ulps of position are a larger share of the triangle
+                T = b["positions"].reshape(-1, 3, 3)[ref["primitiveIndex"][same]].astype(np.float64)
+                uvf, uvr = fast["coordinates"][same].astype(np.float64), ref["coordinates"][same].astype(np.float64)
+                point = lambda uv: T[:, 0] + uv[:, :1] * (T[:, 1] - T[:, 0]) + uv[:, 1:] * (T[:, 2] - T[:, 0])
+                assert np.abs(point(uvf) - point(uvr)).max() < 1e-5, tag
+                edge = np.minimum(np.linalg.norm(T[:, 1] - T[:, 0], axis=1), np.linalg.norm(T[:, 2] - T[:, 0], axis=1))
+                assert (np.abs(uvf - uvr).max(1) <= np.maximum(2e-5, 1e-5 / edge)).all(), tag
+                fast_any = c.trace(rays, any_hit=True) >= 0
+                assert (fast_any != ref_any).mean() < 2e-3
+                for regen in ((-1,) if not force_global else (0, 1)):      # (HBM: the lock-step megakernel and path regeneration)
+                    c.set_option(capi.OPT_REGEN, regen)
+                    c.set_option(capi.OPT_COUNTERS, 1)
+                    c.reset_stats()
+                    c.render(0, spp, bnc)
+                    st = c.stats()
+                    tests[tag] = (st.tri_tests / st.rays, st.node_fetches / st.rays)
+                    rmse, frac_ok, _ = image_metrics(c.read_accum(), img_libm)
+                    assert rmse <= TOL_RMSE and frac_ok >= 1.0 - edge_flip_allowance(w * h, st.rays) / (w * h), (tag, regen, rmse, frac_ok)
+                    c.set_option(capi.OPT_COUNTERS, 0)
+                c.set_option(capi.OPT_REGEN, -1)
         finally:
             c.close()
     # the box leaves are in use: fewer primitive tests per ray (one per box where a cube took one or two quads) and fewer node steps (no subtree)
-    assert tests["1"][0] < tests["0"][0] and tests["1"][1] < 0.97 * tests["0"][1], tests
+    for fg in (0, 1):
+        assert tests[("1", fg)][0] < tests[("0", fg)][0] and tests[("1", fg)][1] < 0.97 * tests[("0", fg)][1], tests
 
 
 @pytest.mark.parametrize("n,seed,gpu_build", [(300, 1, 0), (300, 2, 1), (3000, 3, 0), (3000, 4, 1), (3000, 5, 2), (3000, 6, 3), (2, 7, 1), (5, 8, 1)])

@@ -479,6 +479,22 @@ def test_host_builder_under_sanitizers():
         assert "n=200000" in r.stdout and "ERROR" not in r.stderr and "runtime error" not in r.stderr and "WARNING: ThreadSanitizer" not in r.stderr
 
 
+def test_box_flavour_of_the_wide_tree_under_sanitizers():
+    """The second 4-wide collapse (shipped build, scenes traversed from HBM): every box -- and every lone quad, dressed as a box of no thickness --
+    is a leaf addressed like a record behind the records.  tests/helpers/box_tree_check.cpp builds 1 ... 9,000 cubes + a lone triangle + two lone
+    quads (threaded above 65,536 triangles) under -fsanitize=address,undefined and checks that every child code is in range and every leaf
+    record is reached exactly once through exactly one leaf."""
+    import tempfile
+    csrc = os.path.join(ROOT, "toyraygun_amd", "csrc")
+    with tempfile.TemporaryDirectory() as td:
+        exe = os.path.join(td, "boxcheck")
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-pthread", "-fno-omit-frame-pointer",
+                               "-I" + csrc, os.path.join(ROOT, "tests", "helpers", "box_tree_check.cpp"), os.path.join(csrc, "bvh_build.cpp"), "-o", exe])
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, TRG_BVH_THREADS="4"))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2000:])
+    assert r.stdout.count("every record once: yes") == 5 and "ERROR" not in r.stderr and "runtime error" not in r.stderr
+
+
 def test_threaded_host_build_is_identical_to_the_single_threaded_one(built):
     """Worker threads build disjoint subtrees of the same tree: node arrays, triangle order and quantised nodes are the
     same bits for 1 and 5 threads (run in child processes: the thread count is read from the environment at build time)."""

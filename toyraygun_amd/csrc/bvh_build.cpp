@@ -475,17 +475,34 @@ void build_bvh(const float *pos, const uint32_t *idx, const uint32_t *masks, uin
     }
 
     out.boxes.clear();
+    std::vector<int32_t> box_node_of_out;   // per entry of out.boxes: the build node that is its subtree's root
     for (uint32_t i = 0; i < n_prims && !synth_root; ++i) {
         const uint32_t b = B.prims[i].box;
         if (b == ~0u || box_root_node[b] < 0 || dev_index[(size_t)box_root_node[b]] < 0) continue;
         BoxLeaf bl;
+        box_node_of_out.push_back(box_root_node[b]);
         bl.node = (uint32_t)dev_index[(size_t)box_root_node[b]];
         bl.first_rec = rec_first[i];
         for (int a = 0; a < 3; ++a) { bl.center[a] = (float)box_geom[b].c[a]; for (int k = 0; k < 3; ++k) bl.axis[k][a] = (float)box_geom[b].a[k][a]; }
+        bl.mask = masks[B.prims[i].id];
         for (int f = 0; f < 6; ++f) {
-            bl.face_rec[f] = 0;
-            for (uint32_t j = 0; j < 6; ++j)
-                if (box_quads[b][j].q == box_geom[b].face_quad[f]) bl.face_rec[f] = (uint8_t)(2u * j);
+            bl.face_rec[f] = 0; bl.face_bits[f] = 0;
+            for (uint32_t j = 0; j < 6; ++j) {
+                if (box_quads[b][j].q != box_geom[b].face_quad[f]) continue;
+                bl.face_rec[f] = (uint8_t)(2u * j);
+                // the quad's own parameters in the box's frame: X.e1 and Y.e2 run along the two axes other than the face's
+                const uint32_t x = box_quads[b][j].x, y = box_quads[b][j].y;
+                const int kx = f / 2, ia = kx == 0 ? 1 : 0, ja = kx == 2 ? 1 : 2;   // i < j, both != kx
+                double l1[3] = { 0, 0, 0 }, l2[3] = { 0, 0, 0 };
+                for (int ax = 0; ax < 3; ++ax)
+                    for (int a = 0; a < 3; ++a) {
+                        l1[ax] += box_geom[b].a[ax][a] * ((double)vtx(x, 1)[a] - (double)vtx(x, 0)[a]);
+                        l2[ax] += box_geom[b].a[ax][a] * ((double)vtx(y, 2)[a] - (double)vtx(y, 0)[a]);
+                    }
+                const bool swap = std::fabs(l1[ja]) > std::fabs(l1[ia]);                // s runs along l_j
+                const double ds = swap ? l1[ja] : l1[ia], dt = swap ? l2[ia] : l2[ja];
+                bl.face_bits[f] = (uint8_t)((swap ? 1u : 0u) | (ds < 0 ? 2u : 0u) | (dt < 0 ? 4u : 0u));
+            }
         }
         out.boxes.push_back(bl);
     }
@@ -494,6 +511,53 @@ void build_bvh(const float *pos, const uint32_t *idx, const uint32_t *masks, uin
     //      largest surface area first, until it has four children.  Same leaves, same triangle records. ----
     constexpr int32_t kEmpty = (int32_t)0x80000000;
     struct Wide { int32_t child[4]; Box box[4]; };
+    // Two flavours of the same collapse: the plain one (what the strict build and the tests see), and -- if the scene has boxes -- one in which the
+    // root of a box's subtree is a LEAF whose code carries the index of its BoxLeaf (the shipped build's HBM traversal, trav_step_wide)
+    std::vector<int32_t> box_of_node(B.nodes.size(), -1);
+    for (size_t b = 0; b < out.boxes.size(); ++b) box_of_node[(size_t)box_node_of_out[b]] = (int32_t)b;
+    out.n_boxes_real = (uint32_t)out.boxes.size();
+    // ... and in that flavour a LONE QUAD is a box too, one of no thickness (half thickness 2^-30 of its longer edge: the two slab planes round to
+    // the quad's own plane), so that a scene made of quads and cubes -- the reference's Scene API makes nothing else -- never runs the triangle
+    // half of the unified step: frame rows 0, 1 = the quad's own (s, t) scaled to [-1, 1], row 2 = the unit normal over the half thickness; every
+    // face names the quad's X record.  (BoxLeaf::node = ~0u: nothing the LDS layout could match.)
+    if (!out.boxes.empty() && !synth_root) {
+        for (size_t bn = 0; bn < B.nodes.size(); ++bn) {
+            const BuildNode &n = B.nodes[bn];
+            if (!n.leaf || n.count != 1u || n.boxprim != ~0u || dev_index.size() <= bn) continue;
+            const Prim &pr = B.prims[n.first];
+            if (pr.id2 == ~0u || pr.box != ~0u) continue;
+            const uint32_t r0 = rec_first[n.first];
+            const F4 *X = &out.tris[(size_t)r0 * 3], *Y = &out.tris[(size_t)(r0 + 1) * 3];
+            const double p0[3] = { X[0].x, X[0].y, X[0].z }, e1[3] = { X[1].x, X[1].y, X[1].z }, e2[3] = { Y[2].x, Y[2].y, Y[2].z };
+            auto cross = [](const double *u, const double *v, double *o) { o[0] = u[1] * v[2] - u[2] * v[1]; o[1] = u[2] * v[0] - u[0] * v[2]; o[2] = u[0] * v[1] - u[1] * v[0]; };
+            auto dot = [](const double *u, const double *v) { return u[0] * v[0] + u[1] * v[1] + u[2] * v[2]; };
+            double nn[3], c1[3], c2[3];
+            cross(e1, e2, nn);
+            const double len = std::sqrt(dot(nn, nn)), size = std::sqrt(std::max(dot(e1, e1), dot(e2, e2)));
+            if (!(len > 0.0) || !std::isfinite(len) || !(size > 0.0)) continue;
+            for (int a = 0; a < 3; ++a) nn[a] /= len;
+            cross(e2, nn, c1); cross(nn, e1, c2);
+            const double s1 = dot(e1, c1), s2 = dot(e2, c2), eh = size * (1.0 / 1073741824.0);   // 2^-30: in fp32 the slab's two planes ARE the quad's plane (-lo_2 -+ 1 rounds to -lo_2), so t is the plane test's t
+            if (s1 == 0.0 || s2 == 0.0) continue;
+            BoxLeaf bl;
+            bl.node = ~0u; bl.first_rec = r0; bl.mask = masks[pr.id];
+            for (int a = 0; a < 3; ++a) {
+                bl.center[a] = (float)(p0[a] + 0.5 * (e1[a] + e2[a]));
+                bl.axis[0][a] = (float)(2.0 * c1[a] / s1); bl.axis[1][a] = (float)(2.0 * c2[a] / s2); bl.axis[2][a] = (float)(nn[a] / eh);
+            }
+            bool finite = true;
+            for (int k = 0; k < 3; ++k) for (int a = 0; a < 3; ++a) finite = finite && std::isfinite(bl.axis[k][a]);
+            if (!finite) continue;
+            for (int f = 0; f < 6; ++f) { bl.face_rec[f] = 0; bl.face_bits[f] = 0; }
+            box_of_node[bn] = (int32_t)out.boxes.size();
+            out.boxes.push_back(bl);
+        }
+    }
+    out.nodes4q_box.clear(); out.n_nodes4_box = 0; out.depth4_box = 0;
+    const bool root_is_box = !synth_root && root >= 0 && box_of_node[(size_t)root] >= 0;
+    for (int flavour = 0; flavour < ((out.boxes.empty() || synth_root || root_is_box) ? 1 : 2); ++flavour) {
+    const bool box_flavour = flavour == 1;
+    auto leaf_like = [&](int32_t bn) { return B.nodes[(size_t)bn].leaf || (box_flavour && box_of_node[(size_t)bn] >= 0); };
     std::vector<Wide> wide;
     uint32_t wdepth = 0;
     if (synth_root) {
@@ -523,7 +587,7 @@ void build_bvh(const float *pos, const uint32_t *idx, const uint32_t *masks, uin
             while (nch < 4) {
                 int best = -1; float best_area = -1.f;
                 for (int k = 0; k < nch; ++k)
-                    if (!B.nodes[ch[k]].leaf) { const float a = B.nodes[ch[k]].box.half_area(); if (a > best_area) { best_area = a; best = k; } }
+                    if (!leaf_like(ch[k])) { const float a = B.nodes[ch[k]].box.half_area(); if (a > best_area) { best_area = a; best = k; } }
                 if (best < 0) break;
                 const int32_t open = ch[best];
                 ch[best] = B.nodes[open].child[0];
@@ -534,7 +598,10 @@ void build_bvh(const float *pos, const uint32_t *idx, const uint32_t *masks, uin
             for (int k = 0; k < nch; ++k) {
                 const BuildNode &c = B.nodes[ch[k]];
                 w.box[k] = padded(c.box);
-                if (c.leaf) {
+                if (box_flavour && box_of_node[(size_t)ch[k]] >= 0) {
+                    // (the index of its BoxLeaf BEHIND the leaf records: the traversal addresses box b like record nrec + b, bvh_build.h)
+                    w.child[k] = ~(int32_t)((((uint32_t)(out.tris.size() / 3) + (uint32_t)box_of_node[(size_t)ch[k]]) << 3) | kLeafBox);
+                } else if (c.leaf) {
                     w.child[k] = leaf_of(c);
                 } else {
                     w.child[k] = (int32_t)wide.size();
@@ -545,12 +612,10 @@ void build_bvh(const float *pos, const uint32_t *idx, const uint32_t *masks, uin
             wide[it.wi] = w;
         }
     }
-    out.n_nodes4 = (uint32_t)wide.size();
-    out.depth4 = wdepth;
-    out.nodes4.assign((size_t)out.n_nodes4 * 8, F4{ 0, 0, 0, 0 });
+    std::vector<F4> nodes4f((size_t)wide.size() * 8, F4{ 0, 0, 0, 0 });
     for (size_t i = 0; i < wide.size(); ++i) {
         const Wide &w = wide[i];
-        F4 *n = &out.nodes4[i * 8];
+        F4 *n = &nodes4f[i * 8];
         float v[6][4];
         for (int k = 0; k < 4; ++k) {
             const bool e = w.child[k] == kEmpty;
@@ -561,8 +626,11 @@ void build_bvh(const float *pos, const uint32_t *idx, const uint32_t *masks, uin
         n[7] = F4{ 0.f, 0.f, 0.f, 0.f };
     }
 
-    out.nodes4q.assign((size_t)out.n_nodes4 * 16, 0u);
-    for (size_t i = 0; i < wide.size(); ++i) quantize_node4(&out.nodes4[i * 8].x, &out.nodes4q[i * 16]);
+    std::vector<uint32_t> nodes4q((size_t)wide.size() * 16, 0u);
+    for (size_t i = 0; i < wide.size(); ++i) quantize_node4(&nodes4f[i * 8].x, &nodes4q[i * 16]);
+    if (!box_flavour) { out.n_nodes4 = (uint32_t)wide.size(); out.depth4 = wdepth; out.nodes4.swap(nodes4f); out.nodes4q.swap(nodes4q); }
+    else { out.n_nodes4_box = (uint32_t)wide.size(); out.depth4_box = wdepth; out.nodes4q_box.swap(nodes4q); }
+    }   // (flavours)
 
     // ---- 8-wide compressed collapse (q8node.h; TRG_WIDE8 builds) ----
     out.nodes8.clear(); out.rec8.clear(); out.rec8_flags.clear(); out.n_nodes8 = 0; out.depth8 = 0; out.wide8_ok = false;

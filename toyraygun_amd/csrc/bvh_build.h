@@ -48,6 +48,9 @@ struct BoxLeaf {
     float center[3];        // the parallelepiped: local coordinate l_k = axis[k] . (P - center), inside <=> |l_k| <= 1 for k = 0, 1, 2
     float axis[3][3];
     uint8_t face_rec[6];    // face f = 2 k + (l_k > 0 ? 1 : 0): offset (0, 2, .. 10) of its quad's X record from first_rec
+    uint8_t face_bits[6];   // how that quad's (s, t) -- P = p0 + s X.e1 + t Y.e2 -- follow the two OTHER local coordinates l_i, l_j (i < j) of a point on the face:
+                            // bit 0: s follows l_j (and t l_i); bit 1: s = (1 - l) / 2 instead of (1 + l) / 2; bit 2: the same for t
+    uint32_t mask;          // the material id of its twelve triangles
 };
 
 struct Bvh {
@@ -59,7 +62,10 @@ struct Bvh {
     std::vector<F4> tris;    // 3 per triangle
     uint32_t n_nodes = 0, n_leaves = 0, depth = 0, max_leaf = 0;
     uint32_t n_nodes4 = 0, depth4 = 0;
-    std::vector<BoxLeaf> boxes;   // want_boxes: the parallelepipeds found (see kLeafBox)
+    std::vector<BoxLeaf> boxes;   // want_boxes: the parallelepipeds found (see kLeafBox), then -- node = ~0u -- the lone quads as boxes of no thickness (HBM flavour only)
+    uint32_t n_boxes_real = 0;    // how many of them are parallelepipeds
+    std::vector<uint32_t> nodes4q_box;   // the quantised 4-wide nodes once more, with every box a LEAF: child code ~(((number of records + index into `boxes`) << 3) | kLeafBox) -- what
+    uint32_t n_nodes4_box = 0, depth4_box = 0;   // the shipped build traverses from HBM (empty: no boxes, or the whole scene is one)
     double sah_cost = 0.0;
     // ---- 8-wide compressed nodes (round-5 experiment, TRG_WIDE8 builds; q8node.h): the same BVH2 collapsed to up to eight children per node ----
     std::vector<uint32_t> nodes8;   // 20 dwords (80 bytes) per node, breadth first: the inner children of a node have consecutive indices

@@ -107,7 +107,7 @@ static inline uint64_t align16_64(uint64_t v) { return (v + 15ull) & ~15ull; }
 // tables.  Then, for every scene, what the HBM kernels traverse: n_nodes4 quantised wide nodes and n_fat 128-byte leaf records.
 constexpr uint64_t kBlobLimit = 0xFFFFFFF0ull;
 static bool plan_scene_layout(uint64_t n_nodes, uint32_t node_bytes, uint64_t nt_rec, uint64_t attr_tris, bool with_htab, uint64_t n_nodes4, uint64_t n_fat,
-                              SceneDesc &sc, uint64_t &total) {
+                              SceneDesc &sc, uint64_t &total, uint64_t n_nodes4_box = 0, uint64_t n_boxrec = 0) {
     const uint64_t off_nodes = 0;
     const uint64_t off_tris = align16_64(off_nodes + n_nodes * node_bytes);
     const uint64_t off_normals = align16_64(off_tris + nt_rec * 48ull);
@@ -117,13 +117,18 @@ static bool plan_scene_layout(uint64_t n_nodes, uint32_t node_bytes, uint64_t nt
     const uint64_t off_htab = align16_64(off_meta + nt_rec * 2ull);
     const uint64_t stage_end = align16_64(off_htab + (with_htab ? kHtabBytes : 0u));
     const uint64_t off_nodes4 = (stage_end + 127ull) & ~127ull;  // 64-byte nodes, two per 128-byte line
-    const uint64_t off_fat = (off_nodes4 + n_nodes4 * (TRG_WIDE8 ? kQ8NodeBytes : kQ4NodeBytes) + 127ull) & ~127ull;   // one record per 128-byte line
+    // (the box-leaf flavour of the 4-wide nodes -- only a host build of a scene with boxes has it -- sits BEFORE the leaf records: the kernels
+    //  address records by an unsigned 32-bit distance from the node array they traverse)
+    const uint64_t off_nodes4_box = (off_nodes4 + n_nodes4 * (TRG_WIDE8 ? kQ8NodeBytes : kQ4NodeBytes) + 127ull) & ~127ull;
+    const uint64_t off_fat = (off_nodes4_box + n_nodes4_box * kQ4NodeBytes + 127ull) & ~127ull;   // one record per 128-byte line
     const uint64_t off_fat_planes = off_fat + n_fat * kFatRecBytes;                        // the shipped build's leaf records (planes), one per line as well
-    const uint64_t off_tris_alt = off_fat_planes + n_fat * kFatRecBytes;                   // the plane records of an LDS-sized scene (16-byte aligned)
+    const uint64_t off_boxrec = off_fat_planes + n_fat * kFatRecBytes;                     // ... and, right behind them at the SAME stride, the box records: box b is "record n_fat + b"
+    const uint64_t off_tris_alt = off_boxrec + n_boxrec * kFatRecBytes;                    // the plane records of an LDS-sized scene (16-byte aligned)
     const uint64_t off_flat = (off_tris_alt + nt_rec * 48ull + 63ull) & ~63ull;            // the flat primitive list of a tiny scene (sc.n_flat set by the caller)
     total = off_flat + (uint64_t)sc.n_flat * kFlatPrimBytes + 128ull;
     sc.off_flat = (uint32_t)off_flat;
     if (total > kBlobLimit) return false;
+    sc.off_nodes4_box = n_nodes4_box ? (uint32_t)off_nodes4_box : (uint32_t)off_nodes4; sc.off_boxrec = (uint32_t)off_boxrec; sc.n_boxrec = n_nodes4_box ? (uint32_t)n_boxrec : 0u;
     sc.off_meta = (uint32_t)off_meta; sc.off_tris_alt = (uint32_t)off_tris_alt;
     sc.off_nodes = (uint32_t)off_nodes; sc.off_tris = (uint32_t)off_tris; sc.off_normals = (uint32_t)off_normals;
     sc.off_colors = (uint32_t)off_colors; sc.off_mats = (uint32_t)off_mats; sc.off_htab = (uint32_t)off_htab;
@@ -574,7 +579,7 @@ int host_scene_build(trg_ctx *c, const float *pos, const float *nrm, const float
     // (boxes: only a scene that may be staged in LDS can use them -- 170 triangles at most; the switch is wider so that the answer does not hinge on it)
     uint32_t box_max_tris = 1024u;
     if (const char *e = getenv("TRG_BVH_BOXES_MAX_TRIS")) box_max_tris = (uint32_t)strtoul(e, nullptr, 10);   // (measurements: boxes as units of the split rule in larger scenes too)
-    build_bvh(pos, idx, mat, n_tris, bvh, TRG_WIDE8 != 0, TRG_BOX_LEAVES && !TRG_WIDE8 && n_tris <= box_max_tris);
+    build_bvh(pos, idx, mat, n_tris, bvh, TRG_WIDE8 != 0, TRG_BOX_LEAVES && !TRG_WIDE8 && (TRG_BOX_LEAVES_HBM || n_tris <= box_max_tris));
     if (TRG_WIDE8 && !bvh.wide8_ok) { delete hs; return fail(c, TRG_ERR_RANGE, "trg_load_scene: the 8-wide layout of this build needs leaves of at most two records (TRG_BVH_MAXLEAF <= 2)"); }
     hs->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
     if (n_tris) {
@@ -612,7 +617,10 @@ int host_scene_build(trg_ctx *c, const float *pos, const float *nrm, const float
     sc.n_nodes4 = TRG_WIDE8 ? bvh.n_nodes8 : bvh.n_nodes4;
     const uint32_t n_fat = TRG_WIDE8 ? (uint32_t)bvh.rec8.size() : nt_rec;   // (TRG_WIDE8: two entries per leaf, in the order the 8-wide tree addresses them)
     uint64_t total = 0;
-    if (!plan_scene_layout(sc.n_nodes, node_bytes, lds_candidate ? nt_rec : 0u, lds_candidate ? attr_tris : 0u, lds_candidate, sc.n_nodes4, n_fat, sc, total)) {
+    // the box-leaf flavour of the HBM tree (shipped build): TRG_BVH_BOXES_HBM=0 leaves it out (A/B runs: the kernels then never meet a box code)
+    const bool hbm_boxes = TRG_BOX_LEAVES_HBM && !TRG_WIDE8 && bvh.n_nodes4_box != 0 && !(getenv("TRG_BVH_BOXES_HBM") && atoi(getenv("TRG_BVH_BOXES_HBM")) == 0);
+    if (!plan_scene_layout(sc.n_nodes, node_bytes, lds_candidate ? nt_rec : 0u, lds_candidate ? attr_tris : 0u, lds_candidate, sc.n_nodes4, n_fat, sc, total,
+                           hbm_boxes ? bvh.n_nodes4_box : 0u, hbm_boxes ? bvh.boxes.size() : 0u)) {
         delete hs;
         return fail(c, TRG_ERR_RANGE, "trg_load_scene: scene needs %llu B on the device (limit 4 GiB)", (unsigned long long)total);
     }
@@ -661,6 +669,7 @@ int host_scene_build(trg_ctx *c, const float *pos, const float *nrm, const float
         // a box leaf's twelve plane records hold six quads X, Y, X, Y ...: a quad's test reads its X record only, so the Y slots are free -- the first
         // takes the box itself, rows (a_k, d_k): l_k = a_k . (P - scene centre) + d_k, the second the X-record offset of each of its six faces
         for (const BoxLeaf &bl : bvh.boxes) {
+            if (bl.node == ~0u) continue;   // (a lone quad dressed as a box: the HBM flavour's business)
             float rec[12];
             for (int k = 0; k < 3; ++k) {
                 double dk = 0.0;
@@ -745,9 +754,29 @@ int host_scene_build(trg_ctx *c, const float *pos, const float *nrm, const float
     if (sc.n_nodes4) memcpy(&host[sc.off_nodes4], bvh.nodes4q.data(), (size_t)sc.n_nodes4 * kQ4NodeBytes);
 #endif
 
+    if (hbm_boxes) {
+        memcpy(&host[sc.off_nodes4_box], bvh.nodes4q_box.data(), (size_t)bvh.n_nodes4_box * kQ4NodeBytes);
+        for (size_t b = 0; b < bvh.boxes.size(); ++b) {
+            const BoxLeaf &bl = bvh.boxes[b];
+            float rec[16];
+            for (int k = 0; k < 3; ++k) {
+                double dk = 0.0;
+                for (int a = 0; a < 3; ++a) { rec[k * 4 + a] = bl.axis[k][a]; dk -= (double)bl.axis[k][a] * ((double)bl.center[a] - (double)sc.center[a]); }
+                rec[k * 4 + 3] = (float)dk;
+            }
+            uint32_t row3[4] = { bl.first_rec, bl.mask, 0u, 0u };
+            for (int f = 0; f < 6; ++f) {
+                const uint32_t w7 = (uint32_t)bl.face_rec[f] | ((uint32_t)bl.face_bits[f] << 4);
+                row3[2 + f / 4] |= w7 << (7 * (f % 4));
+            }
+            memcpy(&rec[12], row3, 16);
+            memcpy(&host[sc.off_boxrec + b * (size_t)kFatRecBytes], rec, 64);   // (the second half of the line is padding)
+        }
+    }
+
     hs->sc = sc;
     hs->bvh_nodes = bvh.n_nodes; hs->bvh_depth = bvh.depth; hs->bvh_leaves = bvh.n_leaves;
-    hs->bvh_quads = bvh.n_quads; hs->bvh_boxes = lds_candidate ? (uint32_t)bvh.boxes.size() : 0u;
+    hs->bvh_quads = bvh.n_quads; hs->bvh_boxes = (lds_candidate || hbm_boxes) ? bvh.n_boxes_real : 0u;
     hs->bvh_nodes4 = TRG_WIDE8 ? bvh.n_nodes8 : bvh.n_nodes4; hs->bvh_depth4 = TRG_WIDE8 ? bvh.depth8 : bvh.depth4;
     *out = hs;
     return TRG_OK;
@@ -1340,10 +1369,10 @@ int trg_debug_boxes(const float *positions3, const uint32_t *indices, const uint
         if (indices[i] >= n_verts) return TRG_ERR_INVALID;
     Bvh bvh;
     build_bvh(positions3, indices, material_ids, n_tris, bvh, false, true);
-    if (n_boxes) *n_boxes = (uint32_t)bvh.boxes.size();
+    if (n_boxes) *n_boxes = bvh.n_boxes_real;
     if (boxes20_out) {
-        if (boxes_cap < bvh.boxes.size()) return TRG_ERR_RANGE;
-        for (size_t b = 0; b < bvh.boxes.size(); ++b) {
+        if (boxes_cap < bvh.n_boxes_real) return TRG_ERR_RANGE;
+        for (size_t b = 0; b < bvh.n_boxes_real; ++b) {
             const BoxLeaf &bl = bvh.boxes[b];
             float *o = boxes20_out + b * 20;
             o[0] = (float)bl.node; o[1] = (float)bl.first_rec;

@@ -579,6 +579,8 @@ constexpr bool kTriPlanes = !TRG_STRICT && TRG_TRI_PLANES;
 constexpr bool kRecPlanes = !TRG_STRICT && TRG_TRI_PLANES_HBM;
 
 constexpr bool kRecMetaFirst = kRecPlanes && TRG_REC_META_FIRST;   // plane records: index / mask = floats 12, 13 (else 30, 31)
+constexpr bool kBoxHbm = kRecPlanes && TRG_BOX_LEAVES && TRG_BOX_LEAVES_HBM;   // box leaves in the tree traversed from HBM (shipped build only)
+static_assert(!kBoxHbm || kRecMetaFirst, "a box record keeps its first record, mask and face table in row 3, which the unified step loads for TRG_REC_META_FIRST");
 // (TRG_WIDE8: the index word of a record carries two flag bits, 28 and 29 -- trav_step_wide8)
 TRG_DEV int fat_prim(const v4f *recs, uint32_t r) { return (TRG_WIDE8 ? 0x0FFFFFFF : -1) & __float_as_int(kRecMetaFirst ? recs[(size_t)r * kRecV4 + 3].x : kRecPlanes ? recs[(size_t)r * kRecV4 + 7].z : recs[(size_t)r * kRecV4].w); }
 TRG_DEV uint32_t fat_mask(const v4f *recs, uint32_t r) { return (uint32_t)__float_as_int(kRecMetaFirst ? recs[(size_t)r * kRecV4 + 3].y : kRecPlanes ? recs[(size_t)r * kRecV4 + 7].w : recs[(size_t)r * kRecV4 + 1].w); }
@@ -872,6 +874,52 @@ TRG_DEV bool trav_tri_planes_rec(const v4f a, const v4f b, const v4f c, uint32_t
     tv.hit.v = take ? v : tv.hit.v;
     return any && ok;
 }
+// A BOX leaf of a scene traversed from HBM (shipped build; trg_kernels.h SceneDesc::off_boxrec): q0..q2 = the box's frame, q3 = (first leaf record,
+// material id, face table low / high).  The same slab test as trav_box_planes; the hit's triangle and weights come from the two OTHER local
+// coordinates of the hit point and three bits per face (which of them s follows, and the signs), so nothing but these 64 bytes is read.
+// The hit keeps the leaf RECORD of its triangle, like every HBM hit (the shading event reads index and attributes from it).
+template <bool COUNT>
+TRG_DEV bool trav_box_rec(const v4f b0, const v4f b1, const v4f b2, const v4f b3, Trav &tv, bool any, Counters &cnt, const v4f *recs, V3 center) {
+    const uint32_t first = (uint32_t)__float_as_int(b3.x), mask = (uint32_t)__float_as_int(b3.y);
+    const bool masked_in = (mask & tv.rmask) != 0u;
+    if (COUNT) { if (masked_in) cnt.tris++; if (mbcnt64(__ballot(1)) == 0) cnt.wtris++; }
+    const V3 o = tv.o - center, d = tv.d;
+    const float lox = b0.x * o.x + (b0.y * o.y + (b0.z * o.z + b0.w)), ldx = b0.x * d.x + (b0.y * d.y + b0.z * d.z);
+    const float loy = b1.x * o.x + (b1.y * o.y + (b1.z * o.z + b1.w)), ldy = b1.x * d.x + (b1.y * d.y + b1.z * d.z);
+    const float loz = b2.x * o.x + (b2.y * o.y + (b2.z * o.z + b2.w)), ldz = b2.x * d.x + (b2.y * d.y + b2.z * d.z);
+    const float ix = rcp_fast(ldx), iy = rcp_fast(ldy), iz = rcp_fast(ldz);
+    const float mx = -lox * ix, my = -loy * iy, mz = -loz * iz;
+    const float ax = fabsf(ix), ay = fabsf(iy), az = fabsf(iz);
+    const float nx = mx - ax, ny = my - ay, nz = mz - az, fx = mx + ax, fy = my + ay, fz = mz + az;
+    const float tnear = fmaxf(fmaxf(nx, ny), nz), tfar = fminf(fminf(fx, fy), fz);
+    const bool inside = tnear < 0.0f;
+    const float t = inside ? tfar : tnear;
+    const bool ok = (tnear <= tfar) && (t >= 0.0f) && (t <= tv.best) && masked_in;
+    // the face: the axis whose plane gives t -- the LAST one on a tie (a lone quad is a box of no thickness along axis 2: a shot at its very edge
+    // enters "through the rim" and through the face at the same t, and only the face has weights)
+    const float cz = inside ? fz : nz, cy = inside ? fy : ny;
+    const bool isz = cz == t, isy = !isz && cy == t, isx = !isz && !isy;
+    const float lx = lox + t * ldx, ly = loy + t * ldy, lz = loz + t * ldz;     // the hit point in the box's frame
+    const float lk = isx ? lx : isy ? ly : lz;
+    const uint32_t f = (isx ? 0u : isy ? 2u : 4u) + (lk > 0.0f ? 1u : 0u);
+    const uint32_t tw = (uint32_t)__float_as_int(f >= 4u ? b3.w : b3.z) >> (7u * (f & 3u));
+    const float li = isx ? ly : lx, lj = (isx || isy) ? lz : ly;               // the two other coordinates, i < j
+    const bool swap = (tw & 16u) != 0u;
+    const float ls = swap ? lj : li, lt = swap ? li : lj;
+    const float s0 = ls * ((tw & 32u) ? -0.5f : 0.5f) + 0.5f, t0 = lt * ((tw & 64u) ? -0.5f : 0.5f) + 0.5f;
+    const bool second = s0 < t0;
+    const float u = second ? s0 : s0 - t0, v = second ? t0 - s0 : t0;
+    const uint32_t rec = first + (tw & 15u) + (second ? 1u : 0u);
+    const bool closer = any || !tv.found || t < tv.best;
+    bool take = ok && closer;
+    if (ok && !closer && t == tv.best) take = fat_prim(recs, rec) < fat_prim(recs, (uint32_t)tv.hit.prim);
+    tv.found = tv.found || ok;
+    tv.best = take ? t : tv.best;
+    tv.hit.prim = take ? (int)rec : tv.hit.prim;
+    tv.hit.u = take ? u : tv.hit.u;
+    tv.hit.v = take ? v : tv.hit.v;
+    return any && ok;
+}
 // triangle `k` of the records starting at `tr` (LDS-resident scene): whichever test the build uses
 template <bool COUNT>
 TRG_DEV bool trav_tri_lds(const SceneView &sc, const v4f *tr, uint32_t rec, Trav &tv, bool any, Counters &cnt) {
@@ -1002,6 +1050,8 @@ TRG_DEV void trav_step_wide(const SceneView &sc, Trav &tv, bool any, STK stk, Co
     const uint32_t first = code >> 3, left = code & 7u;
     // one wave-uniform base + a 32-bit byte offset per lane (the scene blob is below 4 GiB and the records follow the nodes in it):
     // the loads take the SGPR-base form, no 64-bit address arithmetic per lane
+    const bool boxleaf = kBoxHbm && !inner && left == kLeafBox;   // (shipped build: ONE leaf for a parallelepiped's twelve triangles; its 64-byte record -- addressed like a
+                                                                  //  leaf record behind the leaf records -- is all the test reads)
     const uint32_t off = inner ? (uint32_t)tv.node * 64u : (code & ~7u) * (uint32_t)(kRecV4 * 16 / 8) + sc.rec_delta;
     const v4f *ptr = reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(sc.nodes) + off);
     const v4f q0 = ptr[0], q1 = ptr[1], q2 = ptr[2];
@@ -1012,6 +1062,12 @@ TRG_DEV void trav_step_wide(const SceneView &sc, Trav &tv, bool any, STK stk, Co
     else if (inner) q3 = ptr[3];
     if (inner) {
         trav_node4_math<COUNT, BLOCK>(q0, q1, q2, q3, tv, stk, cnt);
+    } else if (kBoxHbm && boxleaf) {
+        const bool stop = trav_box_rec<COUNT>(q0, q1, q2, q3, tv, any, cnt, sc.tris, sc.center);
+        const int sp = tv.sp - (stop ? 0 : STK::unit);
+        const int popped = stk.pop(sp);
+        tv.node = stop ? kNodeDone : popped;
+        tv.sp = sp;
     } else {
         // a QUAD leaf (count field 7, bvh_build.h): the shipped build decides both triangles with one parallelogram test; the strict build
         // tests record `first`, then advances to the single-triangle code of record first + 1

@@ -66,6 +66,12 @@ struct SceneDesc {
     // off_tris_alt), row 3 = (original index of the triangle / of the quad's X, original index of the quad's Y or ~0, material id = mask, 1 = quad).
     // Such a scene is not walked through its tree at all: every ray tests every primitive in record order (trg_device.h traverse_flat).
     uint32_t off_flat, n_flat;
+    // BOX leaves of the shipped build's HBM traversal (TRG_BOX_LEAVES_HBM, round 5): a second array of quantised 4-wide nodes in which a box's subtree is
+    // ONE leaf -- child code ~(((n_fat + box index) << 3) | 6): a box is addressed like a leaf record behind the plane records, same 128-byte stride, so the
+    // traversal's address arithmetic does not know about boxes -- and 64 bytes per box: rows 0..2 = (a_k, d_k), l_k = a_k . (P - center) + d_k the box's own
+    // frame, row 3 = (its first leaf record, material id, face table low, high: 7 bits per face f = 2 k + (l_k > 0), 0..3 in the low word, 4..5 in
+    // the high one -- X-record offset 0..10 | swap << 4 | negate s << 5 | negate t << 6).  A scene without boxes: off_nodes4_box = off_nodes4, n_boxrec = 0.
+    uint32_t off_nodes4_box, off_boxrec, n_boxrec;
     // the planes are stored relative to this point (the centre of the scene's bounding box) and a ray's origin is shifted by it when its
     // traversal begins: n . o - d0 then cancels numbers of the size of the scene instead of its distance from the coordinate origin
     float center[3];
@@ -232,6 +238,9 @@ struct TraceParams {
 #ifndef TRG_BOX_LEAVES
 #define TRG_BOX_LEAVES 1       // scenes staged in LDS: addCube's twelve triangles become ONE leaf (bvh_build.h kLeafBox): twelve triangle tests in the strict
                                // build, one slab test in the parallelepiped's own frame in the shipped one (trg_device.h trav_box_planes)
+#endif
+#ifndef TRG_BOX_LEAVES_HBM
+#define TRG_BOX_LEAVES_HBM 1   // the same box leaf for scenes traversed from HBM (shipped build: SceneDesc::off_nodes4_box / off_boxrec; the strict build keeps the plain tree)
 #endif
 #ifndef TRG_HALTON_TABLES
 #define TRG_HALTON_TABLES 1

@@ -65,7 +65,7 @@ TRG_DEV SceneView scene_view(const trg::SceneDesc &sc, unsigned char *smem) {
         v.htab = reinterpret_cast<const float *>(smem + sc.off_htab);
     } else {
         // traversed from HBM: the quantised 4-wide nodes and the 128-byte leaf records (geometry + attributes, trg_device.h kRecV4)
-        v.nodes = reinterpret_cast<const v4f *>(sc.blob + sc.off_nodes4);
+        v.nodes = reinterpret_cast<const v4f *>(sc.blob + (kBoxHbm ? sc.off_nodes4_box : sc.off_nodes4));   // (shipped build: the flavour whose boxes are leaves)
         v.tris = reinterpret_cast<const v4f *>(sc.blob + (kRecPlanes ? sc.off_fat_planes : sc.off_fat));
         v.normals = nullptr; v.colors = nullptr; v.mats = nullptr; v.meta = nullptr;
         v.htab = nullptr;
@@ -74,7 +74,7 @@ TRG_DEV SceneView scene_view(const trg::SceneDesc &sc, unsigned char *smem) {
     v.n_flat = (LDS_SCENE && kTriPlanes) ? sc.n_flat : 0u;
     v.center = mk(sc.center[0], sc.center[1], sc.center[2]);
     v.tex.uv = nullptr; v.tex.ids = nullptr; v.tex.table = nullptr; v.tex.texels = nullptr;
-    v.rec_delta = LDS_SCENE ? 0u : (kRecPlanes ? sc.off_fat_planes : sc.off_fat) - sc.off_nodes4;
+    v.rec_delta = LDS_SCENE ? 0u : (kRecPlanes ? sc.off_fat_planes : sc.off_fat) - (kBoxHbm ? sc.off_nodes4_box : sc.off_nodes4);   // (>= 0: both node arrays sit before the records, trg_capi.cpp plan_scene_layout)
     return v;
 }
 
