@@ -1,5 +1,6 @@
 #include "bvh_build.h"
 #include "q4node.h"
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -33,6 +34,25 @@ int main() {
         }
         Bvh b;
         build_bvh(pos.data(), idx.data(), mat.data(), (uint32_t)mat.size(), b, false, true);
+        if (n == 7) {
+            // hostile cubes: the same scene again with cubes of no size, of no thickness, at 1e30, with a NaN / an infinite corner, with two materials,
+            // and one whose corner is off by 1e-3 -- none of them may be taken for a box (or crash the builder); the seven good ones still are
+            std::vector<float> p2 = pos; std::vector<uint32_t> i2 = idx, m2 = mat;
+            const size_t v0 = p2.size() / 3;
+            auto cube_at = [&](float h, float cx) { add_cube(p2, i2, m2, cx, 8.f, 8.f, h); return p2.size() / 3 - 36; };
+            cube_at(0.f, 1.f);                                                         // a point
+            { const size_t c = cube_at(0.1f, 2.f); for (size_t v = c; v < c + 36; ++v) p2[v * 3 + 2] = 8.f; }          // flat
+            { const size_t c = cube_at(0.1f, 3.f); for (size_t v = c; v < c + 36; ++v) for (int a = 0; a < 3; ++a) p2[v * 3 + a] *= 1e30f; }
+            { const size_t c = cube_at(0.1f, 4.f); p2[c * 3] = std::nanf(""); }
+            { const size_t c = cube_at(0.1f, 5.f); p2[(c + 7) * 3 + 1] = INFINITY; }
+            { cube_at(0.1f, 6.f); m2[m2.size() - 1] = 2; }
+            { const size_t c = cube_at(0.1f, 7.f); p2[(c + 2) * 3] += 1e-3f; }
+            (void)v0;
+            Bvh h;
+            build_bvh(p2.data(), i2.data(), m2.data(), (uint32_t)m2.size(), h, false, true);
+            if (h.n_boxes_real != 7u) { printf("hostile cubes: %u boxes\n", h.n_boxes_real); return 1; }
+            printf("hostile cubes: none taken for a box\n");
+        }
         const uint32_t nrec = (uint32_t)(b.tris.size() / 3);
         std::vector<int> seen(nrec, 0);
         size_t box_refs = 0;

@@ -482,7 +482,7 @@ def test_host_builder_under_sanitizers():
 def test_box_flavour_of_the_wide_tree_under_sanitizers():
     """The second 4-wide collapse (shipped build, scenes traversed from HBM): every box -- and every lone quad, dressed as a box of no thickness --
     is a leaf addressed like a record behind the records.  tests/helpers/box_tree_check.cpp builds 1 ... 9,000 cubes + a lone triangle + two lone
-    quads (threaded above 65,536 triangles) under -fsanitize=address,undefined and checks that every child code is in range and every leaf
+    quads (threaded above 65,536 triangles), and once a handful of hostile cubes, under -fsanitize=address,undefined and checks that every child code is in range and every leaf
     record is reached exactly once through exactly one leaf."""
     import tempfile
     csrc = os.path.join(ROOT, "toyraygun_amd", "csrc")
@@ -493,6 +493,8 @@ def test_box_flavour_of_the_wide_tree_under_sanitizers():
         r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, TRG_BVH_THREADS="4"))
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2000:])
     assert r.stdout.count("every record once: yes") == 5 and "ERROR" not in r.stderr and "runtime error" not in r.stderr
+    # (cubes of no size, of no thickness, at 1e30, with a NaN or an infinite corner, of two materials, with a corner off by 1e-3: not boxes, no crash)
+    assert "hostile cubes: none taken for a box" in r.stdout
 
 
 def test_threaded_host_build_is_identical_to_the_single_threaded_one(built):
