@@ -769,6 +769,7 @@ int host_scene_build(trg_ctx *c, const float *pos, const float *nrm, const float
                 const uint32_t w7 = (uint32_t)bl.face_rec[f] | ((uint32_t)bl.face_bits[f] << 4);
                 row3[2 + f / 4] |= w7 << (7 * (f % 4));
             }
+            if (bl.node == ~0u) row3[3] |= 0x80000000u;   // a lone quad dressed as a box: its face is axis 2 (box_hit_resolve)
             memcpy(&rec[12], row3, 16);
             memcpy(&host[sc.off_boxrec + b * (size_t)kFatRecBytes], rec, 64);   // (the second half of the line is padding)
         }

@@ -518,6 +518,7 @@ struct SceneView {
     const unsigned short *meta;   // LDS scene: per record (original index << 2) | (material id & 3) (the plane test of the shipped build)
     V3 center;              // shipped build: the point the plane records are relative to (SceneDesc::center); Trav::o is relative to it too
     uint32_t rec_delta;     // HBM scene: byte distance from `nodes` to `tris` (the records follow the nodes in the blob)
+    uint32_t n_rec;         // HBM scene: its leaf records; an index from here on names a BOX record (shipped build: SceneDesc::off_boxrec sits right behind them)
     const v4f *flat;        // shipped build, tiny LDS-resident scene: the flat primitive list in global memory (trg_kernels.h SceneDesc::off_flat), wave-uniform
     uint32_t n_flat;        // its entries; 0: walk the tree
 };
@@ -827,32 +828,41 @@ TRG_DEV bool trav_box_planes(const SceneView &sc, const v4f *tr, uint32_t first,
     const float ix = rcp_fast(ldx), iy = rcp_fast(ldy), iz = rcp_fast(ldz);
     const float mx = -lox * ix, my = -loy * iy, mz = -loz * iz;              // the ray meets the planes l_k = -1, +1 at m_k -+ |1 / ld_k|
     const float ax = fabsf(ix), ay = fabsf(iy), az = fabsf(iz);
-    const float nx = mx - ax, ny = my - ay, nz = mz - az, fx = mx + ax, fy = my + ay, fz = mz + az;
-    const float tnear = fmaxf(fmaxf(nx, ny), nz), tfar = fminf(fminf(fx, fy), fz);
-    const bool inside = tnear < 0.0f;
-    const float t = inside ? tfar : tnear;
+    const float tnear = fmaxf(fmaxf(mx - ax, my - ay), mz - az), tfar = fminf(fminf(mx + ax, my + ay), mz + az);
+    const float t = tnear < 0.0f ? tfar : tnear;                             // (from inside: the triangles are two-sided, the ray meets the face it leaves by)
     const bool ok = (tnear <= tfar) && (t >= 0.0f) && (t <= tv.best) && masked_in;
-    // the face: the axis whose plane gives t, the side the hit point lies on
-    const float cx = inside ? fx : nx, cy = inside ? fy : ny;
-    const bool isx = cx == t, isy = cy == t;
-    const float lk = isx ? lox + t * ldx : isy ? loy + t * ldy : loz + t * ldz;
+    // only the slab test inside the traversal loop: an accepted hit keeps the distance and -(first + 2) -- "a box, triangle and weights still to be
+    // named" -- and lds_box_hit_resolve() names them once, for the hit that survived, when the traversal is over (an any-hit query never needs them)
+    const bool take = ok && (any || !tv.found || t < tv.best);
+    tv.found = tv.found || ok;
+    tv.best = take ? t : tv.best;
+    tv.hit.prim = take ? -(int)(first + 2u) : tv.hit.prim;
+    return any && ok;
+}
+TRG_DEV const v4f *lds_records(const SceneView &sc, uint32_t first);
+// the triangle and the weights of a hit that is still a box (h.prim <= -2): the hit point in the box's frame, the face = the axis along which it lies
+// farthest out, that face's own quad planes for (s, t) -- exactly what its quad test would have computed there
+TRG_DEV void lds_box_hit_resolve(const SceneView &sc, const Trav &tv, Hit &h) {
+    if (!(kTriPlanes && TRG_BOX_LEAVES) || h.prim > -2) return;
+    const uint32_t first = (uint32_t)(-h.prim - 2);
+    const v4f *tr = lds_records(sc, first);
+    const v4f b0 = tr[3], b1 = tr[4], b2 = tr[5];
+    const V3 o = tv.o, d = tv.d;
+    const V3 P = mk(o.x + h.t * d.x, o.y + h.t * d.y, o.z + h.t * d.z);
+    const float lx = b0.x * P.x + (b0.y * P.y + (b0.z * P.z + b0.w)), ly = b1.x * P.x + (b1.y * P.y + (b1.z * P.z + b1.w)), lz = b2.x * P.x + (b2.y * P.y + (b2.z * P.z + b2.w));
+    const float fx = fabsf(lx), fy = fabsf(ly), fz = fabsf(lz);
+    const bool isz = fz >= fx && fz >= fy, isy = !isz && fy >= fx, isx = !isz && !isy;
+    const float lk = isx ? lx : isy ? ly : lz;
     const uint32_t f = (isx ? 0u : isy ? 2u : 4u) + (lk > 0.0f ? 1u : 0u);
     const uint32_t fw = reinterpret_cast<const uint32_t *>(tr + 9)[f];
     const v4f *q = reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(tr) + (fw & 0xFFFFu));
     const v4f q1 = q[1], q2 = q[2];
-    const V3 P = mk(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);
     const float s0 = q1.x * P.x + (q1.y * P.y + (q1.z * P.z + q1.w));
     const float t0 = q2.x * P.x + (q2.y * P.y + (q2.z * P.z + q2.w));
     const bool second = s0 < t0;
-    const float u = second ? s0 : s0 - t0, v = second ? t0 - s0 : t0;
-    const int prim = (int)((uint32_t)sc.meta[first + (fw >> 16) + (second ? 1u : 0u)] >> 2);
-    const bool take = ok && (any || !tv.found || t < tv.best || (t == tv.best && prim < tv.hit.prim));
-    tv.found = tv.found || ok;
-    tv.best = take ? t : tv.best;
-    tv.hit.prim = take ? prim : tv.hit.prim;
-    tv.hit.u = take ? u : tv.hit.u;
-    tv.hit.v = take ? v : tv.hit.v;
-    return any && ok;
+    h.u = second ? s0 : s0 - t0;
+    h.v = second ? t0 - s0 : t0;
+    h.prim = (int)((uint32_t)sc.meta[first + (fw >> 16) + (second ? 1u : 0u)] >> 2);
 }
 // ... and on a leaf RECORD of an HBM-resident scene (the hit keeps the record index; ties go to the lower original index, read back from the
 // held record only then): mask and prim are floats 13 and 12 of the record (TRG_REC_META_FIRST; its last two words before)
@@ -875,12 +885,13 @@ TRG_DEV bool trav_tri_planes_rec(const v4f a, const v4f b, const v4f c, uint32_t
     return any && ok;
 }
 // A BOX leaf of a scene traversed from HBM (shipped build; trg_kernels.h SceneDesc::off_boxrec): q0..q2 = the box's frame, q3 = (first leaf record,
-// material id, face table low / high).  The same slab test as trav_box_planes; the hit's triangle and weights come from the two OTHER local
-// coordinates of the hit point and three bits per face (which of them s follows, and the signs), so nothing but these 64 bytes is read.
-// The hit keeps the leaf RECORD of its triangle, like every HBM hit (the shading event reads index and attributes from it).
+// material id, face table low / high).  The same slab test as trav_box_planes -- and nothing else inside the traversal loop: an accepted hit keeps
+// the distance and the index of the BOX record (`self`: it sits behind the leaf records, so any index >= SceneView::n_rec says "a box, face and
+// weights still to be named"); box_hit_resolve() names them once, for the hit that survived, when the traversal is over (any-hit queries never need
+// them).  A tie in distance goes to whoever came first: which triangle of the box it is is not known yet (shipped build: undecidable either way).
 template <bool COUNT>
-TRG_DEV bool trav_box_rec(const v4f b0, const v4f b1, const v4f b2, const v4f b3, Trav &tv, bool any, Counters &cnt, const v4f *recs, V3 center) {
-    const uint32_t first = (uint32_t)__float_as_int(b3.x), mask = (uint32_t)__float_as_int(b3.y);
+TRG_DEV bool trav_box_rec(const v4f b0, const v4f b1, const v4f b2, const v4f b3, Trav &tv, bool any, Counters &cnt, uint32_t self, V3 center) {
+    const uint32_t mask = (uint32_t)__float_as_int(b3.y);
     const bool masked_in = (mask & tv.rmask) != 0u;
     if (COUNT) { if (masked_in) cnt.tris++; if (mbcnt64(__ballot(1)) == 0) cnt.wtris++; }
     const V3 o = tv.o - center, d = tv.d;
@@ -888,37 +899,41 @@ TRG_DEV bool trav_box_rec(const v4f b0, const v4f b1, const v4f b2, const v4f b3
     const float loy = b1.x * o.x + (b1.y * o.y + (b1.z * o.z + b1.w)), ldy = b1.x * d.x + (b1.y * d.y + b1.z * d.z);
     const float loz = b2.x * o.x + (b2.y * o.y + (b2.z * o.z + b2.w)), ldz = b2.x * d.x + (b2.y * d.y + b2.z * d.z);
     const float ix = rcp_fast(ldx), iy = rcp_fast(ldy), iz = rcp_fast(ldz);
-    const float mx = -lox * ix, my = -loy * iy, mz = -loz * iz;
+    const float mx = -lox * ix, my = -loy * iy, mz = -loz * iz;              // the ray meets the planes l_k = -1, +1 at m_k -+ |1 / ld_k|
     const float ax = fabsf(ix), ay = fabsf(iy), az = fabsf(iz);
-    const float nx = mx - ax, ny = my - ay, nz = mz - az, fx = mx + ax, fy = my + ay, fz = mz + az;
-    const float tnear = fmaxf(fmaxf(nx, ny), nz), tfar = fminf(fminf(fx, fy), fz);
-    const bool inside = tnear < 0.0f;
-    const float t = inside ? tfar : tnear;
+    const float tnear = fmaxf(fmaxf(mx - ax, my - ay), mz - az), tfar = fminf(fminf(mx + ax, my + ay), mz + az);
+    const float t = tnear < 0.0f ? tfar : tnear;                             // (from inside: the triangles are two-sided, the ray meets the face it leaves by)
     const bool ok = (tnear <= tfar) && (t >= 0.0f) && (t <= tv.best) && masked_in;
-    // the face: the axis whose plane gives t -- the LAST one on a tie (a lone quad is a box of no thickness along axis 2: a shot at its very edge
-    // enters "through the rim" and through the face at the same t, and only the face has weights)
-    const float cz = inside ? fz : nz, cy = inside ? fy : ny;
-    const bool isz = cz == t, isy = !isz && cy == t, isx = !isz && !isy;
-    const float lx = lox + t * ldx, ly = loy + t * ldy, lz = loz + t * ldz;     // the hit point in the box's frame
+    const bool take = ok && (any || !tv.found || t < tv.best);
+    tv.found = tv.found || ok;
+    tv.best = take ? t : tv.best;
+    tv.hit.prim = take ? (int)self : tv.hit.prim;
+    return any && ok;
+}
+// ... and, after the traversal, the triangle and the weights of a hit that is still a box (h.prim >= sc.n_rec): the hit point in the box's frame,
+// the face = the axis along which it lies farthest out (|l_k| = 1 there, less on the other two; a lone quad dressed as a box of no thickness
+// says so in bit 31 of the table's high word: its l_2 is rounding noise), then (s, t) from the two OTHER coordinates and three bits per face.
+TRG_DEV void box_hit_resolve(const SceneView &sc, const Trav &tv, Hit &h) {
+    if (!kBoxHbm || h.prim < (int)sc.n_rec) return;
+    const v4f *br = sc.tris + (size_t)(uint32_t)h.prim * kRecV4;
+    const v4f b0 = br[0], b1 = br[1], b2 = br[2], b3 = br[3];
+    const V3 o = tv.o - sc.center, d = tv.d;
+    const V3 P = mk(o.x + h.t * d.x, o.y + h.t * d.y, o.z + h.t * d.z);
+    const float lx = b0.x * P.x + (b0.y * P.y + (b0.z * P.z + b0.w)), ly = b1.x * P.x + (b1.y * P.y + (b1.z * P.z + b1.w)), lz = b2.x * P.x + (b2.y * P.y + (b2.z * P.z + b2.w));
+    const float fx = fabsf(lx), fy = fabsf(ly), fz = fabsf(lz);
+    const uint32_t hiw = (uint32_t)__float_as_int(b3.w);
+    const bool isz = (hiw >> 31) != 0u || (fz >= fx && fz >= fy), isy = !isz && fy >= fx, isx = !isz && !isy;   // (bit 31: a lone quad -- its face is axis 2 whatever the noise says)
     const float lk = isx ? lx : isy ? ly : lz;
     const uint32_t f = (isx ? 0u : isy ? 2u : 4u) + (lk > 0.0f ? 1u : 0u);
-    const uint32_t tw = (uint32_t)__float_as_int(f >= 4u ? b3.w : b3.z) >> (7u * (f & 3u));
+    const uint32_t tw = (f >= 4u ? hiw : (uint32_t)__float_as_int(b3.z)) >> (7u * (f & 3u));
     const float li = isx ? ly : lx, lj = (isx || isy) ? lz : ly;               // the two other coordinates, i < j
     const bool swap = (tw & 16u) != 0u;
     const float ls = swap ? lj : li, lt = swap ? li : lj;
     const float s0 = ls * ((tw & 32u) ? -0.5f : 0.5f) + 0.5f, t0 = lt * ((tw & 64u) ? -0.5f : 0.5f) + 0.5f;
     const bool second = s0 < t0;
-    const float u = second ? s0 : s0 - t0, v = second ? t0 - s0 : t0;
-    const uint32_t rec = first + (tw & 15u) + (second ? 1u : 0u);
-    const bool closer = any || !tv.found || t < tv.best;
-    bool take = ok && closer;
-    if (ok && !closer && t == tv.best) take = fat_prim(recs, rec) < fat_prim(recs, (uint32_t)tv.hit.prim);
-    tv.found = tv.found || ok;
-    tv.best = take ? t : tv.best;
-    tv.hit.prim = take ? (int)rec : tv.hit.prim;
-    tv.hit.u = take ? u : tv.hit.u;
-    tv.hit.v = take ? v : tv.hit.v;
-    return any && ok;
+    h.u = second ? s0 : s0 - t0;
+    h.v = second ? t0 - s0 : t0;
+    h.prim = (int)((uint32_t)__float_as_int(b3.x) + (tw & 15u) + (second ? 1u : 0u));
 }
 // triangle `k` of the records starting at `tr` (LDS-resident scene): whichever test the build uses
 template <bool COUNT>
@@ -1063,7 +1078,7 @@ TRG_DEV void trav_step_wide(const SceneView &sc, Trav &tv, bool any, STK stk, Co
     if (inner) {
         trav_node4_math<COUNT, BLOCK>(q0, q1, q2, q3, tv, stk, cnt);
     } else if (kBoxHbm && boxleaf) {
-        const bool stop = trav_box_rec<COUNT>(q0, q1, q2, q3, tv, any, cnt, sc.tris, sc.center);
+        const bool stop = trav_box_rec<COUNT>(q0, q1, q2, q3, tv, any, cnt, first, sc.center);
         const int sp = tv.sp - (stop ? 0 : STK::unit);
         const int popped = stk.pop(sp);
         tv.node = stop ? kNodeDone : popped;
@@ -1139,6 +1154,8 @@ TRG_DEV bool traverse(const SceneView &sc, V3 o, V3 d, float tmax_ray, uint32_t 
         }
     }
     hit = trav_hit(tv);
+    if (UNIFIED && !ANY) box_hit_resolve(sc, tv, hit);
+    if (!UNIFIED && !ANY) lds_box_hit_resolve(sc, tv, hit);
     return tv.found;
 }
 
@@ -1171,6 +1188,7 @@ TRG_DEV void traverse_pair(const SceneView &sc, V3 org, bool has_shadow, V3 sdir
                 if (phase == 1) trav_begin(sc, tv, org, ndir, INFINITY, nmask, stk.first(), lds_node_base<UNIFIED>(sc), !UNIFIED);
             } else {
                 nhit = trav_hit(tv); nfound = tv.found;
+                if (UNIFIED) box_hit_resolve(sc, tv, nhit); else lds_box_hit_resolve(sc, tv, nhit);
                 phase = 2;
             }
         }

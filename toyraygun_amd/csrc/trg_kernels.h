@@ -70,7 +70,7 @@ struct SceneDesc {
     // ONE leaf -- child code ~(((n_fat + box index) << 3) | 6): a box is addressed like a leaf record behind the plane records, same 128-byte stride, so the
     // traversal's address arithmetic does not know about boxes -- and 64 bytes per box: rows 0..2 = (a_k, d_k), l_k = a_k . (P - center) + d_k the box's own
     // frame, row 3 = (its first leaf record, material id, face table low, high: 7 bits per face f = 2 k + (l_k > 0), 0..3 in the low word, 4..5 in
-    // the high one -- X-record offset 0..10 | swap << 4 | negate s << 5 | negate t << 6).  A scene without boxes: off_nodes4_box = off_nodes4, n_boxrec = 0.
+    // the high one -- X-record offset 0..10 | swap << 4 | negate s << 5 | negate t << 6; bit 31 of the high word: a lone quad dressed as a box).  A scene without boxes: off_nodes4_box = off_nodes4, n_boxrec = 0.
     uint32_t off_nodes4_box, off_boxrec, n_boxrec;
     // the planes are stored relative to this point (the centre of the scene's bounding box) and a ray's origin is shifted by it when its
     // traversal begins: n . o - d0 then cancels numbers of the size of the scene instead of its distance from the coordinate origin

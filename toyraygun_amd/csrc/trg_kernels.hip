@@ -74,6 +74,7 @@ TRG_DEV SceneView scene_view(const trg::SceneDesc &sc, unsigned char *smem) {
     v.n_flat = (LDS_SCENE && kTriPlanes) ? sc.n_flat : 0u;
     v.center = mk(sc.center[0], sc.center[1], sc.center[2]);
     v.tex.uv = nullptr; v.tex.ids = nullptr; v.tex.table = nullptr; v.tex.texels = nullptr;
+    v.n_rec = sc.n_fat;
     v.rec_delta = LDS_SCENE ? 0u : (kRecPlanes ? sc.off_fat_planes : sc.off_fat) - (kBoxHbm ? sc.off_nodes4_box : sc.off_nodes4);   // (>= 0: both node arrays sit before the records, trg_capi.cpp plan_scene_layout)
     return v;
 }

@@ -259,7 +259,8 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_HBM) void render_regen_k
                         V3 thr = mk(park[3 * trg::kBlock], park[4 * trg::kBlock], park[5 * trg::kBlock]);
                         V3 rad = mk(park[6 * trg::kBlock], park[7 * trg::kBlock], park[8 * trg::kBlock]);
                         if (has_shadow && !occluded) rad = rad + scol;
-                        const Hit h = trav_hit(tv);
+                        Hit h = trav_hit(tv);
+                        box_hit_resolve(sc, tv, h);      // (a hit that is still a box: its triangle and weights, named once, here)
                         V3 o = tv.o, d = tv.d;
                         uint32_t rmask = primary_ray ? 3u : 1u;
                         so = shade_event<false, true>(TRG_RG_U, sc, h, tv.found, TRG_RG_B, last, TRG_RG_HIDX, o, d, thr, rad, rmask, active, light_color, r4);
