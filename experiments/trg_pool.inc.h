@@ -81,7 +81,9 @@ TRG_DEV void trace_queue(const SceneView &sc, const PoolView pv, const unsigned 
                     if (tv.found) { v4f sh = pv.SH[slot]; sh.w = -1.0f; pv.SH[slot] = sh; }
                 } else {
                     v4f h;
-                    h.x = tv.found ? tv.best : -1.0f; h.y = __int_as_float(tv.hit.prim); h.z = tv.hit.u; h.w = tv.hit.v;
+                    Hit bh = trav_hit(tv);      // (a hit that is still a BOX gets its triangle and weights here: trg_device.h box_hit_resolve / lds_box_hit_resolve)
+                    box_hit_resolve(sc, tv, bh); lds_box_hit_resolve(sc, tv, bh);
+                    h.x = bh.t; h.y = __int_as_float(bh.prim); h.z = bh.u; h.w = bh.v;
                     pv.H[slot] = h;
                 }
                 busy = false;

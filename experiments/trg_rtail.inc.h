@@ -86,7 +86,8 @@ __global__ __launch_bounds__(trg::kBlock, TRG_EXP_WAVES_RTAIL) void render_rtail
             ShadeOut so; so.want_shadow = false; so.want_next = false; so.shaded = false; so.sdir = mk(0.0f, 0.0f, 1.0f); so.scol = mk(0.0f, 0.0f, 0.0f); so.smax = -1.0f;
             bool active = false;
             if (wait_s) {
-                const Hit h = trav_hit(tv);
+                Hit h = trav_hit(tv);
+                lds_box_hit_resolve(sc, tv, h);      // (a hit that is still a BOX: its triangle and weights)
                 uint32_t rmask = primary_ray ? 3u : 1u;
                 active = true;
                 so = shade_event<TAB>(*(const trg_uniforms *)up, sc, h, tv.found, b, last, hidx, o, d, x, rad, rmask, active, light_color);

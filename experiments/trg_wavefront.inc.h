@@ -183,7 +183,9 @@ __global__ __launch_bounds__(trg::kBlock, 8) void wf_trace_kernel(const trg::WfP
                     if (tv.found) reinterpret_cast<float *>(&w.sh[pid])[3] = -1.0f;   // occluded: nothing to add
                 } else {
                     v4f h;
-                    h.x = tv.found ? tv.best : -1.0f; h.y = __int_as_float(tv.hit.prim); h.z = tv.hit.u; h.w = tv.hit.v;
+                    Hit bh = trav_hit(tv);      // (a hit that is still a BOX gets its triangle and weights here: trg_device.h box_hit_resolve / lds_box_hit_resolve)
+                    box_hit_resolve(sc, tv, bh); lds_box_hit_resolve(sc, tv, bh);
+                    h.x = bh.t; h.y = __int_as_float(bh.prim); h.z = bh.u; h.w = bh.v;
                     wf_st(&w.hit[pid], h);
                 }
                 busy = false;
