@@ -77,7 +77,7 @@ TRG_DEV void trav_step_wide8(const SceneView &sc, Trav &tv, bool any, STK stk, C
             const uint32_t iw = (uint32_t)__float_as_int(kRecMetaFirst ? q3.x : 0.0f);
             flags = iw >> 28;
             const bool quad = (flags & 2u) != 0u;
-            stop = trav_tri_planes_rec<COUNT>(q0, q1, q2, (uint32_t)__float_as_int(q3.y), (int)(iw & 0x0FFFFFFFu), tv, any, cnt, rec, sc.tris, sc.center, quad);
+            stop = trav_tri_planes_rec<COUNT>(q0, q1, q2, (uint32_t)__float_as_int(q3.y), (int)(iw & 0x0FFFFFFFu), tv, any, cnt, rec, sc.tris, sc.center, quad, sc.n_rec);
             if (quad) flags = 0u;          // (both triangles decided: nothing more in this leaf)
         } else {
             flags = (uint32_t)__float_as_int(q2.w);

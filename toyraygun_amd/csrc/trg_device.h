@@ -864,10 +864,16 @@ TRG_DEV void lds_box_hit_resolve(const SceneView &sc, const Trav &tv, Hit &h) {
     h.v = second ? t0 - s0 : t0;
     h.prim = (int)((uint32_t)sc.meta[first + (fw >> 16) + (second ? 1u : 0u)] >> 2);
 }
+// the original index a held HBM hit stands for in the distance-tie rule: its record's, or -- a hit that is still a BOX (index >= n_rec, trav_box_rec) --
+// that of the box's first record: a box's triangles are consecutive, so any of them orders it against everything outside the box
+TRG_DEV int held_prim_index(const v4f *recs, uint32_t n_rec, int held) {
+    const uint32_t r = (uint32_t)held;
+    return fat_prim(recs, (kBoxHbm && r >= n_rec) ? (uint32_t)__float_as_int(recs[(size_t)r * kRecV4 + 3].x) : r);
+}
 // ... and on a leaf RECORD of an HBM-resident scene (the hit keeps the record index; ties go to the lower original index, read back from the
 // held record only then): mask and prim are floats 13 and 12 of the record (TRG_REC_META_FIRST; its last two words before)
 template <bool COUNT>
-TRG_DEV bool trav_tri_planes_rec(const v4f a, const v4f b, const v4f c, uint32_t mask, int prim, Trav &tv, bool any, Counters &cnt, uint32_t rec, const v4f *recs, V3 center, bool quad) {
+TRG_DEV bool trav_tri_planes_rec(const v4f a, const v4f b, const v4f c, uint32_t mask, int prim, Trav &tv, bool any, Counters &cnt, uint32_t rec, const v4f *recs, V3 center, bool quad, uint32_t n_rec) {
     const bool masked_in = (mask & tv.rmask) != 0u;
     if (COUNT) { if (masked_in) cnt.tris++; if (mbcnt64(__ballot(1)) == 0) cnt.wtris++; }
     float t, u, v;
@@ -876,7 +882,7 @@ TRG_DEV bool trav_tri_planes_rec(const v4f a, const v4f b, const v4f c, uint32_t
     rec += second ? 1u : 0u;
     const bool closer = any || !tv.found || t < tv.best;
     bool take = ok && closer;
-    if (ok && !closer && t == tv.best) take = (second ? fat_prim(recs, rec) : prim) < fat_prim(recs, (uint32_t)tv.hit.prim);
+    if (ok && !closer && t == tv.best) take = (second ? fat_prim(recs, rec) : prim) < held_prim_index(recs, n_rec, tv.hit.prim);
     tv.found = tv.found || ok;
     tv.best = take ? t : tv.best;
     tv.hit.prim = take ? (int)rec : tv.hit.prim;
@@ -888,9 +894,9 @@ TRG_DEV bool trav_tri_planes_rec(const v4f a, const v4f b, const v4f c, uint32_t
 // material id, face table low / high).  The same slab test as trav_box_planes -- and nothing else inside the traversal loop: an accepted hit keeps
 // the distance and the index of the BOX record (`self`: it sits behind the leaf records, so any index >= SceneView::n_rec says "a box, face and
 // weights still to be named"); box_hit_resolve() names them once, for the hit that survived, when the traversal is over (any-hit queries never need
-// them).  A tie in distance goes to whoever came first: which triangle of the box it is is not known yet (shipped build: undecidable either way).
+// them).
 template <bool COUNT>
-TRG_DEV bool trav_box_rec(const v4f b0, const v4f b1, const v4f b2, const v4f b3, Trav &tv, bool any, Counters &cnt, uint32_t self, V3 center) {
+TRG_DEV bool trav_box_rec(const v4f b0, const v4f b1, const v4f b2, const v4f b3, Trav &tv, bool any, Counters &cnt, uint32_t self, V3 center, const v4f *recs, uint32_t n_rec) {
     const uint32_t mask = (uint32_t)__float_as_int(b3.y);
     const bool masked_in = (mask & tv.rmask) != 0u;
     if (COUNT) { if (masked_in) cnt.tris++; if (mbcnt64(__ballot(1)) == 0) cnt.wtris++; }
@@ -904,7 +910,11 @@ TRG_DEV bool trav_box_rec(const v4f b0, const v4f b1, const v4f b2, const v4f b3
     const float tnear = fmaxf(fmaxf(mx - ax, my - ay), mz - az), tfar = fminf(fminf(mx + ax, my + ay), mz + az);
     const float t = tnear < 0.0f ? tfar : tnear;                             // (from inside: the triangles are two-sided, the ray meets the face it leaves by)
     const bool ok = (tnear <= tfar) && (t >= 0.0f) && (t <= tv.best) && masked_in;
-    const bool take = ok && (any || !tv.found || t < tv.best);
+    const bool closer = any || !tv.found || t < tv.best;
+    bool take = ok && closer;
+    // the distance-tie rule (lower original index), as far as it can be told before the triangle is named: by the box's first record (read only at
+    // bit-equal distances -- an exact duplicate of a quad, two cubes face to face)
+    if (ok && !closer && t == tv.best) take = fat_prim(recs, (uint32_t)__float_as_int(b3.x)) < held_prim_index(recs, n_rec, tv.hit.prim);
     tv.found = tv.found || ok;
     tv.best = take ? t : tv.best;
     tv.hit.prim = take ? (int)self : tv.hit.prim;
@@ -1078,7 +1088,7 @@ TRG_DEV void trav_step_wide(const SceneView &sc, Trav &tv, bool any, STK stk, Co
     if (inner) {
         trav_node4_math<COUNT, BLOCK>(q0, q1, q2, q3, tv, stk, cnt);
     } else if (kBoxHbm && boxleaf) {
-        const bool stop = trav_box_rec<COUNT>(q0, q1, q2, q3, tv, any, cnt, first, sc.center);
+        const bool stop = trav_box_rec<COUNT>(q0, q1, q2, q3, tv, any, cnt, first, sc.center, sc.tris, sc.n_rec);
         const int sp = tv.sp - (stop ? 0 : STK::unit);
         const int popped = stk.pop(sp);
         tv.node = stop ? kNodeDone : popped;
@@ -1087,7 +1097,7 @@ TRG_DEV void trav_step_wide(const SceneView &sc, Trav &tv, bool any, STK stk, Co
         // a QUAD leaf (count field 7, bvh_build.h): the shipped build decides both triangles with one parallelogram test; the strict build
         // tests record `first`, then advances to the single-triangle code of record first + 1
         const bool quad = left == kLeafQuad;
-        const bool stop = kRecPlanes ? trav_tri_planes_rec<COUNT>(q0, q1, q2, (uint32_t)__float_as_int(kRecMetaFirst ? q3.y : q3.w), __float_as_int(kRecMetaFirst ? q3.x : q3.z), tv, any, cnt, first, sc.tris, sc.center, quad)
+        const bool stop = kRecPlanes ? trav_tri_planes_rec<COUNT>(q0, q1, q2, (uint32_t)__float_as_int(kRecMetaFirst ? q3.y : q3.w), __float_as_int(kRecMetaFirst ? q3.x : q3.z), tv, any, cnt, first, sc.tris, sc.center, quad, sc.n_rec)
                                      : trav_tri_math<COUNT, true>(q0, q1, q2, tv, any, cnt, first, sc.tris);
         const bool more = kRecPlanes ? (left != 0u && !quad) : (left != 0u);
         const bool do_pop = !stop && !more;
